@@ -1,0 +1,524 @@
+// index.hip — C ABI (include/bergen_hip.h): resident flat index + exact search orchestration.
+//
+// Reference behaviour being replaced (naver/bergen):
+//   modules/retrieve.py:84-90    all chunk files loaded to HOST RAM            -> one HBM-resident index
+//   modules/retrieve.py:152-164  per query chunk: H2D of every doc chunk, torch.mm, torch.topk
+//                                                                              -> bh_scan_topk_kernel
+//   modules/retrieve.py:165-166  IOError when the index has fewer rows than the dataset
+//                                                                              -> BH_EINCOMPLETE
+//   modules/retrieve.py:169-177  host concat + fp32 topk + gather              -> bh_merge_rescore_kernel
+// There is no CPU fallback here: every entry point that computes needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bergen_hip.h"
+#include "bh_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? BH_ENOMEM : BH_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                            \
+    } while (0)
+
+struct Options {
+    int query_tile = 128;
+    int share_threshold = 1;
+    int nontemporal = 1;
+    int workgroups_per_cu = 1;
+} g_opt;
+
+int pad_dim(int dim) {
+    static const int sizes[] = {64, 128, 256, 384, 512, 768, 1024};
+    for (int s : sizes)
+        if (dim <= s) return s;
+    return -1;
+}
+
+int pick_kp(int k) {
+    if (k <= 56) return 64;
+    if (k <= 120) return 128;
+    if (k <= 248) return 256;
+    return -1;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n) {
+        if (n <= cap) return BH_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
+        cap = n;
+        return BH_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct bh_index {
+    int device = 0;
+    int n_cu = 256;
+    int64_t n_rows = 0;
+    int64_t n_tiles = 0;
+    int dim = 0, dim_padded = 0;
+    int metric = 0;
+    _Float16* rows = nullptr;
+    bool finalized = false;
+    std::vector<std::pair<int64_t, int64_t>> have;  // merged [begin, end) intervals uploaded
+    hipStream_t stream = nullptr;
+    DevBuf<bh_u64> cand, partial;
+    DevBuf<unsigned> gthr;
+    DevBuf<_Float16> qbuf;
+    DevBuf<unsigned char> staging;
+    std::vector<hipEvent_t> events;
+    bh_counters counters{};
+
+    hipEvent_t event(size_t i) {
+        while (events.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            events.push_back(e);
+        }
+        return events[i];
+    }
+};
+
+namespace {
+
+void add_interval(std::vector<std::pair<int64_t, int64_t>>& v, int64_t b, int64_t e) {
+    v.emplace_back(b, e);
+    std::sort(v.begin(), v.end());
+    std::vector<std::pair<int64_t, int64_t>> out;
+    for (auto& iv : v) {
+        if (!out.empty() && iv.first <= out.back().second)
+            out.back().second = std::max(out.back().second, iv.second);
+        else
+            out.push_back(iv);
+    }
+    v.swap(out);
+}
+
+int64_t rows_have(const bh_index* ix) {
+    int64_t n = 0;
+    for (auto& iv : ix->have) n += iv.second - iv.first;
+    return n;
+}
+
+int upload_common(bh_index* ix, int64_t row0, const void* src, int64_t n, int32_t src_dtype, bool src_on_device) {
+    if (!ix) return fail(BH_EINVAL, "null index");
+    if (n < 0 || row0 < 0 || row0 + n > ix->n_rows)
+        return fail(BH_EINVAL, "rows [%lld, %lld) outside the index (n_rows=%lld)", (long long)row0,
+                    (long long)(row0 + n), (long long)ix->n_rows);
+    if (src_dtype != BH_F16 && src_dtype != BH_F32) return fail(BH_EINVAL, "bad src_dtype %d", src_dtype);
+    if (n == 0) return BH_OK;
+    if (!src) return fail(BH_EINVAL, "null source");
+    if (ix->finalized && ix->metric == BH_METRIC_COS)
+        return fail(BH_EINVAL, "cosine index already finalized (rows are normalised in place)");
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t esz = src_dtype == BH_F16 ? 2 : 4;
+    _Float16* dst = ix->rows + (size_t)row0 * ix->dim_padded;
+    if (src_dtype == BH_F16 && ix->dim == ix->dim_padded) {
+        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * ix->dim * 2,
+                               src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
+    } else if (src_on_device) {
+        HIP_TRY(bh_launch_convert_rows(src, src_dtype, n, ix->dim, dst, ix->dim_padded, ix->stream));
+    } else {
+        // host source needing conversion/padding: stage through HBM in <= 256 MiB pieces
+        const size_t row_bytes = (size_t)ix->dim * esz;
+        int64_t rows_per = std::max<int64_t>(1, (int64_t)((256ull << 20) / row_bytes));
+        rows_per = std::min<int64_t>(rows_per, n);
+        int rc = ix->staging.ensure((size_t)rows_per * row_bytes);
+        if (rc) return rc;
+        for (int64_t r = 0; r < n; r += rows_per) {
+            const int64_t m = std::min<int64_t>(rows_per, n - r);
+            HIP_TRY(hipMemcpyAsync(ix->staging.p, (const unsigned char*)src + (size_t)r * row_bytes,
+                                   (size_t)m * row_bytes, hipMemcpyHostToDevice, ix->stream));
+            HIP_TRY(bh_launch_convert_rows(ix->staging.p, src_dtype, m, ix->dim,
+                                           dst + (size_t)r * ix->dim_padded, ix->dim_padded, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    add_interval(ix->have, row0, row0 + n);
+    return BH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bh_version(void) { return BH_VERSION; }
+const char* bh_last_error(void) { return g_err.c_str(); }
+
+int bh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bh_init(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(BH_EHIP, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(BH_EINVAL, "device %d out of range [0,%d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BH_EUNSUPPORTED, "device %d is %s; this library contains gfx950 (MI355X) code only", device_id,
+                    prop.gcnArchName);
+    return BH_OK;
+}
+
+int bh_set_option(const char* name, int64_t value) {
+    if (!name) return fail(BH_EINVAL, "null option name");
+    std::string s(name);
+    if (s == "query_tile") {
+        if (value != 128 && value != 256) return fail(BH_EINVAL, "query_tile must be 128 or 256");
+        g_opt.query_tile = (int)value;
+    } else if (s == "share_threshold") {
+        g_opt.share_threshold = value != 0;
+    } else if (s == "nontemporal") {
+        g_opt.nontemporal = value != 0;
+    } else if (s == "workgroups_per_cu") {
+        if (value != 1) return fail(BH_EINVAL, "workgroups_per_cu must be 1 (LDS ring fills the CU)");
+        g_opt.workgroups_per_cu = 1;
+    } else {
+        return fail(BH_EINVAL, "unknown option '%s'", name);
+    }
+    return BH_OK;
+}
+
+int bh_index_create(bh_index** out, int64_t n_rows, int32_t dim, int32_t dtype, int32_t metric) {
+    if (!out) return fail(BH_EINVAL, "null out");
+    *out = nullptr;
+    if (n_rows < 0 || n_rows >= 0xffffffffll) return fail(BH_EINVAL, "n_rows %lld out of range", (long long)n_rows);
+    if (dim <= 0) return fail(BH_EINVAL, "dim must be positive");
+    if (dtype != BH_F16)
+        return fail(BH_EUNSUPPORTED, "index storage dtype %d unsupported (fp16 only; fp32 sources are rounded "
+                                     "at upload like the reference's fp16 embeddings)", dtype);
+    if (metric != BH_METRIC_IP && metric != BH_METRIC_COS) return fail(BH_EINVAL, "bad metric %d", metric);
+    const int dp = pad_dim(dim);
+    if (dp < 0) return fail(BH_EUNSUPPORTED, "dim %d unsupported (max 1024)", dim);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BH_EUNSUPPORTED, "device %d is %s; gfx950 required", dev, prop.gcnArchName);
+    bh_index* ix = new bh_index();
+    ix->device = dev;
+    ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ix->n_rows = n_rows;
+    ix->n_tiles = (n_rows + 31) / 32;
+    ix->dim = dim;
+    ix->dim_padded = dp;
+    ix->metric = metric;
+    const size_t bytes = std::max<size_t>((size_t)ix->n_tiles * 32 * dp * 2, 64);
+    hipError_t e = hipMalloc((void**)&ix->rows, bytes);
+    if (e != hipSuccess) {
+        delete ix;
+        return fail(e == hipErrorOutOfMemory ? BH_ENOMEM : BH_EHIP, "hipMalloc(%zu bytes) for the index: %s", bytes,
+                    hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        (void)hipFree(ix->rows);
+        delete ix;
+        return fail(BH_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    // zero the row padding of the last tile (and the column padding when the source is dense fp16)
+    if (n_rows % 32 != 0 || dim != dp) {
+        const size_t tail_from = (dim != dp) ? 0 : (size_t)n_rows * dp * 2;
+        e = hipMemsetAsync((unsigned char*)ix->rows + tail_from, 0, bytes - tail_from, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        if (e != hipSuccess) {
+            bh_index_destroy(ix);
+            return fail(BH_EHIP, "memset: %s", hipGetErrorString(e));
+        }
+    }
+    *out = ix;
+    return BH_OK;
+}
+
+void bh_index_destroy(bh_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    for (auto e : ix->events) (void)hipEventDestroy(e);
+    ix->cand.release();
+    ix->partial.release();
+    ix->gthr.release();
+    ix->qbuf.release();
+    ix->staging.release();
+    if (ix->rows) (void)hipFree(ix->rows);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+int bh_index_upload(bh_index* ix, int64_t row0, const void* host_rows, int64_t n, int32_t src_dtype) {
+    return upload_common(ix, row0, host_rows, n, src_dtype, false);
+}
+int bh_index_upload_device(bh_index* ix, int64_t row0, const void* dev_rows, int64_t n, int32_t src_dtype) {
+    return upload_common(ix, row0, dev_rows, n, src_dtype, true);
+}
+
+int64_t bh_index_rows_uploaded(const bh_index* ix) { return ix ? rows_have(ix) : 0; }
+
+int bh_index_finalize(bh_index* ix) {
+    if (!ix) return fail(BH_EINVAL, "null index");
+    const int64_t have = rows_have(ix);
+    if (have != ix->n_rows)
+        return fail(BH_EINCOMPLETE, "!!! Index is not complete. Please re-index. Missing %lld documents in the index. !!!",
+                    (long long)(ix->n_rows - have));
+    if (ix->finalized) return BH_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    if (ix->metric == BH_METRIC_COS) {
+        HIP_TRY(bh_launch_l2_normalize_rows(ix->rows, ix->n_rows, ix->dim, ix->dim_padded, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    ix->finalized = true;
+    return BH_OK;
+}
+
+int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                     float* out_scores_dev, int64_t* out_ids_dev) {
+    if (!ix) return fail(BH_EINVAL, "null index");
+    if (!ix->finalized) {
+        const int64_t have = rows_have(ix);
+        if (have != ix->n_rows)
+            return fail(BH_EINCOMPLETE,
+                        "!!! Index is not complete. Please re-index. Missing %lld documents in the index. !!!",
+                        (long long)(ix->n_rows - have));
+        return fail(BH_EINVAL, "index not finalized");
+    }
+    if (nq < 0 || k <= 0) return fail(BH_EINVAL, "nq=%d k=%d", nq, k);
+    if (q_dtype != BH_F16 && q_dtype != BH_F32) return fail(BH_EINVAL, "bad q_dtype %d", q_dtype);
+    const int kp = pick_kp(k);
+    if (kp < 0) return fail(BH_EUNSUPPORTED, "k=%d unsupported (max 248)", k);
+    if (nq == 0) return BH_OK;
+    if (!q_dev || !out_scores_dev || !out_ids_dev) return fail(BH_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+
+    const int dp = ix->dim_padded;
+    int qw = (g_opt.query_tile == 256 && bh_scan_supports(dp, kp, 2)) ? 2 : 1;
+    const int bq = 128 * qw;
+    const int n_pass = (nq + bq - 1) / bq;
+    const int64_t nq_pad = (int64_t)n_pass * bq;
+    const int grid = ix->n_cu * g_opt.workgroups_per_cu;
+
+    int rc;
+    if ((rc = ix->qbuf.ensure((size_t)nq_pad * dp))) return rc;
+    if ((rc = ix->cand.ensure((size_t)grid * bq * 2 * kp))) return rc;
+    if ((rc = ix->partial.ensure((size_t)grid * bq * kp))) return rc;
+    if ((rc = ix->gthr.ensure((size_t)bq))) return rc;
+
+    hipStream_t st = ix->stream;
+    // queries -> padded fp16 tile buffer (zero rows beyond nq)
+    if (nq_pad > nq) HIP_TRY(hipMemsetAsync(ix->qbuf.p + (size_t)nq * dp, 0, (size_t)(nq_pad - nq) * dp * 2, st));
+    HIP_TRY(bh_launch_convert_rows(q_dev, q_dtype, nq, ix->dim, ix->qbuf.p, dp, st));
+    if (ix->metric == BH_METRIC_COS) HIP_TRY(bh_launch_l2_normalize_rows(ix->qbuf.p, nq, ix->dim, dp, st));
+
+    hipEvent_t ev_begin = ix->event(0), ev_end = ix->event(1);
+    if (!ev_begin || !ev_end) return fail(BH_EHIP, "hipEventCreate failed");
+    for (int p = 0; p < n_pass; ++p)
+        if (!ix->event(2 + 3 * p + 2)) return fail(BH_EHIP, "hipEventCreate failed");
+
+    HIP_TRY(hipEventRecord(ev_begin, st));
+    for (int p = 0; p < n_pass; ++p) {
+        const int q0 = p * bq;
+        const int nq_tile = std::min(bq, nq - q0);
+        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, bq, 0x007fffffu, st));
+        BhScanArgs sa;
+        sa.corpus = ix->rows;
+        sa.n_rows = ix->n_rows;
+        sa.n_tiles = ix->n_tiles;
+        sa.qtile = ix->qbuf.p + (size_t)q0 * dp;
+        sa.cand = ix->cand.p;
+        sa.partial = ix->partial.p;
+        sa.gthr = ix->gthr.p;
+        sa.share = g_opt.share_threshold;
+        sa.nontemporal = g_opt.nontemporal;
+        HIP_TRY(hipEventRecord(ix->event(2 + 3 * p), st));
+        HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
+        HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 1), st));
+        BhMergeArgs ma;
+        ma.partial = ix->partial.p;
+        ma.n_lists = grid;
+        ma.bq = bq;
+        ma.corpus = ix->rows;
+        ma.n_rows = ix->n_rows;
+        ma.qtile = sa.qtile;
+        ma.dim_padded = dp;
+        ma.k = k;
+        ma.id_offset = id_offset;
+        ma.out_scores = out_scores_dev + (size_t)q0 * k;
+        ma.out_ids = reinterpret_cast<long long*>(out_ids_dev) + (size_t)q0 * k;
+        HIP_TRY(bh_launch_merge_rescore(ma, kp, nq_tile, st));
+        HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 2), st));
+    }
+    HIP_TRY(hipEventRecord(ev_end, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    bh_counters& c = ix->counters;
+    c.n_rows = ix->n_rows;
+    c.dim = ix->dim;
+    c.dim_padded = dp;
+    c.query_tile = bq;
+    c.n_passes = n_pass;
+    c.n_workgroups = grid;
+    c.k_padded = kp;
+    c.scan_ms = 0;
+    c.merge_ms = 0;
+    for (int p = 0; p < n_pass; ++p) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 3 * p), ix->event(2 + 3 * p + 1)));
+        c.scan_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 3 * p + 1), ix->event(2 + 3 * p + 2)));
+        c.merge_ms += ms;
+    }
+    float tot = 0;
+    HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
+    c.total_ms = tot;
+    // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
+    c.algorithmic_bytes =
+        (double)n_pass * ((double)ix->n_rows * ix->dim * 2.0 + (double)bq * ix->dim * 2.0 + (double)bq * k * 12.0);
+    return BH_OK;
+}
+
+int bh_search(bh_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+              float* out_scores, int64_t* out_ids) {
+    if (!ix) return fail(BH_EINVAL, "null index");
+    if (nq < 0 || k <= 0) return fail(BH_EINVAL, "nq=%d k=%d", nq, k);
+    if (q_dtype != BH_F16 && q_dtype != BH_F32) return fail(BH_EINVAL, "bad q_dtype %d", q_dtype);
+    if (nq == 0) return bh_search_device(ix, nullptr, q_dtype, 0, k, id_offset, nullptr, nullptr);
+    if (!q_host || !out_scores || !out_ids) return fail(BH_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t esz = q_dtype == BH_F16 ? 2 : 4;
+    const size_t qbytes = (size_t)nq * ix->dim * esz;
+    const size_t sbytes = (size_t)nq * k * sizeof(float), ibytes = (size_t)nq * k * sizeof(int64_t);
+    unsigned char* tmp = nullptr;
+    const size_t off_s = (qbytes + 255) & ~(size_t)255, off_i = off_s + ((sbytes + 255) & ~(size_t)255);
+    HIP_TRY(hipMalloc((void**)&tmp, off_i + ibytes));
+    int rc = BH_OK;
+    hipError_t e = hipMemcpy(tmp, q_host, qbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(BH_EHIP, "H2D queries: %s", hipGetErrorString(e));
+    if (rc == BH_OK)
+        rc = bh_search_device(ix, tmp, q_dtype, nq, k, id_offset, (float*)(tmp + off_s), (int64_t*)(tmp + off_i));
+    if (rc == BH_OK) {
+        e = hipMemcpy(out_scores, tmp + off_s, sbytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(out_ids, tmp + off_i, ibytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(BH_EHIP, "D2H results: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int bh_merge_topk_device(const float* scores_dev, const int64_t* ids_dev, int32_t n_lists, int32_t nq, int32_t k,
+                         float* out_scores_dev, int64_t* out_ids_dev) {
+    if (n_lists <= 0 || nq < 0 || k <= 0) return fail(BH_EINVAL, "n_lists=%d nq=%d k=%d", n_lists, nq, k);
+    if (nq == 0) return BH_OK;
+    if (!scores_dev || !ids_dev || !out_scores_dev || !out_ids_dev) return fail(BH_EINVAL, "null buffer");
+    if (k > 4096) return fail(BH_EUNSUPPORTED, "k=%d too large", k);
+    const int group = std::max(1, 4096 / k);  // lists merged per launch
+    if (n_lists <= group) {
+        HIP_TRY(bh_launch_merge_lists(scores_dev, reinterpret_cast<const long long*>(ids_dev), n_lists, nq, k,
+                                      out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return BH_OK;
+    }
+    if (group < 2) return fail(BH_EUNSUPPORTED, "k=%d too large to merge %d lists", k, n_lists);
+    // tree reduction: merge `group` lists at a time into a scratch set of lists
+    const int n_mid = (n_lists + group - 1) / group;
+    float* mid_s = nullptr;
+    long long* mid_i = nullptr;
+    HIP_TRY(hipMalloc((void**)&mid_s, (size_t)n_mid * nq * k * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&mid_i, (size_t)n_mid * nq * k * sizeof(long long));
+    if (e != hipSuccess) {
+        (void)hipFree(mid_s);
+        return fail(BH_ENOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = BH_OK;
+    for (int g = 0; g < n_mid && rc == BH_OK; ++g) {
+        const int l0 = g * group, nl = std::min(group, n_lists - l0);
+        e = bh_launch_merge_lists(scores_dev + (size_t)l0 * nq * k,
+                                  reinterpret_cast<const long long*>(ids_dev) + (size_t)l0 * nq * k, nl, nq, k,
+                                  mid_s + (size_t)g * nq * k, mid_i + (size_t)g * nq * k, nullptr);
+        if (e != hipSuccess) rc = fail(BH_EHIP, "merge launch: %s", hipGetErrorString(e));
+    }
+    if (rc == BH_OK) {
+        e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) rc = fail(BH_EHIP, "merge: %s", hipGetErrorString(e));
+    }
+    if (rc == BH_OK)
+        rc = bh_merge_topk_device(mid_s, reinterpret_cast<const int64_t*>(mid_i), n_mid, nq, k, out_scores_dev,
+                                  out_ids_dev);
+    (void)hipFree(mid_s);
+    (void)hipFree(mid_i);
+    return rc;
+}
+
+int bh_merge_topk(const float* scores, const int64_t* ids, int32_t n_lists, int32_t nq, int32_t k, float* out_scores,
+                  int64_t* out_ids) {
+    if (n_lists <= 0 || nq < 0 || k <= 0) return fail(BH_EINVAL, "n_lists=%d nq=%d k=%d", n_lists, nq, k);
+    if (nq == 0) return BH_OK;
+    if (!scores || !ids || !out_scores || !out_ids) return fail(BH_EINVAL, "null buffer");
+    const size_t n_in = (size_t)n_lists * nq * k, n_out = (size_t)nq * k;
+    float* d_s = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_s, (n_in + n_out) * (sizeof(float) + sizeof(int64_t)) + 8));
+    int64_t* d_i = reinterpret_cast<int64_t*>(d_s + n_in + n_out + ((n_in + n_out) & 1));
+    // layout: [scores in | scores out | pad] [ids in | ids out]
+    float* d_so = d_s + n_in;
+    int64_t* d_io = d_i + n_in;
+    int rc = BH_OK;
+    hipError_t e = hipMemcpy(d_s, scores, n_in * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_i, ids, n_in * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(BH_EHIP, "H2D: %s", hipGetErrorString(e));
+    if (rc == BH_OK) rc = bh_merge_topk_device(d_s, d_i, n_lists, nq, k, d_so, d_io);
+    if (rc == BH_OK) {
+        e = hipMemcpy(out_scores, d_so, n_out * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(out_ids, d_io, n_out * sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(BH_EHIP, "D2H: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_s);
+    return rc;
+}
+
+int bh_bench_counters(const bh_index* ix, bh_counters* out) {
+    if (!ix || !out) return fail(BH_EINVAL, "null argument");
+    *out = ix->counters;
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// merge_rescore.hip — per-query merge of the scan's per-workgroup candidate lists, canonical
+// fp64 re-scoring of the merged best KP, final sort and cut to k.
+//
+// Replaces the reference's host merge `torch.cat` -> `.cpu().float()` -> `torch.topk` ->
+// `torch.gather` (modules/retrieve.py:169-177), which orders ties arbitrarily.
+//
+// One 256-thread workgroup per query:
+//   1. each of the 4 waves folds every 4th workgroup list (sorted, KP keys) into a running
+//      best-KP with a bitonic merge held in registers (lists whose best key cannot enter the
+//      running list are skipped after one 8-byte load);
+//   2. the 4 running lists are combined through LDS by wave 0;
+//   3. thread i re-scores candidate i: canonical score = fp32(sum_{j=0..d-1} q[j]*x[j]) with
+//      the sum taken sequentially in fp64 (products of fp16 values are exact in fp64, so the
+//      result does not depend on FMA contraction and is reproducible bit-for-bit by the
+//      oracle's plain C loop);
+//   4. wave 0 sorts the KP canonical keys (score desc, row asc) and writes the first k.
+// Roofline: latency / L2 (KP x d x 2 bytes gathered per query); negligible next to the scan.
+#include "bh_device.h"
+#include "bh_kernels.h"
+
+template <int KP>
+__global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
+    constexpr int EPL = KP / 64;
+    __shared__ u64 lds_keys[4 * KP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x;  // query inside the tile
+    const size_t list_stride = (size_t)a.bq * KP;
+    const u64* base = a.partial + (size_t)q * KP;
+
+    // ---- 1. fold lists wave, wave+4, ...
+    u64 acc[EPL];
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) acc[r] = 0ull;
+    for (int g = wave; g < a.n_lists; g += 4) {
+        const u64* lst = base + (size_t)g * list_stride;
+        const u64 best = lst[0];                            // uniform load
+        const u64 worst = bh_shfl64(acc[EPL - 1], 63);      // running KP-th best
+        if (best <= worst) continue;                        // cannot contribute (covers empty lists)
+        u64 b[EPL];
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) b[r] = lst[r * 64 + lane];
+        bh_wave_merge_top<EPL>(acc, b, lane);
+    }
+    // ---- 2. combine the 4 waves
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) lds_keys[wave * KP + r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            u64 b[EPL];
+#pragma unroll
+            for (int r = 0; r < EPL; ++r) b[r] = lds_keys[w * KP + r * 64 + lane];
+            bh_wave_merge_top<EPL>(acc, b, lane);
+        }
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) lds_keys[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    // ---- 3. canonical re-scoring, one candidate per thread
+    if (tid < KP) {
+        const u64 key = lds_keys[tid];
+        u64 out = 0ull;
+        const unsigned row = bh_key_row(key);
+        if (key != 0ull && (long long)row < a.n_rows) {
+            const half8* x = reinterpret_cast<const half8*>(a.corpus + (size_t)row * a.dim_padded);
+            const half8* qv = reinterpret_cast<const half8*>(a.qtile + (size_t)q * a.dim_padded);
+            double s = 0.0;
+            const int n8 = a.dim_padded >> 3;
+            for (int j = 0; j < n8; ++j) {
+                const half8 xv = x[j];
+                const half8 qq = qv[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = __builtin_fma((double)qq[e], (double)xv[e], s);
+            }
+            out = bh_make_key((float)s, row);
+        }
+        lds_keys[KP + tid] = out;
+    }
+    __syncthreads();
+    // ---- 4. final sort + output
+    if (wave == 0) {
+        u64 e[EPL];
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) e[r] = lds_keys[KP + r * 64 + lane];
+        bh_wave_sort_desc<EPL>(e, lane);
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const int i = r * 64 + lane;
+            if (i < a.k) {
+                const bool valid = e[r] != 0ull;
+                a.out_scores[(size_t)q * a.k + i] = valid ? bh_key_score(e[r]) : -__builtin_inff();
+                a.out_ids[(size_t)q * a.k + i] = valid ? a.id_offset + (long long)bh_key_row(e[r]) : -1ll;
+            }
+        }
+    }
+}
+
+hipError_t bh_launch_merge_rescore(const BhMergeArgs& a, int kp, int nq_tile, hipStream_t stream) {
+    if (nq_tile <= 0) return hipSuccess;
+    switch (kp) {
+        case 64: hipLaunchKernelGGL(bh_merge_rescore_kernel<64>, dim3(nq_tile), dim3(256), 0, stream, a); break;
+        case 128: hipLaunchKernelGGL(bh_merge_rescore_kernel<128>, dim3(nq_tile), dim3(256), 0, stream, a); break;
+        case 256: hipLaunchKernelGGL(bh_merge_rescore_kernel<256>, dim3(nq_tile), dim3(256), 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

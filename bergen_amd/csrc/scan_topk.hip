@@ -1,0 +1,333 @@
+// scan_topk.hip — fused inner-product + running top-k scan over a resident fp16 corpus.
+//
+// Replaces, in one kernel, the reference's per-chunk  torch.mm  (models/retrievers/dense.py:81)
+// + torch.topk (modules/retrieve.py:157): the [Bq, n] score matrix is never materialised.
+//
+// Roofline: HBM.  One launch reads every corpus row exactly once (N*d*2 bytes) for a tile of
+// BQ = 128*QW queries; arithmetic intensity = BQ flop/byte, below the gfx950 ridge (~310).
+//
+// Work decomposition (gfx950: 256 CUs, wave64, 160 KiB LDS, 512 regs/lane at 1 wave/SIMD)
+//   * persistent grid, one 256-thread workgroup (4 waves, one per SIMD) per CU;
+//     workgroup b walks row tiles t = b, b+G, b+2G, ... (32 rows each, ascending).
+//   * QUERIES LIVE IN REGISTERS: wave w keeps queries [32w*QW, 32w*QW+32*QW) of the tile as
+//     MFMA B-fragments, pinned in the ACCUMULATOR half of the register file (AGPRs; MFMA reads
+//     B straight from them) for the whole launch — d=768: 192 regs/lane per 32 queries.  The
+//     register file is the largest on-chip store (512 KiB/CU) and this costs zero re-reads.
+//   * CORPUS STREAMS THROUGH LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR round trip)
+//     into an R-deep ring of stages; a stage = 32 rows x LS 128-byte lines.  All 4 waves read
+//     every stage (each against its own queries) with conflict-free ds_read_b128, software
+//     pipelined one line (4 fragments) ahead of the MFMAs.
+//   * v_mfma_f32_32x32x16_f16, A = 32 corpus rows, B = 32 queries, fp32 accumulate: lane l ends
+//     up with 16 scores of ONE query (l & 31)  ->  one threshold register per lane.
+//   * top-k: per-query threshold compare (15 v_max + 1 v_cmp per tile); survivors are
+//     appended to a per-(workgroup, query) candidate buffer in global memory (L2-resident),
+//     slot counters live in registers (both half-lanes of a query keep identical copies);
+//     when a buffer nears capacity the owning wave bitonic-sorts it, keeps the best KP and
+//     raises the threshold.  Thresholds may additionally be shared between workgroups
+//     through one agent-scope atomicMax word per query — a pure filter hint: a stale value
+//     only means less filtering, never a wrong result.
+//
+// LDS image / bank conflicts.  One LDS-DMA instruction writes 1 KiB lane-linearly
+// (dest = base + lane*16).  Lanes 8j..8j+7 fetch the eight 16-byte chunks of ONE 128-byte
+// line of row 8*rg+j (full-line coalescing), with the chunk order XOR-permuted by
+// g(row) = ((row>>1)&1) | ((row>>3)<<1).  The MFMA A-fragment read (lane l: row l&31, chunk
+// 2*j4 + (l>>5)) then hits 16 distinct 16-byte slots in each of ds_read_b128's four 16-lane
+// service groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) => conflict-free.
+//
+// Exactness.  The scan ranks by the fp32 MFMA score and keeps KP >= k+8 candidates per
+// workgroup; merge_rescore.hip re-scores the merged best KP in sequential fp64 (the
+// canonical score) and cuts to k.  The threshold logic can only drop a row that at least KP
+// better rows (score desc, row asc) beat, so the merged top-KP is independent of timing.
+#include "bh_device.h"
+#include "bh_kernels.h"
+
+namespace {
+
+template <int EPL>
+__device__ __forceinline__ void load_list(u64 (&e)[EPL], const u64* buf, unsigned n, int lane) {
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const unsigned idx = r * 64 + lane;
+        e[r] = idx < n ? buf[idx] : 0ull;
+    }
+}
+
+// Sort one query's candidate buffer (n <= 2*KP entries) with the whole wave; on return
+// e[0 .. KP/64) hold the best KP keys, sorted descending (element i = r*64 + lane).
+template <int KP>
+__device__ __forceinline__ void sort_candidates(u64 (&e)[2 * KP / 64], const u64* buf, unsigned n, int lane) {
+    load_list<2 * KP / 64>(e, buf, n, lane);
+    bh_wave_sort_desc<2 * KP / 64>(e, lane);
+}
+
+}  // namespace
+
+// NK = padded dim / 16 (MFMA k-steps per row); KP = candidate list length (64|128|256);
+// LS = 128-byte lines per stage; R = ring depth in stages; QW = 32-query blocks per wave;
+// NT = non-temporal cache policy on the corpus stream.
+template <int NK, int KP, int LS, int R, int QW, bool NT>
+__global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = NK * 16;
+    constexpr int LINES = D / 64;
+    static_assert(LINES % LS == 0, "stage must divide the row");
+    constexpr int S = LINES / LS;  // stages per 32-row tile
+    constexpr int STAGE_BYTES = 32 * LS * 128;
+    constexpr int CAP = 2 * KP;
+    constexpr int EPLC = CAP / 64;
+    constexpr int EPLK = KP / 64;
+    constexpr int BQ = 128 * QW;
+    constexpr int ROW_BYTES = D * 2;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    const int ql = lane & 31, h = lane >> 5;
+
+    const long long my_tiles = (a.n_tiles > b) ? (a.n_tiles - b + G - 1) / G : 0;
+    u64* cand_wg = a.cand + (size_t)b * BQ * CAP;
+    u64* part_wg = a.partial + (size_t)b * BQ * KP;
+
+    // ---- queries -> registers (B fragments).  Lane (ql, h) holds, for k-step s, the 8 halfs
+    // at k = 16 s + 8 h of query  (wave*QW + w2)*32 + ql.  All loads first, then pin to AGPRs.
+    half8 qf[QW][NK];
+#pragma unroll
+    for (int w2 = 0; w2 < QW; ++w2) {
+        const _Float16* qrow = a.qtile + (size_t)((wave * QW + w2) * 32 + ql) * D;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) qf[w2][s] = *reinterpret_cast<const half8*>(qrow + (2 * s + h) * 8);
+    }
+#pragma unroll
+    for (int w2 = 0; w2 < QW; ++w2)
+#pragma unroll
+        for (int s = 0; s < NK; ++s) asm volatile("" : "+a"(qf[w2][s]));
+
+    float thr[QW];     // candidate iff score > thr   (per lane = per query)
+    unsigned cnt[QW];  // entries in the query's candidate buffer (identical in both half-lanes)
+#pragma unroll
+    for (int w2 = 0; w2 < QW; ++w2) {
+        thr[w2] = -__builtin_inff();
+        cnt[w2] = 0;
+    }
+
+    // ---- per-lane constants of the LDS-DMA source pattern and of the fragment reads
+    const int ld_row = 8 * wave + (lane >> 3);         // row inside the tile this lane fetches
+    const int ld_g = ((lane >> 4) & 1) | (wave << 1);  // g(ld_row)
+    const unsigned ld_off = (unsigned)ld_row * ROW_BYTES + (unsigned)(((lane & 7) ^ ld_g) << 4);
+    const int rd_g = ((ql >> 1) & 1) | ((ql >> 3) << 1);  // g(row = ql)
+    unsigned rd_off[4];
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4)
+        rd_off[j4] = (unsigned)((ql >> 3) * 1024 + (ql & 7) * 128 + (((2 * j4 + h) ^ rd_g) << 4));
+
+    // Compact query qq (of block w2) of this wave: sort, keep best KP, raise its threshold.
+    auto compact = [&](int w2, int qq) {
+        const int qi = (wave * QW + w2) * 32 + qq;
+        const unsigned n = __builtin_amdgcn_readlane(cnt[w2], qq);
+        u64* buf = cand_wg + (size_t)qi * CAP;
+        u64 e[EPLC];
+        sort_candidates<KP>(e, buf, n, lane);
+#pragma unroll
+        for (int r = 0; r < EPLK; ++r) buf[r * 64 + lane] = e[r];
+        if (ql == qq) cnt[w2] = n < (unsigned)KP ? n : (unsigned)KP;
+        const u64 kth = bh_shfl64(e[EPLK - 1], 63);
+        if (kth != 0ull) {
+            // Rows arrive in ascending order inside a workgroup, so a later row that merely
+            // TIES the KP-th best loses on row index: the exclusive compare is exact.
+            const float nt = bh_key_score(kth);
+            if (ql == qq) thr[w2] = fmaxf(thr[w2], nt);
+            if (a.share && lane == 0)
+                __hip_atomic_fetch_max(a.gthr + qi, (unsigned)(kth >> 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    if (my_tiles > 0) {
+        const unsigned char* corpus = reinterpret_cast<const unsigned char*>(a.corpus);
+        // issue cursor: (tile ordinal it, part ip) of the next stage to fetch, and its ring slot
+        long long it = 0;
+        int ip = 0;
+        int islot = 0;
+        auto issue_stage = [&]() {
+            const long long itc = it < my_tiles ? it : my_tiles - 1;  // past the end: harmless re-fetch,
+            const long long tile = b + itc * G;                       // keeps the vmcnt arithmetic uniform
+            const unsigned char* src = corpus + (size_t)tile * 32 * ROW_BYTES + (size_t)ip * LS * 128 + ld_off;
+            unsigned char* dst = smem + islot * STAGE_BYTES + wave * 1024;
+#pragma unroll
+            for (int j = 0; j < LS; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 128),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0,
+                                                 NT ? 2 : 0);
+            if (++ip == S) { ip = 0; ++it; }
+            if (++islot == R) islot = 0;
+        };
+#pragma unroll
+        for (int p = 0; p < R - 1; ++p) issue_stage();
+
+        int cslot = 0;  // ring slot of the stage being consumed
+        for (long long i = 0; i < my_tiles; ++i) {
+            floatx16 acc[QW];
+#pragma unroll
+            for (int w2 = 0; w2 < QW; ++w2)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[w2][v] = 0.f;
+
+#pragma unroll
+            for (int part = 0; part < S; ++part) {
+                // Own LDS-DMA of this stage landed (R-2 younger stages may stay in flight), then
+                // rendezvous: everybody's pieces landed AND everybody is done reading the slot
+                // that the next issue overwrites.
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * LS) : "memory");
+                issue_stage();
+                const unsigned char* st = smem + cslot * STAGE_BYTES;
+                // fragment reads run one 128-byte line (4 k-steps) ahead of the MFMAs
+                half8 af[2][4];
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) af[0][j4] = *reinterpret_cast<const half8*>(st + rd_off[j4]);
+#pragma unroll
+                for (int jl = 0; jl < LS; ++jl) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jl + 1 < LS) {
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4)
+                            af[(jl + 1) & 1][j4] =
+                                *reinterpret_cast<const half8*>(st + (jl + 1) * 4096 + rd_off[j4]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                        for (int w2 = 0; w2 < QW; ++w2)
+                            acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                af[jl & 1][j4], qf[w2][(part * LS + jl) * 4 + j4], acc[w2], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (++cslot == R) cslot = 0;
+            }
+
+            // ---- epilogue: threshold filter ------------------------------------------------
+            const long long row0 = (b + i * G) * 32;
+#pragma unroll
+            for (int w2 = 0; w2 < QW; ++w2) {
+                float m = acc[w2][0];
+#pragma unroll
+                for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[w2][v]);
+                if (__builtin_amdgcn_ballot_w64(m > thr[w2]) != 0ull) {
+                    // (1) make room: a tile adds at most 32 entries per query
+                    u64 need = __builtin_amdgcn_ballot_w64(cnt[w2] > (unsigned)(CAP - 32)) & 0xffffffffull;
+                    while (need) {
+                        const int qq = __builtin_ctzll(need);
+                        need &= need - 1;
+                        compact(w2, qq);
+                    }
+                    // (2) append survivors; slot = cnt + (hits of the same query in lower lanes)
+                    u64* buf = cand_wg + (size_t)((wave * QW + w2) * 32 + ql) * CAP;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const long long row = row0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                        const bool hit = (acc[w2][v] > thr[w2]) && (row < a.n_rows);
+                        const u64 hm = __builtin_amdgcn_ballot_w64(hit);
+                        if (hm != 0ull) {
+                            const unsigned hl = ((unsigned)hm >> ql) & 1u;
+                            const unsigned hh = ((unsigned)(hm >> 32) >> ql) & 1u;
+                            if (hit) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
+                            cnt[w2] += hl + hh;
+                        }
+                    }
+                }
+            }
+            // ---- pick up thresholds published by other workgroups (filter hint only) --------
+            if (a.share && (i & 7) == 7) {
+#pragma unroll
+                for (int w2 = 0; w2 < QW; ++w2) {
+                    const int q = (wave * QW + w2) * 32 + ql;
+                    const unsigned g = __hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // a row that TIES a foreign KP-th best may still win on row index: inclusive
+                    // compare, i.e. exclusive against the next lower float
+                    if (g > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(g - 1u));
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail re-fetches
+    }
+
+    // ---- final: every wave sorts its queries' buffers and publishes the best KP -------------
+#pragma unroll
+    for (int w2 = 0; w2 < QW; ++w2) {
+        for (int qq = 0; qq < 32; ++qq) {
+            const int qi = (wave * QW + w2) * 32 + qq;
+            const unsigned n = __builtin_amdgcn_readlane(cnt[w2], qq);
+            u64 e[EPLC];
+            sort_candidates<KP>(e, cand_wg + (size_t)qi * CAP, n, lane);
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = e[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+
+template <int NK, int KP, int LS, int R, int QW, bool NT>
+static hipError_t launch_one(const BhScanArgs& a, int grid, hipStream_t stream) {
+    constexpr size_t smem = (size_t)R * 32 * LS * 128;
+    static bool attr_done = false;
+    auto kern = bh_scan_topk_kernel<NK, KP, LS, R, QW, NT>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int NK, int LS, int R, int QW>
+static hipError_t launch_kp(const BhScanArgs& a, int kp, int grid, hipStream_t stream) {
+    const bool nt = a.nontemporal != 0;
+    switch (kp) {
+        case 64:
+            return nt ? launch_one<NK, 64, LS, R, QW, true>(a, grid, stream)
+                      : launch_one<NK, 64, LS, R, QW, false>(a, grid, stream);
+        case 128:
+            return nt ? launch_one<NK, 128, LS, R, QW, true>(a, grid, stream)
+                      : launch_one<NK, 128, LS, R, QW, false>(a, grid, stream);
+        case 256:
+            if constexpr (QW == 1)
+                return nt ? launch_one<NK, 256, LS, R, QW, true>(a, grid, stream)
+                          : launch_one<NK, 256, LS, R, QW, false>(a, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int NK, int LS, int R>
+static hipError_t launch_qw(const BhScanArgs& a, int kp, int qw, int grid, hipStream_t stream) {
+    if (qw == 1) return launch_kp<NK, LS, R, 1>(a, kp, grid, stream);
+    if constexpr (NK == 48 || NK == 24) {
+        if (qw == 2) return launch_kp<NK, LS, R, 2>(a, kp, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// dim_padded in {64,128,256,384,512,768,1024}
+hipError_t bh_launch_scan(const BhScanArgs& a, int dim_padded, int kp, int qw, int grid, hipStream_t stream) {
+    switch (dim_padded) {
+        case 64: return launch_qw<4, 1, 6>(a, kp, qw, grid, stream);
+        case 128: return launch_qw<8, 2, 6>(a, kp, qw, grid, stream);
+        case 256: return launch_qw<16, 4, 6>(a, kp, qw, grid, stream);
+        case 384: return launch_qw<24, 6, 6>(a, kp, qw, grid, stream);
+        case 512: return launch_qw<32, 8, 4>(a, kp, qw, grid, stream);
+        case 768: return launch_qw<48, 6, 6>(a, kp, qw, grid, stream);
+        case 1024: return launch_qw<64, 8, 4>(a, kp, qw, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// Query-tile widths: 128 everywhere; 256 (two 32-query blocks per wave) for d in {384, 768}
+// with candidate lists up to 128.
+bool bh_scan_supports(int dim_padded, int kp, int qw) {
+    if (qw == 1) return true;
+    return qw == 2 && (dim_padded == 768 || dim_padded == 384) && kp <= 128;
+}

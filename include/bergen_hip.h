@@ -1,0 +1,130 @@
+/*
+ * bergen_hip.h — C ABI of the MI355X-native dense-retrieval backend for BERGEN.
+ *
+ * The reference (naver/bergen) has no FFI: its retrieval hot path is Python calling
+ * torch ops.  This header is the boundary a replacement exports so that the reference's
+ * `modules.retrieve.Retrieve` (stage seam, reference modules/retrieve.py:20-108) can be
+ * backed by hand-written gfx950 kernels.  Each entry point cites the reference code it
+ * replaces.  INTEGRATION.md shows the ctypes binding a BERGEN maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative bh_status; it never throws;
+ *     a thread-local message is available from bh_last_error().
+ *   - host buffers are owned by the caller and must stay alive for the duration of the
+ *     call; all calls are synchronous (they return after the device work has finished).
+ *   - device memory and the opaque bh_index are owned by the library.
+ *   - matrices are row-major, C-contiguous.
+ *   - there is NO CPU fallback in this library: without a HIP device bh_init fails.
+ */
+#ifndef BERGEN_HIP_H
+#define BERGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_VERSION 100 /* 0.1.0 */
+
+typedef enum bh_status {
+    BH_OK = 0,
+    BH_EINVAL = -1,      /* invalid argument */
+    BH_EHIP = -2,        /* HIP runtime error */
+    BH_ENOMEM = -3,      /* out of device memory */
+    BH_EINCOMPLETE = -4, /* index rows missing (reference: IOError at retrieve.py:165-166) */
+    BH_EUNSUPPORTED = -5 /* unsupported k / dim / dtype */
+} bh_status;
+
+typedef enum bh_dtype { BH_F16 = 0, BH_F32 = 1 } bh_dtype;
+typedef enum bh_metric {
+    BH_METRIC_IP = 0, /* DotProduct.sim, reference models/retrievers/dense.py:77-81 */
+    BH_METRIC_COS = 1 /* CosineSim.sim,  reference models/retrievers/dense.py:83-89 */
+} bh_metric;
+
+typedef struct bh_index bh_index;
+
+/* Kernel-time / traffic counters of the most recent bh_search* call on an index
+ * (consumed by bench.py's `roofline` object). */
+typedef struct bh_counters {
+    int64_t n_rows;           /* rows resident in this index */
+    int32_t dim;              /* logical dim */
+    int32_t dim_padded;       /* row stride in elements (multiple of 64) */
+    int32_t query_tile;       /* queries per corpus pass (Bq_tile) */
+    int32_t n_passes;         /* corpus passes of the last search = ceil(nq / query_tile) */
+    int32_t n_workgroups;     /* persistent workgroups of the scan kernel */
+    int32_t k_padded;         /* candidate list length carried through the scan (k + margin) */
+    double scan_ms;           /* sum of scan-kernel durations (HIP events on the launch stream) */
+    double merge_ms;          /* sum of merge+rescore kernel durations */
+    double total_ms;          /* first launch -> last kernel done (HIP events), excludes H2D/D2H */
+    double algorithmic_bytes; /* sum over passes of N*d*2 + Bq*d*2 + Bq*k*12 */
+} bh_counters;
+
+/* Library / device lifecycle ------------------------------------------------------- */
+
+/* Select the HIP device for the calling thread and verify it is a gfx950 part.
+ * Replaces: `tensor.to('cuda')` device selection, reference modules/retrieve.py:76,124. */
+int bh_init(int device_id);
+int bh_version(void);
+const char* bh_last_error(void);
+/* Number of HIP devices visible; 0 (not an error) when there is none. */
+int bh_device_count(void);
+
+/* Flat index (resident corpus) ----------------------------------------------------- */
+
+/* Allocate an n_rows x dim index in HBM.  dtype is the storage type (BH_F16 only in this
+ * version: the reference stores fp16 embeddings, dense.py:16).  Replaces the host-side
+ * list of chunk tensors built at reference modules/retrieve.py:84-90. */
+int bh_index_create(bh_index** out, int64_t n_rows, int32_t dim, int32_t dtype, int32_t metric);
+
+/* Copy rows [row0, row0+n) from a HOST buffer of `src_dtype` (converted to fp16 with
+ * round-to-nearest-even, like torch .half()).  Replaces the per-query-chunk
+ * `emb_chunk.to('cuda')` of reference modules/retrieve.py:153 (done once, not per chunk). */
+int bh_index_upload(bh_index* ix, int64_t row0, const void* host_rows, int64_t n, int32_t src_dtype);
+/* Same, from a DEVICE buffer (e.g. encoder output that never left HBM). */
+int bh_index_upload_device(bh_index* ix, int64_t row0, const void* dev_rows, int64_t n, int32_t src_dtype);
+
+/* Declare the index complete.  Fails with BH_EINCOMPLETE if fewer than n_rows rows were
+ * uploaded (reference raises IOError, retrieve.py:165-166).  For BH_METRIC_COS every row is
+ * L2-normalised once here (reference renormalises every chunk on every call, dense.py:87-88). */
+int bh_index_finalize(bh_index* ix);
+
+/* Number of rows uploaded so far. */
+int64_t bh_index_rows_uploaded(const bh_index* ix);
+
+void bh_index_destroy(bh_index* ix);
+
+/* Exact brute-force search: for each of nq queries the k rows with the largest inner
+ * product, in the canonical total order (score descending, row index ascending).
+ * Scores are the canonical fp32 scores: round-to-nearest fp32 of the fp64 sum
+ * sum_{j=0..dim-1} q[j]*x[j] taken in index order over the fp16-stored values.
+ * out_ids = id_offset + row index (int64); slots beyond the number of rows hold id -1
+ * and score -inf.  Replaces reference Retrieve.load_collection_and_retrieve
+ * (modules/retrieve.py:146-185): similarity_fn + torch.topk per chunk + CPU merge. */
+int bh_search(bh_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k,
+              int64_t id_offset, float* out_scores, int64_t* out_ids);
+/* Same with DEVICE-resident queries and outputs (feeds the RCCL all-gather without a host
+ * round trip). */
+int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k,
+                     int64_t id_offset, float* out_scores_dev, int64_t* out_ids_dev);
+
+/* Merge n_lists partial top-k lists per query ([n_lists, nq, k] scores + ids, e.g. one per
+ * shard / rank) into one [nq, k] list in the canonical order; entries with id < 0 are
+ * ignored.  Replaces the host `torch.cat` + `torch.topk` + `gather` merge of reference
+ * modules/retrieve.py:169-177.  Runs on the device. */
+int bh_merge_topk(const float* scores, const int64_t* ids, int32_t n_lists, int32_t nq,
+                  int32_t k, float* out_scores, int64_t* out_ids);
+int bh_merge_topk_device(const float* scores_dev, const int64_t* ids_dev, int32_t n_lists,
+                         int32_t nq, int32_t k, float* out_scores_dev, int64_t* out_ids_dev);
+
+/* Counters of the last search on this index. */
+int bh_bench_counters(const bh_index* ix, bh_counters* out);
+
+/* Tuning knobs (process-wide; for bench sweeps).  name in {"query_tile" (128|256),
+ * "share_threshold" (0|1), "nontemporal" (0|1), "workgroups_per_cu" (1)}. */
+int bh_set_option(const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BERGEN_HIP_H */
