@@ -1,0 +1,329 @@
+#!/usr/bin/env python
+"""
+bench.py — BASELINE.json's headline metric on MI355X: exact inner-product top-50 search of the
+kilt_nq-dev-sized query set (2 837 queries) over a KILT-100w-sized corpus (21 M x 768 fp16),
+whole-job queries/s with the index already resident in HBM, plus the fraction of the HBM roofline
+of the dominant kernel and the reference's own CPU path timed beside it.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1            (driver: N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (driver: N>1)
+
+A "step" = one pass of the hot path over the whole query batch: queries (device resident) ->
+per-rank fused scan + merge/rescore over the rank's row shard -> [N>1: one RCCL all-gather of the
+partial top-k lists + canonical merge on rank 0].  The corpus is row-sharded across ranks
+(SURVEY §8e), so total work is fixed as N grows: scaling = "strong".
+
+Synthetic inputs: corpus rows ~ N(0, I) generated on the device in 1M-row blocks
+(block b <- seed 1000+b), L2-normalised, cast to fp16; queries seed 2; for each query 5 positives
+normalize(q + 0.3*noise) planted at rows drawn with seed 3.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  The oracle is used here only as the checker / CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n-rows", type=int, default=21_000_000, help="corpus rows (whole job)")
+    p.add_argument("--queries", type=int, default=2837, help="kilt_nq dev size")
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--k", type=int, default=50)
+    p.add_argument("--query-tile", type=int, default=None, help="128 or 256 (library default if omitted)")
+    p.add_argument("--share-threshold", type=int, default=None)
+    p.add_argument("--nontemporal", type=int, default=None)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
+    p.add_argument("--cpu-sample-queries", type=int, default=1000)
+    p.add_argument("--sweep", action="store_true", help="also time kernel variants (written to gpurun_out/sweep.json)")
+    p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
+                   help="optional PMC-derived HBM bytes per scan launch (written by profiles/collect_pmc.py)")
+    return p.parse_args()
+
+
+def make_queries(nq, dim, device):
+    g = torch.Generator(device=device).manual_seed(2)
+    q = torch.randn(nq, dim, generator=g, device=device)
+    return torch.nn.functional.normalize(q, dim=1).half()
+
+
+def fill_shard(ix, lo, hi, dim, queries, n_total, device):
+    """Upload rows [lo, hi) of the synthetic corpus into ix (local row = global row - lo)."""
+    block = 1_000_000
+    nq = queries.shape[0]
+    gp = torch.Generator().manual_seed(3)
+    plant_rows = torch.randint(0, n_total, (nq, 5), generator=gp)  # global rows, same on every rank
+    planted = []
+    b_first, b_last = lo // block, (max(hi, lo + 1) - 1) // block
+    for b in range(b_first, b_last + 1):
+        b0 = b * block
+        m = min(block, n_total - b0)
+        if m <= 0:
+            break
+        g = torch.Generator(device=device).manual_seed(1000 + b)
+        rows = torch.nn.functional.normalize(torch.randn(m, dim, generator=g, device=device), dim=1)
+        sel = ((plant_rows >= b0) & (plant_rows < b0 + m)).nonzero().tolist()
+        for qi, j in sel:
+            r = int(plant_rows[qi, j])
+            gn = torch.Generator(device=device).manual_seed(7_000_000 + qi * 5 + j)
+            noise = torch.randn(dim, generator=gn, device=device) * (0.3 / dim ** 0.5)
+            rows[r - b0] = torch.nn.functional.normalize(queries[qi].float() + noise, dim=0)
+        rows = rows.half()
+        a, e = max(lo, b0), min(hi, b0 + m)
+        if e > a:
+            ix.upload(rows[a - b0:e - b0].contiguous(), row0=a - lo)
+            for qi, j in sel:
+                r = int(plant_rows[qi, j])
+                if a <= r < e:
+                    planted.append((qi, r))
+        del rows
+    return planted, plant_rows
+
+
+def cpu_baseline(args, dim, k):
+    """The reference's op sequence (torch.mm + torch.topk per chunk + host merge, fp32) on the host cores,
+    on a bounded sample, scaled linearly in N to the full corpus."""
+    from oracle import ref_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nq, n = args.cpu_sample_queries, args.cpu_sample_rows
+    g = torch.Generator().manual_seed(5)
+    q = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g), dim=1).half().float()
+    chunks = []
+    for c in ref_port.reference_chunk_sizes(n, batch_size=512):
+        chunks.append(torch.nn.functional.normalize(torch.randn(c, dim, generator=g), dim=1).half().float())
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref_port.retrieve(q, chunks, k, batch_size_sim=2048)
+        best = min(best, time.perf_counter() - t0)
+    scale = args.n_rows / n
+    qps_full = nq / (best * scale)
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {
+        "value": qps_full, "unit": "queries/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/ref_port.py (the reference's torch.mm+torch.topk chunk loop, fp32, batch_size_sim=2048, "
+                   f"chunks 150016/149504 rows) on Q={nq} x N={n} x d={dim}, best of 3 = {best:.3f} s, "
+                   f"scaled x{scale:.1f} linearly in N to N={args.n_rows}; CPU: {model}; torch {torch.__version__}"),
+        "measured_seconds": best,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import bergen_amd
+    from bergen_amd import _lib
+    _lib.init(local_rank)
+    if args.query_tile is not None:
+        _lib.set_option("query_tile", args.query_tile)
+    if args.share_threshold is not None:
+        _lib.set_option("share_threshold", args.share_threshold)
+    if args.nontemporal is not None:
+        _lib.set_option("nontemporal", args.nontemporal)
+
+    dim, k, nq, n_total = args.dim, args.k, args.queries, args.n_rows
+    lo, hi = bergen_amd.shard_range(n_total, rank, world)
+    queries = make_queries(nq, dim, device)
+    t0 = time.perf_counter()
+    ix = bergen_amd.FlatIndex(hi - lo, dim, metric="ip", device=local_rank)
+    planted, plant_rows = fill_shard(ix, lo, hi, dim, queries, n_total, device)
+    ix.finalize()
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    searcher = bergen_amd.ShardedSearcher(ix, lo, rank=rank, world_size=world) if world > 1 else None
+
+    def step():
+        if searcher is not None:
+            return searcher.search(queries, k)
+        return ix.search(queries, k)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    scan_ms = merge_ms = kernel_total_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        c = ix.counters()
+        scan_ms += c["scan_ms"]
+        merge_ms += c["merge_ms"]
+        kernel_total_ms += c["total_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    c = ix.counters()
+
+    # ---- parity gate (rank 0): planted positives on top + canonical scores of returned ids -------
+    parity = "skipped"
+    if rank == 0:
+        from oracle import c_oracle
+        s_np, i_np = res[0].cpu().numpy(), res[1].cpu().numpy()
+        ok = bool((np.diff(s_np, axis=1) <= 0).all())
+        owner = {}  # row -> query whose plant was written last (plants can collide on a row)
+        for qi in range(nq):
+            for j in range(5):
+                owner[int(plant_rows[qi, j])] = qi
+        for qi in range(nq):
+            mine = set(r for r in (int(v) for v in plant_rows[qi].tolist()) if owner[r] == qi)
+            ok &= set(i_np[qi, :len(mine)].tolist()) == mine
+        if world == 1:
+            # re-score the first 4 queries' hits on the CPU from regenerated rows: the canonical
+            # scores must match bit-for-bit
+            got_rows = _regenerate_rows(i_np[:4].reshape(-1), dim, queries, plant_rows, n_total, device)
+            want = c_oracle.canonical_scores(queries[:4].cpu().numpy(), got_rows,
+                                             np.arange(4 * k, dtype=np.int64).reshape(4, k))
+            ok &= bool(np.array_equal(want.view(np.uint32), s_np[:4].view(np.uint32)))
+        parity = "pass" if ok else "FAIL"
+
+    if rank == 0:
+        n_launch = c["n_passes"] * args.steps
+        per_launch_bytes = c["algorithmic_bytes"] / c["n_passes"]
+        avg_scan_ms = scan_ms / n_launch
+        achieved = per_launch_bytes / (avg_scan_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                if tj.get("n_rows") == hi - lo and tj.get("dim") == dim:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "queries/sec, exact IP top-50, KILT-100w-sized corpus (21M x 768 fp16), kilt_nq-dev-sized query set",
+            "value": nq / (elapsed / args.steps),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16 storage, f32 MFMA accumulate, f64 canonical re-score",
+            "data": "synthetic (unit-norm Gaussian rows, 5 planted positives per query; SURVEY §8d S2)",
+            "config": {
+                "workload": f"configs[1] search half: {nq} queries x {n_total} x {dim} fp16, top-{k}, "
+                            f"corpus row-sharded over {world} GPU(s), resident in HBM",
+                "query_tile": c["query_tile"], "passes_per_step": c["n_passes"], "workgroups": c["n_workgroups"],
+                "rows_per_gpu": hi - lo, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of partial top-k" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "bh_scan_topk_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_scan_ms, "launches": n_launch,
+            },
+            "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,
+                                   "stream_total": kernel_total_ms / args.steps},
+            "index_build_seconds": build_s,
+            "parity_check": parity,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, dim, k)
+        if args.sweep and world == 1:
+            out["sweep"] = sweep(ix, queries, k, args)
+        print(json.dumps(out), flush=True)
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0 and parity == "FAIL":
+        sys.exit(3)
+
+
+def _regenerate_rows(global_rows, dim, queries, plant_rows, n_total, device):
+    """Rebuild specific corpus rows on the device exactly as fill_shard made them -> numpy fp16 [len, dim]."""
+    block = 1_000_000
+    out = np.empty((len(global_rows), dim), np.float16)
+    planted = {int(plant_rows[qi, j]): (qi, j) for qi in range(plant_rows.shape[0]) for j in range(5)}
+    by_block = {}
+    for pos, r in enumerate(global_rows.tolist()):
+        by_block.setdefault(r // block, []).append((pos, r))
+    for b, items in by_block.items():
+        b0 = b * block
+        m = min(block, n_total - b0)
+        g = torch.Generator(device=device).manual_seed(1000 + b)
+        rows = torch.nn.functional.normalize(torch.randn(m, dim, generator=g, device=device), dim=1)
+        sel = ((plant_rows >= b0) & (plant_rows < b0 + m)).nonzero().tolist()
+        for qi, j in sel:  # same order as fill_shard: a later plant on the same row wins there too
+            r = int(plant_rows[qi, j])
+            gn = torch.Generator(device=device).manual_seed(7_000_000 + qi * 5 + j)
+            noise = torch.randn(dim, generator=gn, device=device) * (0.3 / dim ** 0.5)
+            rows[r - b0] = torch.nn.functional.normalize(queries[qi].float() + noise, dim=0)
+        rows = rows.half()
+        for pos, r in items:
+            out[pos] = rows[r - b0].cpu().numpy()
+        del rows
+    return out
+
+
+def sweep(ix, queries, k, args):
+    """Kernel-variant timings for tuning (not part of the headline number)."""
+    from bergen_amd import _lib
+    res = []
+    for tile in (128, 256):
+        for share in (1, 0):
+            for nt in (1, 0):
+                _lib.set_option("query_tile", tile)
+                _lib.set_option("share_threshold", share)
+                _lib.set_option("nontemporal", nt)
+                ix.search(queries, k)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ix.search(queries, k)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                c = ix.counters()
+                per = c["algorithmic_bytes"] / c["n_passes"]
+                res.append({"query_tile": tile, "share": share, "nt": nt, "qps": queries.shape[0] / dt,
+                            "scan_ms_per_pass": c["scan_ms"] / c["n_passes"], "merge_ms_per_pass": c["merge_ms"] / c["n_passes"],
+                            "scan_GBps": per / (c["scan_ms"] / c["n_passes"] * 1e-3) / 1e9})
+    _lib.set_option("query_tile", 128)
+    _lib.set_option("share_threshold", 1)
+    _lib.set_option("nontemporal", 1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "sweep.json"), "w"), indent=1)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,25 @@
+"""
+bergen_amd — MI355X-native dense-retrieval backend for BERGEN (naver/bergen).
+
+Scope: ONE hot path, the reference's encode-then-exact-search stage
+(modules/retrieve.py + models/retrievers/dense.py), rebuilt from scratch for gfx950 behind the
+reference's own Retrieve / Retriever API.  Everything that computes runs in hand-written HIP
+kernels reached through the C ABI of include/bergen_hip.h (bergen_amd/lib/libbergen_hip.so);
+there is no CPU fallback.
+
+  Retrieve            stage object, drop-in for modules.retrieve.Retrieve
+  Dense, MeanPooler, ClsPooler, DotProduct, CosineSim
+                      model plug-in, drop-in for models.retrievers.dense.*
+  FlatIndex           resident HBM index + fused inner-product/top-k search
+  merge_topk          device merge of per-shard partial top-k lists
+  ShardedSearcher     row-sharded multi-GPU search (one process per GPU, RCCL all-gather)
+  utils               chunk-file / .trec formats, path naming (reference utils.py)
+"""
+from . import utils  # noqa: F401
+from .config import instantiate  # noqa: F401
+from .dense import ClsPooler, CosineSim, Dense, DotProduct, MeanPooler, Retriever  # noqa: F401
+from .index import FlatIndex, merge_topk  # noqa: F401
+from .retrieve import Retrieve  # noqa: F401
+from .sharded import ShardedSearcher, shard_range  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,122 @@
+"""
+ctypes loader of libbergen_hip.so (C ABI: include/bergen_hip.h).
+
+BASELINE.json asks for a cffi layer; cffi is not installed in this image, ctypes
+is the stdlib equivalent and binds the same `extern "C"` symbols.
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent the
+import fails loudly, and every compute entry point fails if no gfx950 device is present.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("BERGEN_HIP_LIB", os.path.join(_HERE, "lib", "libbergen_hip.so"))
+
+BH_OK = 0
+BH_EINVAL = -1
+BH_EHIP = -2
+BH_ENOMEM = -3
+BH_EINCOMPLETE = -4
+BH_EUNSUPPORTED = -5
+
+BH_F16 = 0
+BH_F32 = 1
+BH_METRIC_IP = 0
+BH_METRIC_COS = 1
+
+
+class bh_counters(ctypes.Structure):
+    _fields_ = [
+        ("n_rows", ctypes.c_int64),
+        ("dim", ctypes.c_int32),
+        ("dim_padded", ctypes.c_int32),
+        ("query_tile", ctypes.c_int32),
+        ("n_passes", ctypes.c_int32),
+        ("n_workgroups", ctypes.c_int32),
+        ("k_padded", ctypes.c_int32),
+        ("scan_ms", ctypes.c_double),
+        ("merge_ms", ctypes.c_double),
+        ("total_ms", ctypes.c_double),
+        ("algorithmic_bytes", ctypes.c_double),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/bergen_hip.h declares
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+SYMBOLS = {
+    "bh_init": (ctypes.c_int, [ctypes.c_int]),
+    "bh_version": (ctypes.c_int, []),
+    "bh_last_error": (ctypes.c_char_p, []),
+    "bh_device_count": (ctypes.c_int, []),
+    "bh_index_create": (ctypes.c_int, [ctypes.POINTER(_vp), _i64, _i32, _i32, _i32]),
+    "bh_index_upload": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32]),
+    "bh_index_upload_device": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i32]),
+    "bh_index_finalize": (ctypes.c_int, [_vp]),
+    "bh_index_rows_uploaded": (_i64, [_vp]),
+    "bh_index_destroy": (None, [_vp]),
+    "bh_search": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "bh_search_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "bh_merge_topk": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "bh_merge_topk_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "bh_bench_counters": (ctypes.c_int, [_vp, ctypes.POINTER(bh_counters)]),
+    "bh_set_option": (ctypes.c_int, [ctypes.c_char_p, _i64]),
+}
+
+_lib = None
+
+
+class BergenHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libbergen_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def lib():
+    """Load (once) and return the ctypes handle with all prototypes set."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C bergen_amd/csrc`.  bergen_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a bh_status to the reference's exception types (Errors)."""
+    if rc == BH_OK:
+        return
+    msg = lib().bh_last_error().decode("utf-8", "replace")
+    if rc == BH_EINCOMPLETE:
+        raise IOError(msg)  # reference: modules/retrieve.py:165-166
+    if rc == BH_EINVAL:
+        raise ValueError(msg)
+    if rc == BH_ENOMEM:
+        raise MemoryError(msg)
+    raise BergenHipError(rc, msg)
+
+
+_initialised = {}
+
+
+def init(device_id=0):
+    """bh_init once per (process, device)."""
+    if not _initialised.get(device_id):
+        check(lib().bh_init(device_id))
+        _initialised[device_id] = True
+    else:
+        check(lib().bh_init(device_id))  # cheap: re-selects the device for this thread
+
+
+def set_option(name, value):
+    check(lib().bh_set_option(name.encode(), int(value)))

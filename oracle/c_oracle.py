@@ -1,0 +1,110 @@
+"""ctypes binding of oracle/liboracle.so (flat_ip_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile liboracle.so with gcc (no GPU, no reference needed)."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        src = os.path.join(_HERE, "flat_ip_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.oracle_ref_chunked_search.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _as_half_bits(a):
+    """[.., d] array (float16 or float32) -> contiguous uint16 view of its fp16 (RNE) values."""
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.float16:
+        a = a.astype(np.float16)
+    return a.view(np.uint16)
+
+
+def canonical_search(q, x, k, id_offset=0):
+    """bh_search's contract on the CPU: canonical fp64-sequential scores, (score desc, row asc).
+
+    q: [nq, d], x: [n, d] (fp16, or fp32 rounded to fp16 RNE).  Returns (scores f32 [nq,k], ids i64 [nq,k]).
+    """
+    qb, xb = _as_half_bits(q), _as_half_bits(x)
+    nq, d = qb.shape
+    n = xb.shape[0]
+    out_s = np.empty((nq, k), np.float32)
+    out_i = np.empty((nq, k), np.int64)
+    lib().oracle_canonical_search(_p(qb), _p(xb), ctypes.c_int64(nq), ctypes.c_int64(n), ctypes.c_int(d),
+                                  ctypes.c_int(k), ctypes.c_int64(id_offset), _p(out_s), _p(out_i))
+    return out_s, out_i
+
+
+def canonical_scores(q, x, rows):
+    """Canonical scores of given rows per query: rows [nq, m] int64 (-1 -> -inf)."""
+    qb, xb = _as_half_bits(q), _as_half_bits(x)
+    rows = np.ascontiguousarray(rows, np.int64)
+    nq, m = rows.shape
+    out = np.empty((nq, m), np.float32)
+    lib().oracle_canonical_scores(_p(qb), _p(xb), ctypes.c_int64(nq), ctypes.c_int(qb.shape[1]), _p(rows),
+                                  ctypes.c_int(m), _p(out))
+    return out
+
+
+def ref_chunked_search(q32, x32, chunk_rows, dataset_size, k):
+    """The reference's chunk loop (modules/retrieve.py:146-185) in C, fp32 dots, canonical ties.
+
+    Raises IOError with the reference's message when the index is incomplete (retrieve.py:165-166).
+    """
+    q32 = np.ascontiguousarray(q32, np.float32)
+    x32 = np.ascontiguousarray(x32, np.float32)
+    chunk_rows = np.ascontiguousarray(chunk_rows, np.int64)
+    nq, d = q32.shape
+    out_s = np.empty((nq, k), np.float32)
+    out_i = np.empty((nq, k), np.int64)
+    missing = ctypes.c_int64(0)
+    rc = lib().oracle_ref_chunked_search(_p(q32), _p(x32), ctypes.c_int64(nq), ctypes.c_int(d), _p(chunk_rows),
+                                         ctypes.c_int(len(chunk_rows)), ctypes.c_int64(dataset_size),
+                                         ctypes.c_int(k), _p(out_s), _p(out_i), ctypes.byref(missing))
+    if rc == -4:
+        raise IOError(f'!!! Index is not complete. Please re-index. Missing {missing.value} documents in the index. !!!')
+    return out_s, out_i
+
+
+def l2_normalize_rows(x):
+    """Canonical cosine normalisation (restates dense.py:87-88); returns a new fp16 array."""
+    xb = _as_half_bits(x).copy()
+    lib().oracle_l2_normalize_rows(_p(xb), ctypes.c_int64(xb.shape[0]), ctypes.c_int(xb.shape[1]))
+    return xb.view(np.float16)
+
+
+def merge_topk(scores, ids, k=None):
+    """Merge [n_lists, nq, k] partial lists, canonical order (restates retrieve.py:169-177)."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    ids = np.ascontiguousarray(ids, np.int64)
+    n_lists, nq, kk = scores.shape
+    out_s = np.empty((nq, kk), np.float32)
+    out_i = np.empty((nq, kk), np.int64)
+    lib().oracle_merge_topk(_p(scores), _p(ids), ctypes.c_int(n_lists), ctypes.c_int64(nq), ctypes.c_int(kk),
+                            _p(out_s), _p(out_i))
+    return out_s, out_i
+
+
+def floats_to_halfs(a):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty(a.shape, np.uint16)
+    lib().oracle_floats_to_halfs(_p(a), _p(out), ctypes.c_int64(a.size))
+    return out.view(np.float16)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence bench.py's roofline numbers are checked against.
+#   profiles/run_profile.sh <tag>         (run on the GPU box from the repo root, e.g. via gpurun)
+# Writes gpurun_out/prof_<tag>/... ; copy the *_kernel_stats.csv summary into profiles/ afterwards.
+# Kernel trace / stats and PMC counters are collected in SEPARATE runs (never --pmc with a trace).
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
+echo "== kernel trace + stats" 
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
+echo "exit $?" >> "$OUT/trace.log"
+if [ "${2:-}" = "pmc" ]; then
+  echo "== PMC pass 1: FETCH_SIZE"
+  timeout 900 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH --steps 1 > "$OUT/pmc_fetch.log" 2>&1
+  echo "== PMC pass 2: WRITE_SIZE"
+  timeout 900 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o bench -- $BENCH --steps 1 > "$OUT/pmc_write.log" 2>&1
+  echo "== PMC pass 3: SQ"
+  timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o bench -- $BENCH --steps 1 > "$OUT/pmc_sq.log" 2>&1
+fi
+find "$OUT" -name "*.csv" | head -50

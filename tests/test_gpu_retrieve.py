@@ -1,0 +1,95 @@
+"""GPU: the Retrieve stage end to end (chunk files on disk -> resident index -> fused search ->
+doc-id strings -> .trec), against the oracle.  Uses the reference's file formats and return types."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, compare
+
+pytestmark = pytest.mark.gpu
+
+
+class _FakeEncoder(torch.nn.Module):
+    def forward(self, v=None):
+        return (v,)
+
+
+class _TableDense:
+    """A Dense-shaped plug-in whose 'encoder' looks embeddings up in a table keyed by the text (an int)."""
+    model_name = "fake/table-dense"
+
+    def __init__(self, q_table, d_table, similarity):
+        self.model = _FakeEncoder()
+        self.q_table, self.d_table = q_table, d_table
+        self.similarity = similarity
+
+    def collate_fn(self, batch, query_or_doc=None):
+        key = 'generated_query' if query_or_doc == "query" else "content"
+        return {"idx": torch.tensor([int(s[key]) for s in batch])}
+
+    def __call__(self, query_or_doc, batch):
+        t = self.q_table if query_or_doc == "query" else self.d_table
+        return {"embedding": t[batch["idx"].cpu()]}
+
+
+@pytest.mark.parametrize("metric", ["ip", "cos"])
+def test_retrieve_end_to_end(tmp_path, metric):
+    import datasets
+    import bergen_amd
+    from bergen_amd import utils
+    g = torch.Generator().manual_seed(21)
+    n, nq, d, k = 1000, 23, 128, 10
+    d_table = torch.randn(n, d, generator=g).half()
+    q_table = torch.randn(nq, d, generator=g).half()
+    sim = bergen_amd.DotProduct() if metric == "ip" else bergen_amd.CosineSim()
+    r = bergen_amd.Retrieve(init_args=_TableDense(q_table, d_table, sim), batch_size=64, batch_size_sim=16, num_workers=0)
+    dataset = {
+        "doc": datasets.Dataset.from_dict({"id": [f"doc{i}" for i in range(n)], "content": [str(i) for i in range(n)]}),
+        "query": datasets.Dataset.from_dict({"id": [f"q{i}" for i in range(nq)], "generated_query": [str(i) for i in range(nq)],
+                                             "content": [str(i) for i in range(nq)]}),
+    }
+    q_path, d_path = str(tmp_path / "q_idx"), str(tmp_path / "d_idx")
+    out = r.retrieve(dataset, q_path, d_path, k)
+    # reference chunk layout on disk: batch 64 -> save every 2343 batches -> a single final chunk here
+    assert os.listdir(d_path) == ["embedding_chunk_15.pt"] and os.listdir(q_path) == ["embedding_chunk_0.pt"]
+    assert isinstance(out["score"], torch.Tensor) and out["score"].dtype == torch.float32 and not out["score"].is_cuda
+    assert tuple(out["score"].shape) == (nq, k) and out["q_id"] == [f"q{i}" for i in range(nq)]
+    assert isinstance(out["doc_id"][0][0], str)          # prepare_dataset_from_ids asserts this (utils.py:131)
+    xq, xd = q_table.numpy(), d_table.numpy()
+    if metric == "cos":
+        xq, xd = c_oracle.l2_normalize_rows(xq), c_oracle.l2_normalize_rows(xd)
+    ws, wi = c_oracle.canonical_search(xq, xd, k)
+    got_i = np.array([[int(s[3:]) for s in row] for row in out["doc_id"]])
+    compare.assert_bit_exact(out["score"].numpy(), got_i, ws, wi, f"Retrieve.retrieve {metric}")
+    # second call: index folders exist -> no re-encode, resident index reused
+    ix_before = r._resident[d_path][0]
+    out2 = r.retrieve(dataset, q_path, d_path, k)
+    assert r._resident[d_path][0] is ix_before and torch.equal(out2["score"], out["score"])
+    # run file round trip
+    run = str(tmp_path / "run.trec")
+    utils.write_trec(run, out["q_id"], out["doc_id"], out["score"])
+    q_ids, d_ids, scores = utils.load_trec(run)
+    assert q_ids == out["q_id"] and d_ids == out["doc_id"]
+    assert np.array_equal(np.array(scores, np.float32), out["score"].numpy())
+    # an incomplete index raises the reference's IOError
+    os.remove(os.path.join(d_path, "embedding_chunk_15.pt"))
+    torch.save(d_table[:900], os.path.join(d_path, "embedding_chunk_15.pt"))
+    with pytest.raises(IOError, match="Missing 100 documents"):
+        r.retrieve(dataset, q_path, d_path, k)
+    r.close()
+
+
+def test_load_collection_and_retrieve_signature():
+    import bergen_amd
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(700, 64, generator=g).half()
+    q = torch.randn(9, 64, generator=g).half()
+    r = bergen_amd.Retrieve(init_args=_TableDense(q, x, bergen_amd.DotProduct()), num_workers=0)
+    s, i, e = r.load_collection_and_retrieve(q, [x[:300], x[300:]], 7, dataset_size=700)
+    ws, wi = c_oracle.canonical_search(q.numpy(), x.numpy(), 7)
+    compare.assert_bit_exact(s.numpy(), i.numpy(), ws, wi, "load_collection_and_retrieve")
+    assert e is None and s.dtype == torch.float32 and i.dtype == torch.int64
+    with pytest.raises(IOError, match="Missing 5 documents"):
+        r.load_collection_and_retrieve(q, [x], 7, dataset_size=705)

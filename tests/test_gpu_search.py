@@ -1,0 +1,304 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden fixtures.  Bit-exact for ids and canonical fp32 scores."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, compare
+from tests.conftest import gap_tolerance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import bergen_amd
+    from bergen_amd import _lib
+    _lib.init(0)
+    yield bergen_amd
+    for name, val in (("query_tile", 128), ("share_threshold", 1), ("nontemporal", 1)):
+        _lib.set_option(name, val)
+
+
+def _search(amd, x, q, k, metric="ip", chunks=None):
+    ix = amd.FlatIndex(x.shape[0], x.shape[1], metric=metric)
+    try:
+        if chunks is None:
+            ix.upload(x)
+        else:
+            off = 0
+            for c in chunks:
+                ix.upload(x[off:off + c])
+                off += c
+        ix.finalize()
+        return ix.search(q, k)
+    finally:
+        ix.close()
+
+
+def test_kat_small_golden(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "kat_small.npz"))
+    s, i = _search(amd, g["x"], g["q"], int(g["k"]), chunks=[9, 8])
+    compare.assert_bit_exact(s, i, g["canon_scores"], g["canon_ids"], "kat_small")
+    assert np.array_equal(s, g["ref_scores"])  # the reference's scores, canonical order inside ties
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (1, 64, 1, 1), (31, 64, 3, 5), (32, 64, 128, 10), (33, 100, 129, 50), (1000, 128, 7, 56),
+    (4097, 256, 130, 57), (3000, 384, 40, 120), (2500, 512, 33, 121), (7777, 768, 300, 50),
+    (5000, 1024, 65, 200), (2000, 1024, 10, 248), (600, 16, 4, 50), (20000, 768, 64, 50),
+])
+def test_random_matches_oracle(amd, n, d, nq, k):
+    rng = np.random.default_rng(n * 31 + d)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    s, i = _search(amd, x, q, k)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    compare.assert_bit_exact(s, i, ws, wi, f"n={n} d={d} nq={nq} k={k}")
+
+
+def test_fp32_sources_are_rounded_like_torch_half(amd):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3000, 768)).astype(np.float32)
+    q = rng.standard_normal((20, 768)).astype(np.float32)
+    s, i = _search(amd, x, q, 50)
+    ws, wi = c_oracle.canonical_search(q.astype(np.float16), x.astype(np.float16), 50)
+    compare.assert_bit_exact(s, i, ws, wi, "fp32 sources")
+
+
+def test_exact_ties_and_degenerate_corpora(amd):
+    d = 64
+    # (a) 3000 identical rows: every score ties -> ascending row ids, compaction on every buffer fill
+    x = np.tile(np.arange(d, dtype=np.float16)[None] / 8, (3000, 1))
+    q = np.ones((5, d), np.float16)
+    s, i = _search(amd, x, q, 50)
+    assert np.array_equal(i, np.tile(np.arange(50), (5, 1)))
+    # (b) all-zero corpus and zero queries
+    s, i = _search(amd, np.zeros((500, d), np.float16), np.zeros((3, d), np.float16), 20)
+    assert np.array_equal(i, np.tile(np.arange(20), (3, 1))) and (s == 0).all()
+    # (c) adversarial order: scores strictly increase with the row index, so EVERY row is a new best
+    #     (worst case for the threshold filter: maximal append + compaction traffic)
+    n = 40000
+    x = np.zeros((n, d), np.float16)
+    x[:, 0] = (np.arange(n) % 2048).astype(np.float16)     # fp16-exact integers
+    x[:, 1] = (np.arange(n) // 2048).astype(np.float16)
+    q = np.zeros((130, d), np.float16)
+    q[:, 0] = 1.0
+    q[:, 1] = 2048.0
+    q[64:, :2] *= -1                                        # second half: strictly DEcreasing scores
+    s, i = _search(amd, x, q, 50)
+    ws, wi = c_oracle.canonical_search(q, x, 50)
+    compare.assert_bit_exact(s, i, ws, wi, "monotone scores")
+    assert i[0, 0] == n - 1 and i[64, 0] == 0
+    # (d) fewer rows than k
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((7, d)).astype(np.float16)
+    q = rng.standard_normal((2, d)).astype(np.float16)
+    s, i = _search(amd, x, q, 10)
+    ws, wi = c_oracle.canonical_search(q, x, 10)
+    compare.assert_bit_exact(s, i, ws, wi, "short index")
+    assert (i[:, 7:] == -1).all() and np.isneginf(s[:, 7:]).all()
+    # (e) -inf scores / huge magnitudes stay ordered
+    x = rng.standard_normal((300, d)).astype(np.float16)
+    x[5] = 60000
+    x[6] = -60000
+    q = np.full((1, d), 60000, np.float16)
+    s, i = _search(amd, x, q, 10)
+    ws, wi = c_oracle.canonical_search(q, x, 10)
+    compare.assert_bit_exact(s, i, ws, wi, "overflowing scores")
+
+
+def test_config1_golden(amd, s1_inputs):
+    """BASELINE configs[0] on the device: bit-exact vs the committed canonical golden; near-tie rule and
+    1e-3 score tolerance vs the committed outputs of the REAL reference code."""
+    q, d, gold = s1_inputs
+    qh, dh = q.half().numpy(), d.half().numpy()
+    s, i = _search(amd, dh, qh, 50, chunks=[50000, 50000])
+    compare.assert_bit_exact(s, i, gold["canon_h_scores"], gold["canon_h_ids"].astype(np.int64), "config1 canonical")
+    st = compare.compare_near_tie(s, i, gold["ref_h_scores"], gold["ref_h_ids"].astype(np.int64),
+                                  gap_tol=gap_tolerance(qh, dh[:4000]) * 1.2, score_tol=1e-3)
+    assert st["exact_id_queries"] >= 990, st
+
+
+def test_options_do_not_change_results(amd):
+    from bergen_amd import _lib
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((30011, 768)).astype(np.float16)
+    q = rng.standard_normal((300, 768)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q[:40], x, 50)
+    base = None
+    for tile in (128, 256):
+        for share in (0, 1):
+            for nt in (0, 1):
+                _lib.set_option("query_tile", tile)
+                _lib.set_option("share_threshold", share)
+                _lib.set_option("nontemporal", nt)
+                s, i = _search(amd, x, q, 50)
+                compare.assert_bit_exact(s[:40], i[:40], ws, wi, f"tile={tile} share={share} nt={nt}")
+                if base is None:
+                    base = (s, i)
+                compare.assert_bit_exact(s, i, base[0], base[1], f"variant tile={tile} share={share} nt={nt}")
+    _lib.set_option("query_tile", 128)
+    _lib.set_option("share_threshold", 1)
+    _lib.set_option("nontemporal", 1)
+
+
+def test_shard_invariance_and_device_merge(amd):
+    """Results identical for 1/2/4/8 row shards merged by the HIP merge kernel (SURVEY §8c KAT 3)."""
+    rng = np.random.default_rng(4)
+    n, d, nq, k = 10007, 384, 50, 50
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    x[9000] = x[17]
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    full_s, full_i = _search(amd, x, q, k)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    compare.assert_bit_exact(full_s, full_i, ws, wi, "single shard")
+    for shards in (2, 4, 8):
+        ps, pi = [], []
+        for r in range(shards):
+            lo, hi = amd.shard_range(n, r, shards)
+            ix = amd.FlatIndex(hi - lo, d)
+            ix.upload(x[lo:hi])
+            ix.finalize()
+            s, i = ix.search(q, k, id_offset=lo)
+            ix.close()
+            ps.append(s)
+            pi.append(i)
+        ms, mi = amd.merge_topk(np.stack(ps), np.stack(pi))
+        compare.assert_bit_exact(ms, mi, full_s, full_i, f"{shards} shards (host buffers)")
+        ms, mi = amd.merge_topk(torch.from_numpy(np.stack(ps)).cuda(), torch.from_numpy(np.stack(pi)).cuda())
+        compare.assert_bit_exact(ms.cpu().numpy(), mi.cpu().numpy(), full_s, full_i, f"{shards} shards (device)")
+    # many lists (tree reduction path) + invalid entries
+    many_s = np.stack([full_s] + [np.full_like(full_s, -np.inf)] * 99)
+    many_i = np.stack([full_i] + [np.full_like(full_i, -1)] * 99)
+    ms, mi = amd.merge_topk(many_s, many_i)
+    compare.assert_bit_exact(ms, mi, full_s, full_i, "100 lists")
+
+
+def test_cosine_golden(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "cosine_small.npz"))
+    s, i = _search(amd, g["x"], g["q"], int(g["k"]), metric="cos")
+    compare.assert_bit_exact(s, i, g["canon_scores"], g["canon_ids"], "cosine canonical")
+    st = compare.compare_near_tie(s, i, g["ref_scores"], g["ref_ids"], gap_tol=5e-4, score_tol=1e-3)
+    assert st["max_score_err"] < 1e-3
+
+
+def test_device_resident_sources_and_queries(amd):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((6000, 768)).astype(np.float16)
+    q = rng.standard_normal((70, 768)).astype(np.float16)
+    ix = amd.FlatIndex(6000, 768)
+    ix.upload(torch.from_numpy(x[:2500]).cuda())           # fp16 device rows
+    ix.upload(torch.from_numpy(x[2500:]).cuda().float())   # fp32 device rows (exactly representable)
+    ix.finalize()
+    s, i = ix.search(torch.from_numpy(q).cuda(), 50, id_offset=1_000_000)
+    assert s.is_cuda and i.is_cuda and i.dtype == torch.int64
+    ws, wi = c_oracle.canonical_search(q, x, 50, id_offset=1_000_000)
+    compare.assert_bit_exact(s.cpu().numpy(), i.cpu().numpy(), ws, wi, "device path")
+    c = ix.counters()
+    assert c["n_passes"] == 1 and c["query_tile"] == 128 and c["scan_ms"] > 0
+    assert c["algorithmic_bytes"] == 6000 * 768 * 2 + 128 * 768 * 2 + 128 * 50 * 12
+    ix.close()
+
+
+def test_error_behaviour_matches_reference(amd):
+    x = np.zeros((100, 64), np.float16)
+    ix = amd.FlatIndex(100, 64)
+    ix.upload(x[:60])
+    with pytest.raises(IOError, match=r"!!! Index is not complete. Please re-index. Missing 40 documents in the index. !!!"):
+        ix.finalize()
+    with pytest.raises(IOError, match=r"Missing 40 documents"):
+        ix.search(np.zeros((1, 64), np.float16), 5)
+    with pytest.raises(ValueError):
+        ix.upload(x, row0=50)                     # rows beyond the index
+    ix.upload(x[60:])
+    ix.finalize()
+    with pytest.raises(Exception):
+        ix.search(np.zeros((1, 64), np.float16), 500)   # k > 248 unsupported
+    s, i = ix.search(np.zeros((0, 64), np.float16), 5)
+    assert s.shape == (0, 5)
+    ix.close()
+    with pytest.raises(Exception):
+        amd.FlatIndex(10, 5000)                   # dim > 1024 unsupported
+
+
+def test_repeatability(amd):
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((50000, 768)).astype(np.float16)
+    q = rng.standard_normal((256, 768)).astype(np.float16)
+    ix = amd.FlatIndex(50000, 768)
+    ix.upload(x)
+    ix.finalize()
+    a = ix.search(q, 50)
+    for _ in range(3):
+        b = ix.search(q, 50)
+        compare.assert_bit_exact(b[0], b[1], a[0], a[1], "run-to-run")
+    ix.close()
+
+
+def test_full_size_properties(amd):
+    """BASELINE configs[1] size: 21M x 768 fp16 resident (32 GB).  Size-independent properties:
+    planted positives come back on top with their oracle scores, lists are canonically sorted,
+    and a 2-way row split merged by the HIP kernel equals the single-index result."""
+    free, total = torch.cuda.mem_get_info()
+    n, d, nq, k = 21_000_000, 768, 200, 50
+    if free < (n * d * 2) * 2.2:
+        pytest.skip("not enough free HBM for the full-size case")
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    ix = amd.FlatIndex(n, d)
+    half_lo = amd.FlatIndex(n // 2, d)
+    half_hi = amd.FlatIndex(n - n // 2, d)
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=gen, device=dev), dim=1).half()
+    plant_rows = torch.randint(0, n, (nq, 5), generator=gen, device=dev)
+    block = 1_000_000
+    planted = {}
+    for b0 in range(0, n, block):
+        m = min(block, n - b0)
+        rows = torch.nn.functional.normalize(torch.randn(m, d, generator=gen, device=dev), dim=1)
+        sel = ((plant_rows >= b0) & (plant_rows < b0 + m)).nonzero()
+        for qi, j in sel.tolist():
+            r = int(plant_rows[qi, j])
+            noise = torch.randn(d, generator=gen, device=dev) * (0.3 / d ** 0.5)
+            rows[r - b0] = torch.nn.functional.normalize(q[qi].float() + noise, dim=0)
+        rows = rows.half()
+        for qi, j in sel.tolist():
+            r = int(plant_rows[qi, j])
+            planted[(qi, r)] = rows[r - b0].cpu().numpy()
+        ix.upload(rows, row0=b0)
+        lo_n = n // 2
+        if b0 + m <= lo_n:
+            half_lo.upload(rows, row0=b0)
+        elif b0 >= lo_n:
+            half_hi.upload(rows, row0=b0 - lo_n)
+        else:
+            cut = lo_n - b0
+            half_lo.upload(rows[:cut].contiguous(), row0=b0)
+            half_hi.upload(rows[cut:].contiguous(), row0=0)
+        del rows
+    for h in (ix, half_lo, half_hi):
+        h.finalize()
+    s, i = ix.search(q, k)
+    s_np, i_np, q_np = s.cpu().numpy(), i.cpu().numpy(), q.cpu().numpy()
+    # canonical sortedness
+    assert (np.diff(s_np, axis=1) <= 0).all()
+    ties = np.diff(s_np, axis=1) == 0
+    assert (np.diff(i_np, axis=1)[ties] > 0).all()
+    # planted positives: present, and their scores equal the oracle's canonical score
+    for (qi, r), row in planted.items():
+        pos = np.where(i_np[qi] == r)[0]
+        assert len(pos) == 1, f"planted row {r} of query {qi} missing"
+        want = c_oracle.canonical_scores(q_np[qi:qi + 1], row[None], np.zeros((1, 1), np.int64))[0, 0]
+        assert s_np[qi, pos[0]].view(np.uint32) == want.view(np.uint32)
+    for qi in range(nq):
+        mine = sorted(r for (a, r) in planted if a == qi)
+        assert sorted(i_np[qi, :len(mine)].tolist()) == mine
+    # shard invariance at full size
+    s1, i1 = half_lo.search(q, k, id_offset=0)
+    s2, i2 = half_hi.search(q, k, id_offset=n // 2)
+    ms, mi = amd.merge_topk(torch.stack([s1, s2]), torch.stack([i1, i2]))
+    compare.assert_bit_exact(ms.cpu().numpy(), mi.cpu().numpy(), s_np, i_np, "2 shards at full size")
+    for h in (ix, half_lo, half_hi):
+        h.close()
