@@ -59,7 +59,13 @@ __global__ void __launch_bounds__(256) bh_l2_normalize_rows_kernel(_Float16* row
         }
         if (n2 > 0.0) {
             const double inv = 1.0 / __builtin_sqrt(n2);
-            for (int j = 0; j < dim; ++j) x[j] = (_Float16)(float)((double)x[j] * inv);  // fp64 -> fp32 -> fp16, both RNE
+            for (int j = 0; j < dim; ++j) {
+                float y = (float)((double)x[j] * inv);  // fp64 -> fp32, RNE (v_cvt_f32_f64)
+                // hipcc otherwise folds the two casts into ONE fp64->fp16 rounding (different bits in
+                // ~2^-13 of the elements): keep the contract's two roundings
+                asm volatile("" : "+v"(y));
+                x[j] = (_Float16)y;  // fp32 -> fp16, RNE (v_cvt_f16_f32)
+            }
         }
     }
 }

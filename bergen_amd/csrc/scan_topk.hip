@@ -98,10 +98,15 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
 #pragma unroll
         for (int s = 0; s < NK; ++s) qf[w2][s] = *reinterpret_cast<const half8*>(qrow + (2 * s + h) * 8);
     }
+    // Pin fragments into the accumulator file, but never more than it can hold next to the MFMA
+    // accumulators (256 AGPRs - 16*QW): over-subscribing the "a" constraint makes hipcc (ROCm 7.2)
+    // split-spill AGPR tuples and mis-reload them (observed: one dword of a fragment left stale).
+    constexpr int PIN_MAX = (256 - 16 * QW - 16) / 4;
 #pragma unroll
     for (int w2 = 0; w2 < QW; ++w2)
 #pragma unroll
-        for (int s = 0; s < NK; ++s) asm volatile("" : "+a"(qf[w2][s]));
+        for (int s = 0; s < NK; ++s)
+            if (w2 * NK + s < PIN_MAX) asm volatile("" : "+a"(qf[w2][s]));
 
     float thr[QW];     // candidate iff score > thr   (per lane = per query)
     unsigned cnt[QW];  // entries in the query's candidate buffer (identical in both half-lanes)

@@ -129,20 +129,22 @@ def test_options_do_not_change_results(amd):
     q = rng.standard_normal((300, 768)).astype(np.float16)
     ws, wi = c_oracle.canonical_search(q[:40], x, 50)
     base = None
-    for tile in (128, 256):
-        for share in (0, 1):
-            for nt in (0, 1):
-                _lib.set_option("query_tile", tile)
-                _lib.set_option("share_threshold", share)
-                _lib.set_option("nontemporal", nt)
-                s, i = _search(amd, x, q, 50)
-                compare.assert_bit_exact(s[:40], i[:40], ws, wi, f"tile={tile} share={share} nt={nt}")
-                if base is None:
-                    base = (s, i)
-                compare.assert_bit_exact(s, i, base[0], base[1], f"variant tile={tile} share={share} nt={nt}")
-    _lib.set_option("query_tile", 128)
-    _lib.set_option("share_threshold", 1)
-    _lib.set_option("nontemporal", 1)
+    try:
+        for tile in (128, 256):
+            for share in (0, 1):
+                for nt in (0, 1):
+                    _lib.set_option("query_tile", tile)
+                    _lib.set_option("share_threshold", share)
+                    _lib.set_option("nontemporal", nt)
+                    s, i = _search(amd, x, q, 50)
+                    compare.assert_bit_exact(s[:40], i[:40], ws, wi, f"tile={tile} share={share} nt={nt}")
+                    if base is None:
+                        base = (s, i)
+                    compare.assert_bit_exact(s, i, base[0], base[1], f"variant tile={tile} share={share} nt={nt}")
+    finally:
+        _lib.set_option("query_tile", 128)
+        _lib.set_option("share_threshold", 1)
+        _lib.set_option("nontemporal", 1)
 
 
 def test_shard_invariance_and_device_merge(amd):
