@@ -12,9 +12,11 @@ struct BhScanArgs {
     const _Float16* qtile;   // [BQ][D] fp16 query tile (zero rows beyond the valid queries)
     bh_u64* cand;            // [G][BQ][2*KP] candidate buffers (scratch)
     bh_u64* partial;         // [G][BQ][KP]   out: per-workgroup sorted best-KP keys
-    unsigned* gthr;          // [BQ] shared thresholds (ordf), initialised to BH_ORD_NEG_INF
+    unsigned* gthr;          // [BQ][64] threshold slot table (ordf), initialised to BH_ORD_NEG_INF
     int share;               // share thresholds between workgroups
     int nontemporal;         // nt cache policy on the corpus stream
+    int ablate;              // bench-only kernel ablation (0 = production kernel)
+    int ring_variant;        // bench-only LDS ring geometry selector for d=768 (0 = default 6 lines x 6)
 };
 
 // scan_topk.hip

@@ -48,6 +48,8 @@ struct Options {
     int share_threshold = 1;
     int nontemporal = 1;
     int workgroups_per_cu = 1;
+    int ablate = 0;
+    int ring_variant = 0;
 } g_opt;
 
 int pad_dim(int dim) {
@@ -211,6 +213,12 @@ int bh_set_option(const char* name, int64_t value) {
         g_opt.share_threshold = value != 0;
     } else if (s == "nontemporal") {
         g_opt.nontemporal = value != 0;
+    } else if (s == "ablate") {
+        if (value < 0 || value > 4) return fail(BH_EINVAL, "ablate must be 0..4");
+        g_opt.ablate = (int)value;  // bench-only: results are NOT valid search results when != 0
+    } else if (s == "ring_variant") {
+        if (value < 0 || value > 4) return fail(BH_EINVAL, "ring_variant must be 0..4");
+        g_opt.ring_variant = (int)value;
     } else if (s == "workgroups_per_cu") {
         if (value != 1) return fail(BH_EINVAL, "workgroups_per_cu must be 1 (LDS ring fills the CU)");
         g_opt.workgroups_per_cu = 1;
@@ -342,7 +350,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     if ((rc = ix->qbuf.ensure((size_t)nq_pad * dp))) return rc;
     if ((rc = ix->cand.ensure((size_t)grid * bq * 2 * kp))) return rc;
     if ((rc = ix->partial.ensure((size_t)grid * bq * kp))) return rc;
-    if ((rc = ix->gthr.ensure((size_t)bq))) return rc;
+    if ((rc = ix->gthr.ensure((size_t)bq * 64))) return rc;
 
     hipStream_t st = ix->stream;
     // queries -> padded fp16 tile buffer (zero rows beyond nq)
@@ -359,7 +367,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     for (int p = 0; p < n_pass; ++p) {
         const int q0 = p * bq;
         const int nq_tile = std::min(bq, nq - q0);
-        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, bq, 0x007fffffu, st));
+        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)bq * 64, 0x007fffffu, st));
         BhScanArgs sa;
         sa.corpus = ix->rows;
         sa.n_rows = ix->n_rows;
@@ -370,6 +378,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.gthr = ix->gthr.p;
         sa.share = g_opt.share_threshold;
         sa.nontemporal = g_opt.nontemporal;
+        sa.ablate = g_opt.ablate;
+        sa.ring_variant = g_opt.ring_variant;
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p), st));
         HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 1), st));

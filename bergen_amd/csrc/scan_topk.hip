@@ -23,9 +23,13 @@
 //     appended to a per-(workgroup, query) candidate buffer in global memory (L2-resident),
 //     slot counters live in registers (both half-lanes of a query keep identical copies);
 //     when a buffer nears capacity the owning wave bitonic-sorts it, keeps the best KP and
-//     raises the threshold.  Thresholds may additionally be shared between workgroups
-//     through one agent-scope atomicMax word per query — a pure filter hint: a stale value
-//     only means less filtering, never a wrong result.
+//     raises the threshold.
+//   * thresholds are SHARED between workgroups through a 64-slot table per query: workgroup b
+//     atomicMax-es the (KP/64)-th best score it has appended into slot b % 64; the minimum over
+//     the 64 slots is a score that at least 64 * (KP/64) = KP distinct rows reach (distinct
+//     slots <-> distinct workgroups), hence a valid lower bound of the final KP-th best.  A wave
+//     re-reads its queries' slots only after it had hits.  The table is a pure filter hint: a
+//     stale value only means less filtering, never a wrong result.
 //
 // LDS image / bank conflicts.  One LDS-DMA instruction writes 1 KiB lane-linearly
 // (dest = base + lane*16).  Lanes 8j..8j+7 fetch the eight 16-byte chunks of ONE 128-byte
@@ -65,7 +69,9 @@ __device__ __forceinline__ void sort_candidates(u64 (&e)[2 * KP / 64], const u64
 // NK = padded dim / 16 (MFMA k-steps per row); KP = candidate list length (64|128|256);
 // LS = 128-byte lines per stage; R = ring depth in stages; QW = 32-query blocks per wave;
 // NT = non-temporal cache policy on the corpus stream.
-template <int NK, int KP, int LS, int R, int QW, bool NT>
+// ABL (ablation, bench-only, 0 in production): 1 = no threshold epilogue, 2 = stream only (no LDS
+// reads, no MFMA), 3 = LDS reads without MFMA, 4 = MFMA without LDS reads.
+template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NK * 16;
@@ -108,12 +114,19 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
         for (int s = 0; s < NK; ++s)
             if (w2 * NK + s < PIN_MAX) asm volatile("" : "+a"(qf[w2][s]));
 
-    float thr[QW];     // candidate iff score > thr   (per lane = per query)
-    unsigned cnt[QW];  // entries in the query's candidate buffer (identical in both half-lanes)
+    constexpr int RB = KP / 64;  // a workgroup publishes its RB-th best appended score
+    float thr[QW];       // candidate iff score > thr   (per lane = per query)
+    unsigned cnt[QW];    // entries in the query's candidate buffer (identical in both half-lanes)
+    float best[QW][RB];  // this half-lane's RB best appended scores, descending
+    float pub[QW];       // last value published to the slot table
+    long long next_poll = 0;  // tile ordinal of the next slot-table exchange (same in every wave)
 #pragma unroll
     for (int w2 = 0; w2 < QW; ++w2) {
         thr[w2] = -__builtin_inff();
         cnt[w2] = 0;
+        pub[w2] = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < RB; ++r) best[w2][r] = -__builtin_inff();
     }
 
     // ---- per-lane constants of the LDS-DMA source pattern and of the fragment reads
@@ -142,9 +155,6 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
             // TIES the KP-th best loses on row index: the exclusive compare is exact.
             const float nt = bh_key_score(kth);
             if (ql == qq) thr[w2] = fmaxf(thr[w2], nt);
-            if (a.share && lane == 0)
-                __hip_atomic_fetch_max(a.gthr + qi, (unsigned)(kth >> 32), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
         }
     };
 
@@ -188,24 +198,55 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                 const unsigned char* st = smem + cslot * STAGE_BYTES;
                 // fragment reads run one 128-byte line (4 k-steps) ahead of the MFMAs
                 half8 af[2][4];
+                if constexpr (ABL == 2) {
+                    // stream only
+                } else if constexpr (ABL == 4) {
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) af[0][j4] = *reinterpret_cast<const half8*>(st + rd_off[j4]);
+                    for (int j4 = 0; j4 < 4; ++j4) af[0][j4] = af[1][j4] = qf[0][j4];
 #pragma unroll
-                for (int jl = 0; jl < LS; ++jl) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (jl + 1 < LS) {
+                    for (int jl = 0; jl < LS; ++jl)
 #pragma unroll
                         for (int j4 = 0; j4 < 4; ++j4)
-                            af[(jl + 1) & 1][j4] =
-                                *reinterpret_cast<const half8*>(st + (jl + 1) * 4096 + rd_off[j4]);
+#pragma unroll
+                            for (int w2 = 0; w2 < QW; ++w2)
+                                acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    af[jl & 1][j4], qf[w2][(part * LS + jl) * 4 + j4], acc[w2], 0, 0, 0);
+                } else {
+                    // GL lines (4*GL fragments) per group; reads of group g+1 are issued after the
+                    // wait for group g and ahead of group g's MFMAs (>= 128*GL cycles of cover)
+                    constexpr int GL = (LS % 2 == 0) ? 2 : 1;
+                    constexpr int NG = LS / GL;
+                    half8 ag[2][4 * GL];
+#pragma unroll
+                    for (int f = 0; f < 4 * GL; ++f)
+                        ag[0][f] = *reinterpret_cast<const half8*>(st + (f >> 2) * 4096 + rd_off[f & 3]);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        // fake use: makes hipcc wait for THIS group's fragments here (it waits
+                        // lgkmcnt(0), which would otherwise also cover the reads issued next)
+#pragma unroll
+                        for (int f = 0; f < 4 * GL; ++f) asm volatile("" : "+v"(ag[g & 1][f]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + 1 < NG) {
+#pragma unroll
+                            for (int f = 0; f < 4 * GL; ++f)
+                                ag[(g + 1) & 1][f] = *reinterpret_cast<const half8*>(
+                                    st + ((g + 1) * GL + (f >> 2)) * 4096 + rd_off[f & 3]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (ABL == 3) {
+#pragma unroll
+                            for (int f = 0; f < 4 * GL; ++f) asm volatile("" ::"v"(ag[g & 1][f]));
+                        } else {
+#pragma unroll
+                            for (int f = 0; f < 4 * GL; ++f)
+#pragma unroll
+                                for (int w2 = 0; w2 < QW; ++w2)
+                                    acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                        ag[g & 1][f], qf[w2][(part * LS + g * GL) * 4 + f], acc[w2], 0, 0, 0);
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4)
-#pragma unroll
-                        for (int w2 = 0; w2 < QW; ++w2)
-                            acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                af[jl & 1][j4], qf[w2][(part * LS + jl) * 4 + j4], acc[w2], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (++cslot == R) cslot = 0;
@@ -218,6 +259,10 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                 float m = acc[w2][0];
 #pragma unroll
                 for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[w2][v]);
+                if constexpr (ABL != 0) {
+                    asm volatile("" ::"v"(m));
+                    m = -__builtin_inff();
+                }
                 if (__builtin_amdgcn_ballot_w64(m > thr[w2]) != 0ull) {
                     // (1) make room: a tile adds at most 32 entries per query
                     u64 need = __builtin_amdgcn_ballot_w64(cnt[w2] > (unsigned)(CAP - 32)) & 0xffffffffull;
@@ -236,21 +281,63 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                         if (hm != 0ull) {
                             const unsigned hl = ((unsigned)hm >> ql) & 1u;
                             const unsigned hh = ((unsigned)(hm >> 32) >> ql) & 1u;
-                            if (hit) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
+                            if (hit) {
+                                buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
+                                float x = acc[w2][v];  // insert into this half-lane's RB best
+#pragma unroll
+                                for (int r = 0; r < RB; ++r) {
+                                    const float hi = fmaxf(best[w2][r], x);
+                                    x = fminf(best[w2][r], x);
+                                    best[w2][r] = hi;
+                                }
+                            }
                             cnt[w2] += hl + hh;
                         }
                     }
                 }
             }
-            // ---- pick up thresholds published by other workgroups (filter hint only) --------
-            if (a.share && (i & 7) == 7) {
+            // ---- threshold exchange through the slot table (filter hint only) ---------------
+            // Exchanges run on a geometric schedule of the tile ordinal (0,1,2,4,7,11,17,...): the
+            // bound tightens like 1/i, so this keeps it within ~1.5x of what continuous polling
+            // would give at ~20 exchanges per launch; every wave of the workgroup exchanges at the
+            // same tiles so the L2 round trips overlap instead of adding up across waves.
+            if (a.share && i >= next_poll) {
+                next_poll = i + 1 + (i >> 1);
 #pragma unroll
                 for (int w2 = 0; w2 < QW; ++w2) {
+                    // publish: this half-lane's RB-th best appended score -> slot b % 64
                     const int q = (wave * QW + w2) * 32 + ql;
-                    const unsigned g = __hip_atomic_load(a.gthr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // a row that TIES a foreign KP-th best may still win on row index: inclusive
-                    // compare, i.e. exclusive against the next lower float
-                    if (g > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(g - 1u));
+                    const float mine = best[w2][RB - 1];
+                    if (mine > pub[w2]) {
+                        pub[w2] = mine;
+                        __hip_atomic_fetch_max(a.gthr + (size_t)q * 64 + (b & 63), bh_ordf(mine), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int w2 = 0; w2 < QW; ++w2) {
+                    // poll: 16 lanes x 4 slots cover one query; 4 queries per load instruction
+                    uint4 sl[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int q = (wave * QW + w2) * 32 + it * 4 + (lane >> 4);
+                        const unsigned* src = a.gthr + (size_t)q * 64 + (lane & 15) * 4;
+                        sl[it].x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sl[it].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sl[it].z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sl[it].w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        unsigned mn = min(min(sl[it].x, sl[it].y), min(sl[it].z, sl[it].w));
+#pragma unroll
+                        for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
+                        // lanes 16g..16g+15 now hold the minimum of query it*4+g
+                        const unsigned mine = (unsigned)__shfl((int)mn, (ql & 3) * 16, 64);
+                        // a row that TIES the bound may still win on row index: inclusive compare,
+                        // i.e. exclusive against the next lower float
+                        if ((ql >> 2) == it && mine > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(mine - 1u));
+                    }
                 }
             }
         }
@@ -274,11 +361,11 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 
-template <int NK, int KP, int LS, int R, int QW, bool NT>
+template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0>
 static hipError_t launch_one(const BhScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t smem = (size_t)R * 32 * LS * 128;
     static bool attr_done = false;
-    auto kern = bh_scan_topk_kernel<NK, KP, LS, R, QW, NT>;
+    auto kern = bh_scan_topk_kernel<NK, KP, LS, R, QW, NT, ABL>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -292,6 +379,16 @@ static hipError_t launch_one(const BhScanArgs& a, int grid, hipStream_t stream) 
 template <int NK, int LS, int R, int QW>
 static hipError_t launch_kp(const BhScanArgs& a, int kp, int grid, hipStream_t stream) {
     const bool nt = a.nontemporal != 0;
+    if constexpr (NK == 48 && QW == 1 && LS == 6 && R == 6) {
+        if (a.ablate != 0 && kp == 64) {  // bench-only ablations of the d=768 kernel
+            switch (a.ablate) {
+                case 1: return launch_one<NK, 64, LS, R, QW, true, 1>(a, grid, stream);
+                case 2: return launch_one<NK, 64, LS, R, QW, true, 2>(a, grid, stream);
+                case 3: return launch_one<NK, 64, LS, R, QW, true, 3>(a, grid, stream);
+                case 4: return launch_one<NK, 64, LS, R, QW, true, 4>(a, grid, stream);
+            }
+        }
+    }
     switch (kp) {
         case 64:
             return nt ? launch_one<NK, 64, LS, R, QW, true>(a, grid, stream)
@@ -310,7 +407,7 @@ static hipError_t launch_kp(const BhScanArgs& a, int kp, int grid, hipStream_t s
 template <int NK, int LS, int R>
 static hipError_t launch_qw(const BhScanArgs& a, int kp, int qw, int grid, hipStream_t stream) {
     if (qw == 1) return launch_kp<NK, LS, R, 1>(a, kp, grid, stream);
-    if constexpr (NK == 48 || NK == 24) {
+    if constexpr (NK == 24) {
         if (qw == 2) return launch_kp<NK, LS, R, 2>(a, kp, grid, stream);
     }
     return hipErrorInvalidValue;
@@ -324,15 +421,23 @@ hipError_t bh_launch_scan(const BhScanArgs& a, int dim_padded, int kp, int qw, i
         case 256: return launch_qw<16, 4, 6>(a, kp, qw, grid, stream);
         case 384: return launch_qw<24, 6, 6>(a, kp, qw, grid, stream);
         case 512: return launch_qw<32, 8, 4>(a, kp, qw, grid, stream);
-        case 768: return launch_qw<48, 6, 6>(a, kp, qw, grid, stream);
+        case 768:
+            // ring geometry variants (bench option "ring_variant"): lines per stage x ring depth
+            if (a.ring_variant == 1 && kp == 64) return launch_kp<48, 12, 3, 1>(a, kp, grid, stream);
+            if (a.ring_variant == 2 && kp == 64) return launch_kp<48, 4, 9, 1>(a, kp, grid, stream);
+            if (a.ring_variant == 3 && kp == 64) return launch_kp<48, 3, 12, 1>(a, kp, grid, stream);
+            if (a.ring_variant == 4 && kp == 64) return launch_kp<48, 6, 5, 1>(a, kp, grid, stream);
+            return launch_qw<48, 6, 6>(a, kp, qw, grid, stream);
         case 1024: return launch_qw<64, 8, 4>(a, kp, qw, grid, stream);
     }
     return hipErrorInvalidValue;
 }
 
-// Query-tile widths: 128 everywhere; 256 (two 32-query blocks per wave) for d in {384, 768}
-// with candidate lists up to 128.
+// Query-tile widths: 128 everywhere; 256 (two 32-query blocks per wave) only where both blocks'
+// fragments fit the register file without spilling: d = 384 with candidate lists up to 128.
+// (d = 768 needs 384 + 32 + 64 registers before any state: hipcc spills, and its reload of
+// split AGPR tuples was observed to be wrong — not shipped.)
 bool bh_scan_supports(int dim_padded, int kp, int qw) {
     if (qw == 1) return true;
-    return qw == 2 && (dim_padded == 768 || dim_padded == 384) && kp <= 128;
+    return qw == 2 && dim_padded == 384 && kp <= 128;
 }

@@ -12,14 +12,14 @@ export TMPDIR=/tmp
 cd /tmp
 BENCH="python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
 echo "== kernel trace + stats" 
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
 echo "exit $?" >> "$OUT/trace.log"
 if [ "${2:-}" = "pmc" ]; then
   echo "== PMC pass 1: FETCH_SIZE"
-  timeout 900 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH --steps 1 > "$OUT/pmc_fetch.log" 2>&1
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "bh_scan" --output-format csv -d "$OUT/pmc_fetch" -o bench -- $BENCH --steps 1 > "$OUT/pmc_fetch.log" 2>&1
   echo "== PMC pass 2: WRITE_SIZE"
-  timeout 900 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o bench -- $BENCH --steps 1 > "$OUT/pmc_write.log" 2>&1
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "bh_scan" --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH --steps 1 > "$OUT/pmc_write.log" 2>&1
   echo "== PMC pass 3: SQ"
-  timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o bench -- $BENCH --steps 1 > "$OUT/pmc_sq.log" 2>&1
+  timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-include-regex "bh_scan" --output-format csv -d "$OUT/pmc_sq" -o bench -- $BENCH --steps 1 > "$OUT/pmc_sq.log" 2>&1
 fi
 find "$OUT" -name "*.csv" | head -50
