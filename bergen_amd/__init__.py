@@ -10,6 +10,7 @@ there is no CPU fallback.
   Retrieve            stage object, drop-in for modules.retrieve.Retrieve
   Dense, MeanPooler, ClsPooler, DotProduct, CosineSim
                       model plug-in, drop-in for models.retrievers.dense.*
+  BertEncoder         BERT-architecture forward pass on hand-written HIP kernels (HF AutoModel drop-in)
   FlatIndex           resident HBM index + fused inner-product/top-k search
   merge_topk          device merge of per-shard partial top-k lists
   ShardedSearcher     row-sharded multi-GPU search (one process per GPU, RCCL all-gather)
@@ -18,6 +19,7 @@ there is no CPU fallback.
 from . import utils  # noqa: F401
 from .config import instantiate  # noqa: F401
 from .dense import ClsPooler, CosineSim, Dense, DotProduct, MeanPooler, Retriever  # noqa: F401
+from .encoder import BertEncoder  # noqa: F401
 from .index import FlatIndex, merge_topk  # noqa: F401
 from .retrieve import Retrieve  # noqa: F401
 from .sharded import ShardedSearcher, shard_range  # noqa: F401

@@ -42,6 +42,31 @@ class bh_counters(ctypes.Structure):
     ]
 
 
+class bh_encoder_config(ctypes.Structure):
+    _fields_ = [
+        ("n_layers", ctypes.c_int32),
+        ("hidden", ctypes.c_int32),
+        ("n_heads", ctypes.c_int32),
+        ("intermediate", ctypes.c_int32),
+        ("vocab_size", ctypes.c_int32),
+        ("max_position", ctypes.c_int32),
+        ("type_vocab_size", ctypes.c_int32),
+        ("activation", ctypes.c_int32),
+        ("ln_eps", ctypes.c_float),
+    ]
+
+
+class bh_encoder_counters(ctypes.Structure):
+    _fields_ = [
+        ("batch", ctypes.c_int32),
+        ("seq_len", ctypes.c_int32),
+        ("real_tokens", ctypes.c_int64),
+        ("packed_rows", ctypes.c_int64),
+        ("forward_ms", ctypes.c_double),
+        ("flops", ctypes.c_double),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/bergen_hip.h declares
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -63,6 +88,18 @@ SYMBOLS = {
     "bh_merge_topk_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "bh_bench_counters": (ctypes.c_int, [_vp, ctypes.POINTER(bh_counters)]),
     "bh_set_option": (ctypes.c_int, [ctypes.c_char_p, _i64]),
+    "bh_encoder_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(bh_encoder_config)]),
+    "bh_encoder_set_tensor": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, _i32, _i64]),
+    "bh_encoder_commit": (ctypes.c_int, [_vp]),
+    "bh_encoder_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i64]),
+    "bh_encoder_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32]),
+    "bh_encoder_counters_get": (ctypes.c_int, [_vp, ctypes.POINTER(bh_encoder_counters)]),
+    "bh_encoder_destroy": (None, [_vp]),
+    "bh_op_gemm_f16": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _i32,
+                                      _i32, _i32, ctypes.POINTER(ctypes.c_float)]),
+    "bh_op_attention": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32]),
+    "bh_op_layernorm": (ctypes.c_int, [_vp, _vp, _i64, _i32, ctypes.c_float, _vp, _vp]),
+    "bh_gemm_permlane_mode": (ctypes.c_int, []),
 }
 
 _lib = None

@@ -48,3 +48,80 @@ hipError_t bh_launch_convert_rows(const void* src, int src_dtype /*0=f16,1=f32*/
                                   _Float16* dst, int dim_padded, hipStream_t stream);
 hipError_t bh_launch_l2_normalize_rows(_Float16* rows, long long n, int dim, int dim_padded, hipStream_t stream);
 hipError_t bh_launch_fill_u32(unsigned* p, long long n, unsigned v, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// bi-encoder forward pass (gemm_f16.hip, attention.hip, encoder_ops.hip; orchestrated by encoder.hip)
+
+struct BhGemmArgs {
+    const _Float16* A;  // [M][K], row stride lda (activations; K contiguous)
+    long long lda;
+    const _Float16* B;  // [N][K], row stride ldb (weights as HF stores them: [out][in])
+    long long ldb;
+    _Float16* C;  // [M][N], row stride ldc
+    long long ldc;
+    const _Float16* bias;      // bias_mode 1: [N] added per column; 2: [M] added per row; 0: none
+    const _Float16* residual;  // [M][N] row stride ldr, or null
+    long long ldr;
+    int M, N, K;  // K % 64 == 0; lda, ldb, ldc, ldr % 8 == 0
+    int bias_mode;
+    int gelu;    // erf-GELU on the result
+    int swap_b;  // filled by the launcher: direction of v_permlane32_swap on this device
+};
+// variant 0 = auto; see gemm_f16.hip for the explicit tile configurations
+hipError_t bh_launch_gemm_f16(const BhGemmArgs& a, int variant, hipStream_t stream);
+hipError_t bh_gemm_probe_permlane(hipStream_t stream);
+int bh_gemm_swap_mode();
+
+struct BhAttnArgs {
+    const _Float16* qk;  // [tokens][2*d_model]: queries in columns [0, d), keys in [d, 2d)
+    long long ldqk;
+    const _Float16* vt;  // [d_model][ldvt]: values, transposed (column = token)
+    long long ldvt;
+    _Float16* ctx;  // [tokens][d_model]
+    long long ldc;
+    const long long* seq_off;  // [batch] first row of each sequence (multiple of 8)
+    const int* seq_len;        // [batch] tokens per sequence (>= 1)
+    int d_model;
+};
+hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
+
+struct BhEmbedArgs {
+    const int* tok;  // [n_rows] token id / position id / token-type id of each packed row
+    const int* pos;
+    const int* typ;
+    long long n_rows;
+    int d;
+    float eps;
+    const _Float16 *word, *position, *type, *gamma, *beta;
+    _Float16* out;  // [n_rows][d]
+};
+hipError_t bh_launch_embed_ln(const BhEmbedArgs& a, hipStream_t stream);
+
+struct BhLnArgs {
+    const _Float16* in;
+    _Float16* out;  // may alias in
+    long long n_rows;
+    int d;
+    float eps;
+    const _Float16 *gamma, *beta;
+};
+hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t stream);
+
+struct BhPoolArgs {
+    const _Float16* x;  // [tokens][d]
+    _Float16* out;      // [batch][d]
+    const long long* seq_off;
+    const int* seq_len;
+    int batch, d;
+    int mode;  // 0 = CLS (first token), 1 = mean
+    int l2_normalize;
+};
+hipError_t bh_launch_pool(const BhPoolArgs& a, hipStream_t stream);
+
+struct BhUnpackArgs {
+    const _Float16* x;  // [tokens][d]
+    _Float16* out;      // [batch][seq_len_padded][d]
+    const int* slot;    // [batch*seq_len_padded] packed row or -1
+    int batch, seq_len_padded, d;
+};
+hipError_t bh_launch_unpack(const BhUnpackArgs& a, hipStream_t stream);

@@ -1,0 +1,528 @@
+// encoder.hip — C ABI (include/bergen_hip.h, bh_encoder_*): the bi-encoder forward pass on gfx950.
+//
+// Reference behaviour being replaced (naver/bergen):
+//   models/retrievers/dense.py:16-20   AutoModel.from_pretrained(..., torch_dtype=float16)   -> bh_encoder_create /
+//                                                                                               set_tensor / commit
+//   models/retrievers/dense.py:37-47   Dense.__call__: kwargs.to(device); model(**kwargs)[0]; pooler.pool(...)
+//                                                                                            -> bh_encoder_forward
+//   models/retrievers/dense.py:64-75   MeanPooler.pool / ClsPooler.pool                      -> bh_pool_kernel
+//   models/retrievers/dense.py:32-35   torch.nn.DataParallel                                 -> not carried over:
+//                                      one process per GPU, weights resident once, dataset range-partitioned.
+// The architecture is HF BertModel (post-LN encoder, absolute positions, erf-GELU): RetroMAE, contriever,
+// e5-*, bge-* checkpoints named in the reference's config/retriever/*.yaml all load as BertModel.
+//
+// Token packing.  The reference pads every sequence to the longest of the batch (dense.py:57,
+// padding="longest") and runs the padding through every layer.  Here tokens with attention_mask != 0 are
+// packed back to back (each sequence starts at a row that is a multiple of 8): GEMMs, LayerNorms and the
+// attention see real tokens only.  For real tokens the result equals the padded computation (masked keys have
+// zero probability there too).  Rows between sequences and after the last one hold a [PAD]-like dummy token so
+// that every intermediate stays finite; nothing ever reads them as data.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bh_host.h"
+#include "bh_kernels.h"
+
+namespace {
+
+struct Layer {
+    _Float16 *wqk = nullptr, *bqk = nullptr;  // [2d][d], [2d]   query rows then key rows
+    _Float16 *wv = nullptr, *bv = nullptr;    // [d][d], [d]
+    _Float16 *wo = nullptr, *bo = nullptr;    // [d][d], [d]
+    _Float16 *ln1g = nullptr, *ln1b = nullptr;
+    _Float16 *w1 = nullptr, *b1 = nullptr;  // [dff][d], [dff]
+    _Float16 *w2 = nullptr, *b2 = nullptr;  // [d][dff], [d]
+    _Float16 *ln2g = nullptr, *ln2b = nullptr;
+};
+
+int round_up(long long v, int m) { return (int)((v + m - 1) / m * m); }
+
+}  // namespace
+
+struct bh_encoder {
+    bh_encoder_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    _Float16* arena = nullptr;  // all weights, one allocation
+    size_t arena_elems = 0;
+    _Float16 *word = nullptr, *position = nullptr, *type = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    std::vector<Layer> layers;
+    std::map<std::string, std::pair<_Float16*, int64_t>> slots;  // tensor name -> (device dst, numel)
+    std::map<std::string, bool> have;
+    bool committed = false;
+    int gemm_variant = 0;
+    // workspace
+    BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
+    BhDevBuf<int> ibuf;          // tok | pos | typ | seq_len | slot
+    BhDevBuf<long long> seq_off;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bh_encoder_counters counters{};
+};
+
+namespace {
+
+int build_slots(bh_encoder* e) {
+    const bh_encoder_config& c = e->cfg;
+    const size_t d = c.hidden, dff = c.intermediate;
+    size_t total = (size_t)c.vocab_size * d + (size_t)c.max_position * d + (size_t)c.type_vocab_size * d + 2 * d;
+    const size_t per_layer = 2 * d * d + 2 * d + d * d + d + d * d + d + 2 * d + dff * d + dff + d * dff + d + 2 * d;
+    total += per_layer * c.n_layers;
+    total += 64;
+    BH_HIP_TRY(hipMalloc((void**)&e->arena, total * sizeof(_Float16)));
+    e->arena_elems = total;
+    _Float16* p = e->arena;
+    auto take = [&](size_t n) {
+        _Float16* r = p;
+        p += (n + 7) / 8 * 8;  // keep every tensor 16-byte aligned
+        return r;
+    };
+    // (arena was sized without the per-tensor rounding; all sizes here are multiples of 8 because d % 64 == 0)
+    e->word = take((size_t)c.vocab_size * d);
+    e->position = take((size_t)c.max_position * d);
+    e->type = take((size_t)c.type_vocab_size * d);
+    e->emb_g = take(d);
+    e->emb_b = take(d);
+    auto& S = e->slots;
+    S["embeddings.word_embeddings.weight"] = {e->word, (int64_t)c.vocab_size * d};
+    S["embeddings.position_embeddings.weight"] = {e->position, (int64_t)c.max_position * d};
+    S["embeddings.token_type_embeddings.weight"] = {e->type, (int64_t)c.type_vocab_size * d};
+    S["embeddings.LayerNorm.weight"] = {e->emb_g, (int64_t)d};
+    S["embeddings.LayerNorm.bias"] = {e->emb_b, (int64_t)d};
+    e->layers.resize(c.n_layers);
+    for (int l = 0; l < c.n_layers; ++l) {
+        Layer& L = e->layers[l];
+        L.wqk = take(2 * d * d);
+        L.bqk = take(2 * d);
+        L.wv = take(d * d);
+        L.bv = take(d);
+        L.wo = take(d * d);
+        L.bo = take(d);
+        L.ln1g = take(d);
+        L.ln1b = take(d);
+        L.w1 = take(dff * d);
+        L.b1 = take(dff);
+        L.w2 = take(d * dff);
+        L.b2 = take(d);
+        L.ln2g = take(d);
+        L.ln2b = take(d);
+        const std::string pre = "encoder.layer." + std::to_string(l) + ".";
+        S[pre + "attention.self.query.weight"] = {L.wqk, (int64_t)(d * d)};
+        S[pre + "attention.self.key.weight"] = {L.wqk + d * d, (int64_t)(d * d)};
+        S[pre + "attention.self.query.bias"] = {L.bqk, (int64_t)d};
+        S[pre + "attention.self.key.bias"] = {L.bqk + d, (int64_t)d};
+        S[pre + "attention.self.value.weight"] = {L.wv, (int64_t)(d * d)};
+        S[pre + "attention.self.value.bias"] = {L.bv, (int64_t)d};
+        S[pre + "attention.output.dense.weight"] = {L.wo, (int64_t)(d * d)};
+        S[pre + "attention.output.dense.bias"] = {L.bo, (int64_t)d};
+        S[pre + "attention.output.LayerNorm.weight"] = {L.ln1g, (int64_t)d};
+        S[pre + "attention.output.LayerNorm.bias"] = {L.ln1b, (int64_t)d};
+        S[pre + "intermediate.dense.weight"] = {L.w1, (int64_t)(dff * d)};
+        S[pre + "intermediate.dense.bias"] = {L.b1, (int64_t)dff};
+        S[pre + "output.dense.weight"] = {L.w2, (int64_t)(d * dff)};
+        S[pre + "output.dense.bias"] = {L.b2, (int64_t)d};
+        S[pre + "output.LayerNorm.weight"] = {L.ln2g, (int64_t)d};
+        S[pre + "output.LayerNorm.bias"] = {L.ln2b, (int64_t)d};
+    }
+    if ((size_t)(p - e->arena) > total) return bh_fail(BH_EHIP, "internal: weight arena overflow");
+    return BH_OK;
+}
+
+int gemm(bh_encoder* e, const _Float16* A, long long lda, const _Float16* B, long long ldb, _Float16* C, long long ldc,
+         int M, int N, int K, const _Float16* bias, int bias_mode, const _Float16* residual, long long ldr, int gelu) {
+    BhGemmArgs g{};
+    g.A = A;
+    g.lda = lda;
+    g.B = B;
+    g.ldb = ldb;
+    g.C = C;
+    g.ldc = ldc;
+    g.bias = bias;
+    g.bias_mode = bias ? bias_mode : 0;
+    g.residual = residual;
+    g.ldr = ldr;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.gelu = gelu;
+    BH_HIP_TRY(bh_launch_gemm_f16(g, e->gemm_variant, e->stream));
+    return BH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
+    if (!out) return bh_fail(BH_EINVAL, "null out");
+    *out = nullptr;
+    if (!cfg) return bh_fail(BH_EINVAL, "null config");
+    const bh_encoder_config& c = *cfg;
+    if (c.n_layers <= 0 || c.hidden <= 0 || c.n_heads <= 0 || c.intermediate <= 0 || c.vocab_size <= 0 ||
+        c.max_position <= 0 || c.type_vocab_size <= 0)
+        return bh_fail(BH_EINVAL, "encoder config has non-positive fields");
+    if (c.hidden % 64 != 0 || c.hidden > 2048 || c.hidden != c.n_heads * 64)
+        return bh_fail(BH_EUNSUPPORTED, "hidden=%d heads=%d unsupported: head dim must be 64, hidden <= 2048", c.hidden,
+                       c.n_heads);
+    if (c.intermediate % 64 != 0) return bh_fail(BH_EUNSUPPORTED, "intermediate=%d must be a multiple of 64", c.intermediate);
+    if (c.activation != 0) return bh_fail(BH_EUNSUPPORTED, "activation %d unsupported (0 = erf-GELU)", c.activation);
+    int dev = 0;
+    BH_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    BH_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bh_fail(BH_EUNSUPPORTED, "device %d is %s; gfx950 required", dev, prop.gcnArchName);
+    bh_encoder* e = new bh_encoder();
+    e->cfg = c;
+    e->device = dev;
+    int rc = build_slots(e);
+    if (rc == BH_OK) {
+        hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+        if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+        if (he != hipSuccess) rc = bh_fail(BH_EHIP, "stream/event create: %s", hipGetErrorString(he));
+    }
+    if (rc != BH_OK) {
+        bh_encoder_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return BH_OK;
+}
+
+void bh_encoder_destroy(bh_encoder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->X.release();
+    e->Y.release();
+    e->QK.release();
+    e->VT.release();
+    e->CTX.release();
+    e->H.release();
+    e->OUT.release();
+    e->ibuf.release();
+    e->seq_off.release();
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int bh_encoder_set_tensor(bh_encoder* e, const char* name, const void* host, int32_t dtype, int64_t numel) {
+    if (!e || !name || !host) return bh_fail(BH_EINVAL, "null argument");
+    if (dtype != BH_F16 && dtype != BH_F32) return bh_fail(BH_EINVAL, "bad dtype %d", dtype);
+    std::string key(name);
+    for (const char* pre : {"bert.", "model."})  // tolerate task-model prefixes
+        if (key.rfind(pre, 0) == 0 && !e->slots.count(key)) key = key.substr(strlen(pre));
+    auto it = e->slots.find(key);
+    if (it == e->slots.end()) return bh_fail(BH_EINVAL, "unknown tensor '%s'", name);
+    if (it->second.second != numel)
+        return bh_fail(BH_EINVAL, "tensor '%s': expected %lld elements, got %lld", name, (long long)it->second.second,
+                       (long long)numel);
+    BH_HIP_TRY(hipSetDevice(e->device));
+    if (dtype == BH_F16) {
+        BH_HIP_TRY(hipMemcpy(it->second.first, host, (size_t)numel * 2, hipMemcpyHostToDevice));
+    } else {
+        std::vector<_Float16> tmp((size_t)numel);
+        const float* src = static_cast<const float*>(host);
+        for (int64_t i = 0; i < numel; ++i) tmp[(size_t)i] = (_Float16)src[i];  // round-to-nearest-even, like .half()
+        BH_HIP_TRY(hipMemcpy(it->second.first, tmp.data(), (size_t)numel * 2, hipMemcpyHostToDevice));
+    }
+    e->have[key] = true;
+    e->committed = false;
+    return BH_OK;
+}
+
+int bh_encoder_commit(bh_encoder* e) {
+    if (!e) return bh_fail(BH_EINVAL, "null encoder");
+    for (auto& kv : e->slots)
+        if (!e->have.count(kv.first)) return bh_fail(BH_EINCOMPLETE, "encoder weight '%s' was never set", kv.first.c_str());
+    e->committed = true;
+    return BH_OK;
+}
+
+int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
+    if (!e || !name) return bh_fail(BH_EINVAL, "null argument");
+    if (std::string(name) == "gemm_variant") {
+        if (value < 0 || value > 7) return bh_fail(BH_EINVAL, "gemm_variant must be 0..7");
+        e->gemm_variant = (int)value;
+        return BH_OK;
+    }
+    return bh_fail(BH_EINVAL, "unknown encoder option '%s'", name);
+}
+
+int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* attention_mask,
+                       const int64_t* token_type_ids, int32_t batch, int32_t seq_len, int32_t pool,
+                       int32_t l2_normalize, void* out, int32_t out_on_device) {
+    if (!e) return bh_fail(BH_EINVAL, "null encoder");
+    if (!e->committed) return bh_fail(BH_EINCOMPLETE, "encoder weights not committed (bh_encoder_commit)");
+    if (batch < 0 || seq_len <= 0) return bh_fail(BH_EINVAL, "batch=%d seq_len=%d", batch, seq_len);
+    if (pool < 0 || pool > 2) return bh_fail(BH_EINVAL, "pool must be 0 (cls), 1 (mean) or 2 (hidden states)");
+    if (batch == 0) return BH_OK;
+    if (!input_ids || !out) return bh_fail(BH_EINVAL, "null buffer");
+    const bh_encoder_config& c = e->cfg;
+    if (seq_len > c.max_position) return bh_fail(BH_EINVAL, "seq_len %d exceeds max_position %d", seq_len, c.max_position);
+    if (batch > 65535) return bh_fail(BH_EUNSUPPORTED, "batch %d too large (max 65535)", batch);
+    const int d = c.hidden, dff = c.intermediate;
+
+    // ---- packing plan (host)
+    std::vector<long long> off(batch);
+    std::vector<int> len(batch);
+    long long cursor = 0;
+    int max_len = 0;
+    long long real_tokens = 0;
+    double len_sq = 0;
+    for (int b = 0; b < batch; ++b) {
+        int n = 0;
+        for (int t = 0; t < seq_len; ++t) n += attention_mask ? (attention_mask[(size_t)b * seq_len + t] != 0) : 1;
+        if (n == 0) return bh_fail(BH_EINVAL, "sequence %d has an all-zero attention mask", b);
+        if (pool == 0 && attention_mask && attention_mask[(size_t)b * seq_len] == 0)
+            return bh_fail(BH_EINVAL, "CLS pooling needs attention_mask[%d][0] != 0", b);
+        off[b] = cursor;
+        len[b] = n;
+        cursor = (cursor + n + 7) / 8 * 8;
+        max_len = std::max(max_len, n);
+        real_tokens += n;
+        len_sq += (double)n * n;
+    }
+    const int m_pad = round_up(cursor + 32, 256);  // +32: the attention's last key block may read past a sequence
+    // tok | pos | typ  [m_pad each] | seq_len [batch] | slot [batch*seq_len] (pool == 2 only)
+    const size_t n_slot = pool == 2 ? (size_t)batch * seq_len : 0;
+    std::vector<int> ib((size_t)3 * m_pad + batch + n_slot, 0);
+    int* tok = ib.data();
+    int* pos = tok + m_pad;
+    int* typ = pos + m_pad;
+    int* slen = typ + m_pad;
+    int* slot = slen + batch;
+    for (int b = 0; b < batch; ++b) {
+        slen[b] = len[b];
+        long long r = off[b];
+        for (int t = 0; t < seq_len; ++t) {
+            const size_t i = (size_t)b * seq_len + t;
+            const bool keep = attention_mask ? attention_mask[i] != 0 : true;
+            if (pool == 2) slot[i] = keep ? (int)r : -1;
+            if (!keep) continue;
+            const long long id = input_ids[i];
+            if (id < 0 || id >= c.vocab_size) return bh_fail(BH_EINVAL, "token id %lld out of range at [%d][%d]", id, b, t);
+            const long long ty = token_type_ids ? token_type_ids[i] : 0;
+            if (ty < 0 || ty >= c.type_vocab_size) return bh_fail(BH_EINVAL, "token type %lld out of range", ty);
+            tok[r] = (int)id;
+            pos[r] = t;
+            typ[r] = (int)ty;
+            ++r;
+        }
+    }
+
+    BH_HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    int rc;
+    const size_t M = (size_t)m_pad;
+    if ((rc = e->X.ensure(M * d))) return rc;
+    if ((rc = e->Y.ensure(M * d))) return rc;
+    if ((rc = e->QK.ensure(M * 2 * d))) return rc;
+    if ((rc = e->VT.ensure(M * d))) return rc;
+    if ((rc = e->CTX.ensure(M * d, /*zero_new=*/true, st))) return rc;  // rows between sequences are never written
+    if ((rc = e->H.ensure(M * dff))) return rc;
+    if ((rc = e->ibuf.ensure(ib.size()))) return rc;
+    if ((rc = e->seq_off.ensure(batch))) return rc;
+    const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : (size_t)batch * d;
+    _Float16* out_dev = static_cast<_Float16*>(out);
+    if (!out_on_device) {
+        if ((rc = e->OUT.ensure(out_elems))) return rc;
+        out_dev = e->OUT.p;
+    }
+    BH_HIP_TRY(hipMemcpyAsync(e->ibuf.p, ib.data(), ib.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    BH_HIP_TRY(hipMemcpyAsync(e->seq_off.p, off.data(), (size_t)batch * sizeof(long long), hipMemcpyHostToDevice, st));
+    const int* d_tok = e->ibuf.p;
+    const int* d_pos = d_tok + m_pad;
+    const int* d_typ = d_pos + m_pad;
+    const int* d_len = d_typ + m_pad;
+    const int* d_slot = d_len + batch;
+
+    BH_HIP_TRY(hipEventRecord(e->ev0, st));
+    BhEmbedArgs ea{};
+    ea.tok = d_tok;
+    ea.pos = d_pos;
+    ea.typ = d_typ;
+    ea.n_rows = m_pad;
+    ea.d = d;
+    ea.eps = c.ln_eps;
+    ea.word = e->word;
+    ea.position = e->position;
+    ea.type = e->type;
+    ea.gamma = e->emb_g;
+    ea.beta = e->emb_b;
+    ea.out = e->X.p;
+    BH_HIP_TRY(bh_launch_embed_ln(ea, st));
+
+    for (int l = 0; l < c.n_layers; ++l) {
+        const Layer& L = e->layers[l];
+        // Q | K projections: QK[m][2d] = X Wqk^T + bqk
+        if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * d, m_pad, 2 * d, d, L.bqk, 1, nullptr, 0, 0))) return rc;
+        // V projection, written TRANSPOSED: VT[d][m] = Wv X^T + bv (bias per row)
+        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, d, m_pad, d, L.bv, 2, nullptr, 0, 0))) return rc;
+        BhAttnArgs aa{};
+        aa.qk = e->QK.p;
+        aa.ldqk = 2 * d;
+        aa.vt = e->VT.p;
+        aa.ldvt = m_pad;
+        aa.ctx = e->CTX.p;
+        aa.ldc = d;
+        aa.seq_off = e->seq_off.p;
+        aa.seq_len = d_len;
+        aa.d_model = d;
+        BH_HIP_TRY(bh_launch_attention(aa, batch, c.n_heads, max_len, st));
+        // attention output projection + residual, then LayerNorm
+        if ((rc = gemm(e, e->CTX.p, d, L.wo, d, e->Y.p, d, m_pad, d, d, L.bo, 1, e->X.p, d, 0))) return rc;
+        BhLnArgs la{};
+        la.in = e->Y.p;
+        la.out = e->X.p;
+        la.n_rows = m_pad;
+        la.d = d;
+        la.eps = c.ln_eps;
+        la.gamma = L.ln1g;
+        la.beta = L.ln1b;
+        BH_HIP_TRY(bh_launch_layernorm(la, st));
+        // FFN: H = GELU(X W1^T + b1);  Y = H W2^T + b2 + X;  X = LN(Y)
+        if ((rc = gemm(e, e->X.p, d, L.w1, d, e->H.p, dff, m_pad, dff, d, L.b1, 1, nullptr, 0, 1))) return rc;
+        if ((rc = gemm(e, e->H.p, dff, L.w2, dff, e->Y.p, d, m_pad, d, dff, L.b2, 1, e->X.p, d, 0))) return rc;
+        la.gamma = L.ln2g;
+        la.beta = L.ln2b;
+        BH_HIP_TRY(bh_launch_layernorm(la, st));
+    }
+    if (pool == 2) {
+        BhUnpackArgs ua{};
+        ua.x = e->X.p;
+        ua.out = out_dev;
+        ua.slot = d_slot;
+        ua.batch = batch;
+        ua.seq_len_padded = seq_len;
+        ua.d = d;
+        BH_HIP_TRY(bh_launch_unpack(ua, st));
+    } else {
+        BhPoolArgs pa{};
+        pa.x = e->X.p;
+        pa.out = out_dev;
+        pa.seq_off = e->seq_off.p;
+        pa.seq_len = d_len;
+        pa.batch = batch;
+        pa.d = d;
+        pa.mode = pool;
+        pa.l2_normalize = l2_normalize;
+        BH_HIP_TRY(bh_launch_pool(pa, st));
+    }
+    BH_HIP_TRY(hipEventRecord(e->ev1, st));
+    if (!out_on_device) BH_HIP_TRY(hipMemcpyAsync(out, out_dev, out_elems * 2, hipMemcpyDeviceToHost, st));
+    BH_HIP_TRY(hipStreamSynchronize(st));
+
+    float ms = 0;
+    BH_HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    bh_encoder_counters& k = e->counters;
+    k.batch = batch;
+    k.seq_len = seq_len;
+    k.real_tokens = real_tokens;
+    k.packed_rows = m_pad;
+    k.forward_ms = ms;
+    // algorithmic flops over REAL tokens: per layer 8 T d^2 + 4 T d dff (projections) + 4 sum(len^2) d (attention)
+    k.flops = (double)c.n_layers *
+              ((double)real_tokens * (8.0 * d * d + 4.0 * d * dff) + 4.0 * len_sq * d);
+    return BH_OK;
+}
+
+int bh_encoder_counters_get(const bh_encoder* e, bh_encoder_counters* out) {
+    if (!e || !out) return bh_fail(BH_EINVAL, "null argument");
+    *out = e->counters;
+    return BH_OK;
+}
+
+// ---- op-level entry points (device pointers; used by the parity tests and the kernel micro-benchmarks) -----
+
+int bh_op_gemm_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                   int32_t bias_mode, const void* residual, int64_t ldr, int32_t M, int32_t N, int32_t K, int32_t gelu,
+                   int32_t variant, int32_t repeats, float* avg_ms) {
+    if (!A || !B || !C) return bh_fail(BH_EINVAL, "null buffer");
+    if (M < 0 || N < 0 || K <= 0 || (K & 63)) return bh_fail(BH_EUNSUPPORTED, "M=%d N=%d K=%d (K must be a multiple of 64)", M, N, K);
+    if ((lda & 7) || (ldb & 7) || (ldc & 7) || (residual && (ldr & 7)))
+        return bh_fail(BH_EUNSUPPORTED, "leading dimensions must be multiples of 8");
+    if (bias_mode < 0 || bias_mode > 2) return bh_fail(BH_EINVAL, "bias_mode %d", bias_mode);
+    BhGemmArgs g{};
+    g.A = static_cast<const _Float16*>(A);
+    g.lda = lda;
+    g.B = static_cast<const _Float16*>(B);
+    g.ldb = ldb;
+    g.C = static_cast<_Float16*>(C);
+    g.ldc = ldc;
+    g.bias = static_cast<const _Float16*>(bias);
+    g.bias_mode = bias ? bias_mode : 0;
+    g.residual = static_cast<const _Float16*>(residual);
+    g.ldr = ldr;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.gelu = gelu;
+    if (repeats < 1) repeats = 1;
+    hipEvent_t e0, e1;
+    BH_HIP_TRY(hipEventCreate(&e0));
+    BH_HIP_TRY(hipEventCreate(&e1));
+    hipError_t he = bh_launch_gemm_f16(g, variant, nullptr);  // first launch: probe + attribute setup, untimed
+    if (he == hipSuccess) he = hipEventRecord(e0, nullptr);
+    for (int r = 1; r < repeats && he == hipSuccess; ++r) he = bh_launch_gemm_f16(g, variant, nullptr);
+    if (he == hipSuccess) he = hipEventRecord(e1, nullptr);
+    if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+    float ms = 0;
+    if (he == hipSuccess && repeats > 1) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return bh_fail(BH_EHIP, "gemm variant %d: %s", variant, hipGetErrorString(he));
+    if (avg_ms) *avg_ms = repeats > 1 ? ms / (float)(repeats - 1) : 0.f;
+    return BH_OK;
+}
+
+int bh_op_attention(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* ctx, int64_t ldc,
+                    const int64_t* seq_off_dev, const int32_t* seq_len_dev, int32_t batch, int32_t n_heads,
+                    int32_t max_len) {
+    if (!qk || !vt || !ctx || !seq_off_dev || !seq_len_dev) return bh_fail(BH_EINVAL, "null buffer");
+    if (batch <= 0 || batch > 65535 || n_heads <= 0 || max_len <= 0) return bh_fail(BH_EINVAL, "bad sizes");
+    BhAttnArgs aa{};
+    aa.qk = static_cast<const _Float16*>(qk);
+    aa.ldqk = ldqk;
+    aa.vt = static_cast<const _Float16*>(vt);
+    aa.ldvt = ldvt;
+    aa.ctx = static_cast<_Float16*>(ctx);
+    aa.ldc = ldc;
+    aa.seq_off = reinterpret_cast<const long long*>(seq_off_dev);
+    aa.seq_len = seq_len_dev;
+    aa.d_model = n_heads * 64;
+    BH_HIP_TRY(bh_launch_attention(aa, batch, n_heads, max_len, nullptr));
+    BH_HIP_TRY(hipStreamSynchronize(nullptr));
+    return BH_OK;
+}
+
+int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float eps, const void* gamma, const void* beta) {
+    if (!in || !out || !gamma || !beta) return bh_fail(BH_EINVAL, "null buffer");
+    if (d <= 0 || (d & 7) || d > 2048) return bh_fail(BH_EUNSUPPORTED, "d=%d (multiple of 8, <= 2048)", d);
+    BhLnArgs la{};
+    la.in = static_cast<const _Float16*>(in);
+    la.out = static_cast<_Float16*>(out);
+    la.n_rows = n_rows;
+    la.d = d;
+    la.eps = eps;
+    la.gamma = static_cast<const _Float16*>(gamma);
+    la.beta = static_cast<const _Float16*>(beta);
+    BH_HIP_TRY(bh_launch_layernorm(la, nullptr));
+    BH_HIP_TRY(hipStreamSynchronize(nullptr));
+    return BH_OK;
+}
+
+int bh_gemm_permlane_mode(void) {
+    if (bh_gemm_probe_permlane(nullptr) != hipSuccess) return -1;
+    return bh_gemm_swap_mode();
+}
+
+}  // extern "C"

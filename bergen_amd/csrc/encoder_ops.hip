@@ -1,0 +1,201 @@
+// encoder_ops.hip — the HBM-bound row kernels of the bi-encoder forward pass.  One wave per token row,
+// 16-byte accesses, fp32 math, fp16 storage.
+//
+//   bh_embed_ln_kernel   word + position + token-type embedding gather, sum, LayerNorm
+//                        (BertEmbeddings.forward, transformers modeling_bert.py; reached from the
+//                        reference through AutoModel, models/retrievers/dense.py:16)
+//   bh_layernorm_kernel  LayerNorm of (dense output + residual) — the sum is already formed by the GEMM
+//                        epilogue (BertSelfOutput / BertOutput: LayerNorm(dense(x) + input))
+//   bh_pool_kernel       ClsPooler.pool / MeanPooler.pool (reference models/retrievers/dense.py:64-75) over
+//                        the packed rows of each sequence, optional L2 normalisation, fp16 [B][d] out
+//   bh_unpack_kernel     packed rows -> padded [B][T][d] last_hidden_state (API compatibility: a stock
+//                        pooler / stock BERGEN Retrieve can consume it); padding positions are zero
+#include "bh_device.h"
+#include "bh_kernels.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // 8-half chunks per lane: rows up to 64*8*4 = 2048 elements
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// x[c][e]: the lane's elements (chunk c = lane + 64 c).  Normalises in place.
+__device__ __forceinline__ void row_layernorm(float (&x)[MAXC][8], int nchunk, int lane, int d, float eps,
+                                              const _Float16* gamma, const _Float16* beta) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[c][e];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = x[c][e] - mean;
+                q += t * t;
+            }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk) {
+            const half8 g = *reinterpret_cast<const half8*>(gamma + (size_t)(lane + 64 * c) * 8);
+            const half8 b = *reinterpret_cast<const half8*>(beta + (size_t)(lane + 64 * c) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] = (x[c][e] - mean) * rstd * (float)g[e] + (float)b[e];
+        }
+}
+
+__device__ __forceinline__ void store_row(_Float16* dst, const float (&x)[MAXC][8], int nchunk, int lane) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)x[c][e];
+            *reinterpret_cast<half8*>(dst + (size_t)(lane + 64 * c) * 8) = o;
+        }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) bh_embed_ln_kernel(BhEmbedArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int nchunk = a.d >> 3;
+    const int tok = a.tok[row], pos = a.pos[row], typ = a.typ[row];
+    const _Float16* w = a.word + (size_t)tok * a.d;
+    const _Float16* p = a.position + (size_t)pos * a.d;
+    const _Float16* t = a.type + (size_t)typ * a.d;
+    float x[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk) {
+            const size_t o = (size_t)(lane + 64 * c) * 8;
+            const half8 a8 = *reinterpret_cast<const half8*>(w + o);
+            const half8 b8 = *reinterpret_cast<const half8*>(p + o);
+            const half8 c8 = *reinterpret_cast<const half8*>(t + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] = (float)a8[e] + (float)c8[e] + (float)b8[e];
+        }
+    row_layernorm(x, nchunk, lane, a.d, a.eps, a.gamma, a.beta);
+    store_row(a.out + (size_t)row * a.d, x, nchunk, lane);
+}
+
+__global__ void __launch_bounds__(256) bh_layernorm_kernel(BhLnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int nchunk = a.d >> 3;
+    const _Float16* src = a.in + (size_t)row * a.d;
+    float x[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (lane + 64 * c < nchunk) {
+            const half8 v = *reinterpret_cast<const half8*>(src + (size_t)(lane + 64 * c) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] = (float)v[e];
+        }
+    row_layernorm(x, nchunk, lane, a.d, a.eps, a.gamma, a.beta);
+    store_row(a.out + (size_t)row * a.d, x, nchunk, lane);
+}
+
+// one wave per sequence
+__global__ void __launch_bounds__(256) bh_pool_kernel(BhPoolArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= a.batch) return;
+    const int nchunk = a.d >> 3;
+    const long long t0 = a.seq_off[s];
+    const int len = a.seq_len[s];
+    float x[MAXC][8];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[c][e] = 0.f;
+    const int rows = a.mode == 0 ? 1 : len;  // 0 = CLS (first token), 1 = mean over the sequence's tokens
+    for (int r = 0; r < rows; ++r) {
+        const _Float16* src = a.x + (size_t)(t0 + r) * a.d;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < nchunk) {
+                const half8 v = *reinterpret_cast<const half8*>(src + (size_t)(lane + 64 * c) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c][e] += (float)v[e];
+            }
+    }
+    if (a.mode == 1) {
+        const float inv = 1.0f / (float)len;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] *= inv;
+    }
+    if (a.l2_normalize) {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < nchunk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q += x[c][e] * x[c][e];
+        const float n = sqrtf(wave_sum(q));
+        const float inv = n > 0.f ? 1.0f / n : 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] *= inv;
+    }
+    store_row(a.out + (size_t)s * a.d, x, nchunk, lane);
+}
+
+// one wave per (sequence, position) of the padded output
+__global__ void __launch_bounds__(256) bh_unpack_kernel(BhUnpackArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long long)a.batch * a.seq_len_padded) return;
+    const int s = (int)(r / a.seq_len_padded), t = (int)(r % a.seq_len_padded);
+    const int nchunk = a.d >> 3;
+    const int src_row = a.slot[r];  // packed row of this (sequence, position), -1 for padding
+    _Float16* dst = a.out + (size_t)r * a.d;
+    (void)s;
+    (void)t;
+    for (int c = lane; c < nchunk; c += 64) {
+        half8 v;
+        if (src_row >= 0)
+            v = *reinterpret_cast<const half8*>(a.x + (size_t)src_row * a.d + (size_t)c * 8);
+        else
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+        *reinterpret_cast<half8*>(dst + (size_t)c * 8) = v;
+    }
+}
+
+hipError_t bh_launch_embed_ln(const BhEmbedArgs& a, hipStream_t st) {
+    if (a.n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_embed_ln_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t st) {
+    if (a.n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_layernorm_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t bh_launch_pool(const BhPoolArgs& a, hipStream_t st) {
+    if (a.batch <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_pool_kernel, dim3((unsigned)((a.batch + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t bh_launch_unpack(const BhUnpackArgs& a, hipStream_t st) {
+    const long long n = (long long)a.batch * a.seq_len_padded;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

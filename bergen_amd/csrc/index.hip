@@ -19,13 +19,19 @@
 #include <vector>
 
 #include "../../include/bergen_hip.h"
+#include "bh_host.h"
 #include "bh_kernels.h"
 
 namespace {
-
 thread_local std::string g_err;
+#define fail(...) bh_fail(__VA_ARGS__)
 
-int fail(int code, const char* fmt, ...) {
+#define HIP_TRY(expr) BH_HIP_TRY(expr)
+
+}  // namespace
+
+// shared by every translation unit of the library (bh_kernels.h)
+int bh_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -35,13 +41,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
-            return fail(_e == hipErrorOutOfMemory ? BH_ENOMEM : BH_EHIP, "%s failed: %s (%s:%d)", #expr, \
-                        hipGetErrorString(_e), __FILE__, __LINE__);                            \
-    } while (0)
+namespace {
 
 struct Options {
     int query_tile = 128;
@@ -67,24 +67,7 @@ int pick_kp(int k) {
 }
 
 template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;  // elements
-    int ensure(size_t n) {
-        if (n <= cap) return BH_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        HIP_TRY(hipMalloc((void**)&p, n * sizeof(T)));
-        cap = n;
-        return BH_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
+using DevBuf = BhDevBuf<T>;
 
 }  // namespace
 

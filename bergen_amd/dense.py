@@ -14,9 +14,27 @@ range-partitions the dataset, one process per GPU, weights loaded once per proce
 `similarity_fn` exists for API compatibility (it materialises the [Bq, n] matrix the fused
 search kernel avoids); `bergen_amd.retrieve.Retrieve` never calls it.
 """
+import os
 from abc import ABC, abstractmethod
 
 import torch
+
+
+def _native_encoder(model):
+    """Move an HF BertModel-architecture encoder onto the hand-written gfx950 forward pass.
+
+    On a GPU box every BERT-architecture checkpoint (all dense retrievers of the reference's
+    config/retriever/*.yaml except repllama) runs on bergen_amd.BertEncoder; BERGEN_AMD_ENCODER=hf keeps the
+    HF torch module (debugging / A-B comparison).  Other architectures stay on their HF implementation.
+    """
+    from .encoder import BertEncoder
+    if isinstance(model, BertEncoder) or not torch.cuda.is_available():
+        return model
+    if os.environ.get("BERGEN_AMD_ENCODER", "hip") == "hf":
+        return model
+    if BertEncoder.supports(model):
+        return BertEncoder.from_hf(model, device=torch.cuda.current_device())
+    return model
 
 
 class Retriever(ABC):
@@ -92,12 +110,12 @@ class Dense(Retriever):
             from transformers import AutoModel, AutoTokenizer
         if model is None:
             model = AutoModel.from_pretrained(self.model_name, torch_dtype=torch.float16, trust_remote_code=True)
-        self.model = model
+        self.model = _native_encoder(model)
         if query_encoder is not None:
-            self.query_encoder = query_encoder
+            self.query_encoder = _native_encoder(query_encoder)
         elif query_encoder_name:
-            self.query_encoder = AutoModel.from_pretrained(query_encoder_name, torch_dtype=torch.float16,
-                                                           trust_remote_code=True)
+            self.query_encoder = _native_encoder(AutoModel.from_pretrained(query_encoder_name, torch_dtype=torch.float16,
+                                                                           trust_remote_code=True))
         else:
             self.query_encoder = self.model  # otherwise symmetric (dense.py:19-20)
         self.tokenizer = tokenizer if tokenizer is not None else AutoTokenizer.from_pretrained(self.model_name)
@@ -116,14 +134,17 @@ class Dense(Retriever):
 
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
-        kwargs = {key: value.to(self.device) for key, value in kwargs.items()}
         encoder = self.model if query_or_doc == "doc" else self.query_encoder
-        # fused path: an encoder that pools on the device returns the [B, d] embedding directly
+        # fused path: the native encoder takes the HOST BatchEncoding straight through the C ABI, pools on the
+        # device and returns the [B, d] embedding (reference dense.py:38-46 in one call)
         if hasattr(encoder, "encode_pooled"):
-            emb = encoder.encode_pooled(kwargs, self.pooler)
-        else:
-            outputs = encoder(**kwargs)
-            emb = self.pooler.pool(outputs[0], kwargs['attention_mask'])
+            try:
+                return {"embedding": encoder.encode_pooled(kwargs, self.pooler)}
+            except ValueError:
+                pass  # a pooler the kernels do not know: pool the hidden states in torch below
+        kwargs = {key: value.to(self.device) for key, value in kwargs.items()}
+        outputs = encoder(**kwargs)
+        emb = self.pooler.pool(outputs[0], kwargs['attention_mask'])
         return {"embedding": emb}
 
     def collate_fn(self, batch, query_or_doc=None):

@@ -1,0 +1,207 @@
+"""
+BertEncoder — the bi-encoder forward pass on hand-written gfx950 kernels (C ABI: bh_encoder_*).
+
+Drop-in for the HF ``AutoModel`` object the reference stores in ``Dense.model`` / ``Dense.query_encoder``
+(models/retrievers/dense.py:16-20) and calls as ``self.model(**kwargs)[0]`` (dense.py:40-44):
+
+  * ``encoder(input_ids=..., attention_mask=..., token_type_ids=...)`` returns a 1-tuple whose first element
+    is the last hidden state ``[B, T, d]`` fp16 on the device (zeros at padding positions);
+  * ``encoder.encode_pooled(kwargs, pooler)`` fuses the reference's pooler (ClsPooler / MeanPooler,
+    dense.py:64-75) into the forward pass and returns the ``[B, d]`` fp16 embedding directly;
+  * ``.to(device)``, ``.eval()``, ``.half()`` exist because ``Retrieve`` moves ``model.model`` around
+    (modules/retrieve.py:78,124,142); the weights live in HBM inside the library and never move.
+
+Weights come from any HF ``BertModel``-architecture module or state_dict (RetroMAE, contriever, e5, bge ...).
+There is no CPU path: constructing an encoder without a gfx950 device raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_POOL = {"cls": 0, "mean": 1, "none": 2}
+
+
+def _pool_mode(pooler):
+    """Map a reference-style pooler (class or instance, ours or the reference's) to the fused pooling mode."""
+    if isinstance(pooler, str):
+        return _POOL[pooler]
+    name = pooler.__name__ if isinstance(pooler, type) else type(pooler).__name__
+    if name == "ClsPooler":
+        return 0
+    if name == "MeanPooler":
+        return 1
+    raise ValueError(f"no fused pooling for {pooler!r}; use encoder(**kwargs)[0] and pool in torch")
+
+
+class BertEncoder:
+    def __init__(self, config, state_dict, device=0):
+        """config: HF BertConfig (or any object / dict with the same field names)."""
+        get = (lambda k, dflt=None: config.get(k, dflt)) if isinstance(config, dict) else \
+            (lambda k, dflt=None: getattr(config, k, dflt))
+        act = get("hidden_act", "gelu")
+        if act != "gelu":
+            raise ValueError(f"hidden_act={act!r} unsupported (erf-GELU only)")
+        pet = get("position_embedding_type", "absolute")
+        if pet not in (None, "absolute"):
+            raise ValueError(f"position_embedding_type={pet!r} unsupported")
+        self._h = None
+        _lib.init(device)
+        self.device_index = device
+        self.config = config
+        self.hidden_size = int(get("hidden_size"))
+        cfg = _lib.bh_encoder_config(
+            n_layers=int(get("num_hidden_layers")), hidden=self.hidden_size, n_heads=int(get("num_attention_heads")),
+            intermediate=int(get("intermediate_size")), vocab_size=int(get("vocab_size")),
+            max_position=int(get("max_position_embeddings")), type_vocab_size=int(get("type_vocab_size")),
+            activation=0, ln_eps=float(get("layer_norm_eps", 1e-12)))
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))
+        self._h = h
+        n_set = 0
+        for name, t in state_dict.items():
+            key = name
+            for pre in ("bert.", "model."):
+                if key.startswith(pre):
+                    key = key[len(pre):]
+            if key.startswith("pooler.") or key.endswith("position_ids") or key.endswith("token_type_ids"):
+                continue  # the reference uses outputs[0] only (dense.py:40-44): BertPooler is dead weight
+            if not (key.startswith("embeddings.") or key.startswith("encoder.layer.")):
+                continue
+            a = t.detach().to("cpu")
+            if a.dtype not in (torch.float16, torch.float32):
+                a = a.float()
+            a = a.contiguous()
+            code = _lib.BH_F16 if a.dtype == torch.float16 else _lib.BH_F32
+            _lib.check(_lib.lib().bh_encoder_set_tensor(self._h, key.encode(), ctypes.c_void_p(a.data_ptr()), code,
+                                                        a.numel()))
+            n_set += 1
+        _lib.check(_lib.lib().bh_encoder_commit(self._h))
+        self.n_tensors = n_set
+
+    @classmethod
+    def from_hf(cls, model, device=0):
+        """Build from an instantiated HF BertModel (weights are copied into HBM once)."""
+        return cls(model.config, model.state_dict(), device=device)
+
+    @staticmethod
+    def supports(model):
+        cfg = getattr(model, "config", None)
+        return (cfg is not None and getattr(cfg, "model_type", None) == "bert"
+                and getattr(cfg, "hidden_act", "gelu") == "gelu"
+                and getattr(cfg, "position_embedding_type", "absolute") in (None, "absolute")
+                and cfg.hidden_size == cfg.num_attention_heads * 64 and cfg.hidden_size <= 2048)
+
+    # -- nn.Module-like surface used by Retrieve / Dense -------------------------------------------
+    def to(self, *args, **kwargs):
+        return self
+
+    def eval(self):
+        return self
+
+    def half(self):
+        return self
+
+    def set_option(self, name, value):
+        _lib.check(_lib.lib().bh_encoder_set_option(self._h, name.encode(), int(value)))
+
+    # -- forward -----------------------------------------------------------------------------------
+    def _forward(self, input_ids, attention_mask, token_type_ids, pool, l2_normalize=False):
+        ids = torch.as_tensor(input_ids).to("cpu", torch.int64).contiguous()
+        if ids.ndim != 2:
+            raise ValueError(f"input_ids must be [B, T], got {tuple(ids.shape)}")
+        B, T = ids.shape
+        keep = [ids]
+
+        def host(x):
+            if x is None:
+                return None
+            x = torch.as_tensor(x).to("cpu", torch.int64).contiguous()
+            if tuple(x.shape) != (B, T):
+                raise ValueError(f"expected [{B}, {T}], got {tuple(x.shape)}")
+            keep.append(x)
+            return ctypes.c_void_p(x.data_ptr())
+
+        mask_p, type_p = host(attention_mask), host(token_type_ids)
+        dev = torch.device("cuda", self.device_index)
+        shape = (B, T, self.hidden_size) if pool == 2 else (B, self.hidden_size)
+        out = torch.empty(shape, dtype=torch.float16, device=dev)
+        torch.cuda.current_stream(dev).synchronize()  # the library runs on its own stream
+        _lib.init(self.device_index)
+        _lib.check(_lib.lib().bh_encoder_forward(self._h, ctypes.c_void_p(ids.data_ptr()), mask_p, type_p, B, T, pool,
+                                                 int(bool(l2_normalize)), ctypes.c_void_p(out.data_ptr()), 1))
+        del keep
+        return out
+
+    def __call__(self, input_ids=None, attention_mask=None, token_type_ids=None, **unused):
+        """HF-style call: returns (last_hidden_state [B, T, d] fp16,)."""
+        return (self._forward(input_ids, attention_mask, token_type_ids, 2),)
+
+    def encode_pooled(self, kwargs, pooler, l2_normalize=False):
+        """Fused forward + pooling: [B, d] fp16 on the device (reference dense.py:40-46 in one call)."""
+        return self._forward(kwargs["input_ids"], kwargs.get("attention_mask"), kwargs.get("token_type_ids"),
+                             _pool_mode(pooler), l2_normalize)
+
+    def counters(self):
+        c = _lib.bh_encoder_counters()
+        _lib.check(_lib.lib().bh_encoder_counters_get(self._h, ctypes.byref(c)))
+        return {name: getattr(c, name) for name, _ in c._fields_}
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().bh_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- op-level wrappers (device tensors) used by the parity tests and micro-benchmarks --------------------
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def gemm_f16(a, w, bias=None, bias_mode=1, residual=None, gelu=False, variant=0, out=None, repeats=1):
+    """out[M, N] = a[M, K] @ w[N, K]^T (+bias) (+residual) (GELU) on the HIP kernel.  Returns (out, avg_ms)."""
+    assert a.is_cuda and w.is_cuda and a.dtype == torch.float16 and w.dtype == torch.float16
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=a.device)
+    ms = ctypes.c_float(0)
+    torch.cuda.synchronize(a.device)
+    _lib.check(_lib.lib().bh_op_gemm_f16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias),
+                                         bias_mode if bias is not None else 0, _p(residual),
+                                         residual.stride(0) if residual is not None else 0, M, N, K, int(gelu),
+                                         variant, repeats, ctypes.byref(ms)))
+    return out, float(ms.value)
+
+
+def attention(qk, vt, seq_off, seq_len, n_heads, max_len):
+    """Packed varlen attention: qk [tokens, 2d], vt [d, ld] -> ctx [tokens, d] (rows outside sequences zero)."""
+    assert qk.is_cuda and vt.is_cuda
+    d = n_heads * 64
+    ctx = torch.zeros((qk.shape[0], d), dtype=torch.float16, device=qk.device)
+    so = torch.as_tensor(seq_off, dtype=torch.int64, device=qk.device)
+    sl = torch.as_tensor(seq_len, dtype=torch.int32, device=qk.device)
+    torch.cuda.synchronize(qk.device)
+    _lib.check(_lib.lib().bh_op_attention(_p(qk), qk.stride(0), _p(vt), vt.stride(0), _p(ctx), ctx.stride(0), _p(so),
+                                          _p(sl), int(so.numel()), n_heads, int(max_len)))
+    return ctx
+
+
+def layernorm(x, gamma, beta, eps):
+    out = torch.empty_like(x)
+    torch.cuda.synchronize(x.device)
+    _lib.check(_lib.lib().bh_op_layernorm(_p(x), _p(out), x.shape[0], x.shape[1], float(eps), _p(gamma), _p(beta)))
+    return out
+
+
+def permlane_mode():
+    return int(_lib.lib().bh_gemm_permlane_mode())

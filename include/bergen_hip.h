@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_VERSION 100 /* 0.1.0 */
+#define BH_VERSION 110 /* 0.1.1: + bi-encoder forward pass */
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -123,6 +123,78 @@ int bh_bench_counters(const bh_index* ix, bh_counters* out);
 /* Tuning knobs (process-wide; for bench sweeps).  name in {"query_tile" (128|256),
  * "share_threshold" (0|1), "nontemporal" (0|1), "workgroups_per_cu" (1)}. */
 int bh_set_option(const char* name, int64_t value);
+
+/* Bi-encoder forward pass (BERT-architecture dense retrievers) ------------------------------ */
+
+/* Architecture of HF `BertModel` as the reference loads it through AutoModel
+ * (models/retrievers/dense.py:16): post-LN transformer encoder, absolute position embeddings,
+ * head dim 64.  RetroMAE / contriever / e5 / bge checkpoints are all of this class. */
+typedef struct bh_encoder_config {
+    int32_t n_layers;        /* num_hidden_layers */
+    int32_t hidden;          /* hidden_size (multiple of 64, = n_heads * 64) */
+    int32_t n_heads;         /* num_attention_heads */
+    int32_t intermediate;    /* intermediate_size */
+    int32_t vocab_size;
+    int32_t max_position;    /* max_position_embeddings */
+    int32_t type_vocab_size;
+    int32_t activation;      /* 0 = erf-GELU ("gelu") */
+    float ln_eps;            /* layer_norm_eps */
+} bh_encoder_config;
+
+typedef struct bh_encoder bh_encoder;
+
+/* Counters of the most recent bh_encoder_forward (encoder roofline = MFMA). */
+typedef struct bh_encoder_counters {
+    int32_t batch;        /* sequences */
+    int32_t seq_len;      /* padded length of the input matrix */
+    int64_t real_tokens;  /* tokens with attention_mask != 0 */
+    int64_t packed_rows;  /* rows the kernels ran over (real tokens + alignment padding) */
+    double forward_ms;    /* embedding -> pooled output, HIP events on the encoder's stream */
+    double flops;         /* ALGORITHMIC flops over real tokens:
+                             n_layers * (T*(8 d^2 + 4 d d_ff) + 4 d sum(len_s^2)) */
+} bh_encoder_counters;
+
+/* Allocate an encoder (weights + workspace live in HBM, owned by the library).  Replaces
+ * `AutoModel.from_pretrained(model_name, torch_dtype=float16)`, reference dense.py:16-20. */
+int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg);
+/* Copy one weight tensor from HOST memory, addressed by its HF `BertModel.state_dict()` name
+ * (e.g. "encoder.layer.3.attention.self.query.weight"); fp32 sources are rounded to fp16 like
+ * `.half()`.  Shapes are HF's ([out, in] for Linear weights). */
+int bh_encoder_set_tensor(bh_encoder* enc, const char* name, const void* host, int32_t dtype, int64_t numel);
+/* Check that every tensor of the architecture has been set (BH_EINCOMPLETE otherwise). */
+int bh_encoder_commit(bh_encoder* enc);
+/* name in {"gemm_variant" (0 = auto, 1..7 explicit tile configurations; bench sweeps)}. */
+int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
+
+/* One forward pass over a HOST batch in the layout of an HF BatchEncoding (row-major
+ * [batch, seq_len] int64; attention_mask / token_type_ids may be NULL = all ones / all zeros).
+ * pool: 0 = ClsPooler (reference dense.py:71-75), 1 = MeanPooler (dense.py:64-69) -> out is
+ * [batch, hidden] fp16; 2 = no pooling -> out is the padded last_hidden_state
+ * [batch, seq_len, hidden] fp16 (zeros at padding).  l2_normalize applies to pooled outputs.
+ * out is a device pointer when out_on_device != 0 (e.g. the rows of a bh_index, or a torch
+ * tensor), else a host pointer.  Replaces Dense.__call__, reference dense.py:37-47. */
+int bh_encoder_forward(bh_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask,
+                       const int64_t* token_type_ids, int32_t batch, int32_t seq_len, int32_t pool,
+                       int32_t l2_normalize, void* out, int32_t out_on_device);
+int bh_encoder_counters_get(const bh_encoder* enc, bh_encoder_counters* out);
+void bh_encoder_destroy(bh_encoder* enc);
+
+/* Op-level entry points over DEVICE pointers (parity tests, kernel micro-benchmarks).
+ * bh_op_gemm_f16: C[M][N] = A[M][K] . B[N][K]^T (+bias: mode 1 per column [N], 2 per row [M])
+ * (+residual[M][N]) (erf-GELU), fp16 in/out, fp32 accumulate; K % 64 == 0, ld* % 8 == 0.
+ * repeats > 1 times the launches after the first (avg_ms, HIP events on the null stream). */
+int bh_op_gemm_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                   const void* bias, int32_t bias_mode, const void* residual, int64_t ldr, int32_t M,
+                   int32_t N, int32_t K, int32_t gelu, int32_t variant, int32_t repeats, float* avg_ms);
+/* Packed variable-length self-attention, head dim 64: qk [tokens][2*64*n_heads] (queries | keys),
+ * vt [64*n_heads][ldvt] (values, transposed), ctx [tokens][64*n_heads]. */
+int bh_op_attention(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* ctx, int64_t ldc,
+                    const int64_t* seq_off_dev, const int32_t* seq_len_dev, int32_t batch,
+                    int32_t n_heads, int32_t max_len);
+int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float eps, const void* gamma,
+                    const void* beta);
+/* 0 / 1 = direction of v_permlane32_swap found on the device (diagnostic), -1 on failure. */
+int bh_gemm_permlane_mode(void);
 
 #ifdef __cplusplus
 }
