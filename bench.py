@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no 2:1 sparsity), same guide
 
 
 def parse_args():
@@ -51,6 +52,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
     p.add_argument("--cpu-sample-queries", type=int, default=1000)
+    p.add_argument("--no-encoder", action="store_true", help="skip the passages-encoded/s leg")
+    p.add_argument("--enc-batch", type=int, default=512, help="sequences per encoder step (retromae.yaml batch_size)")
+    p.add_argument("--enc-steps", type=int, default=3)
     p.add_argument("--sweep", action="store_true", help="also time kernel variants (written to gpurun_out/sweep.json)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                    help="optional PMC-derived HBM bytes per scan launch (written by profiles/collect_pmc.py)")
@@ -125,6 +129,51 @@ def cpu_baseline(args, dim, k):
                    f"chunks 150016/149504 rows) on Q={nq} x N={n} x d={dim}, best of 3 = {best:.3f} s, "
                    f"scaled x{scale:.1f} linearly in N to N={args.n_rows}; CPU: {model}; torch {torch.__version__}"),
         "measured_seconds": best,
+    }
+
+
+def encoder_leg(args, device_index):
+    """passages-encoded/s: the bi-encoder forward pass (BASELINE configs[1] encoder = RetroMAE = BERT-base
+    architecture, CLS pooling) on a batch of synthetic passages (lengths ~ clipped-Normal(130, 30)
+    in [16, 256], random token ids, seeded random-init weights — no checkpoint exists offline).  A step = one
+    forward pass of --enc-batch passages, token ids on the host (as a tokenizer leaves them), embeddings left
+    in HBM (where the index consumes them).  Roofline = MFMA: algorithmic flops over REAL tokens
+    (12 x (T x 14.16 MFLOP + 4 d sum len^2)) / forward time / 2.5 PFLOP/s."""
+    from bergen_amd import BertEncoder, synth
+    cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = synth.random_bert(cfg, seed=31)
+    enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=device_index)
+    rng = np.random.default_rng(6)
+    lens = np.clip(np.rint(rng.normal(130, 30, size=args.enc_batch)), 16, 256).astype(np.int64)
+    T = int(lens.max())
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    ids = rng.integers(1, cfg["vocab_size"], size=(args.enc_batch, T)).astype(np.int64) * mask
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    enc.encode_pooled(kw, "cls")  # warm-up (workspace allocation, kernel attribute setup)
+    torch.cuda.synchronize()
+    fwd_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.enc_steps):
+        emb = enc.encode_pooled(kw, "cls")
+        fwd_ms += enc.counters()["forward_ms"]
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    c = enc.counters()
+    ok = bool(torch.isfinite(emb.float()).all()) and tuple(emb.shape) == (args.enc_batch, 768)
+    enc.close()
+    achieved = c["flops"] / (fwd_ms / args.enc_steps * 1e-3) / 1e12
+    return {
+        "passages_per_s": args.enc_batch * args.enc_steps / wall,
+        "encoder": {"workload": f"BERT-base (12x768x12 heads, d_ff 3072) forward + CLS pool, {args.enc_batch} synthetic "
+                                f"passages/step, {int(c['real_tokens'])} real tokens (reference pads to {ids.size}), fp16 "
+                                f"storage / fp32 accumulate, random-init weights",
+                    "steps": args.enc_steps, "ms_per_step_wall": wall / args.enc_steps * 1e3,
+                    "ms_per_step_kernels": fwd_ms / args.enc_steps, "packed_rows": int(c["packed_rows"]),
+                    "finite_and_shaped": ok},
+        "encoder_roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                             "algorithmic_flops_per_step": c["flops"]},
     }
 
 
@@ -229,7 +278,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "queries/sec, exact IP top-50, KILT-100w-sized corpus (21M x 768 fp16), kilt_nq-dev-sized query set",
+            "metric": "queries/sec (value) + passages-encoded/sec (passages_per_s), KILT-100w-sized corpus (21M x 768 fp16) "
+                      "top-50, kilt_nq-dev-sized query set; % of HBM / MFMA roofline",
             "value": nq / (elapsed / args.steps),
             "unit": "queries/s",
             "n_gpus": world,
@@ -258,10 +308,13 @@ def main():
             "index_build_seconds": build_s,
             "parity_check": parity,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, dim, k)
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
+        if not args.no_encoder and world == 1:
+            ix.close()  # the search index is no longer needed: give the HBM back before the encoder leg
+            out.update(encoder_leg(args, local_rank))
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, dim, k)
         print(json.dumps(out), flush=True)
     ix.close()
     if world > 1:

@@ -1,0 +1,297 @@
+"""GPU parity tests of the bi-encoder forward pass: every HIP kernel through the C ABI against the fp64 oracle
+(oracle/bert_oracle.py) and the HF-BertModel golden fixture (tests/golden/bert_tiny.npz).
+
+Floating point: fp16 storage, fp32 accumulation.  Tolerances (written here, DESIGN.md "Numerics contract"):
+  GEMM       |got - ref| <= 1.5e-3 * |ref| + 1.5e-3 * rms(ref)   (one fp16 rounding of an fp32-accumulated sum)
+  attention  |got - ref| <= 4e-3 * max|ref|                      (probabilities rounded to fp16 before P.V)
+  encoder    cosine(embedding, oracle) >= 0.999 and max-abs <= 3e-2 * max|ref|
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert_oracle
+
+from conftest import GOLDEN
+from test_encoder_oracle import load_tiny
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def h16(x):
+    return torch.from_numpy(np.asarray(x, np.float16)).to(DEV)
+
+
+def rnd16(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float16)
+
+
+def assert_gemm_close(got, ref, what):
+    got = got.float().cpu().numpy().astype(np.float64)
+    rms = float(np.sqrt((ref ** 2).mean()))
+    err = np.abs(got - ref)
+    bound = 1.5e-3 * np.abs(ref) + 1.5e-3 * rms
+    bad = err > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())} / {bad.size} elements off; worst err {err.max():.4g} at "
+                           f"{np.unravel_index(err.argmax(), err.shape)}, rms {rms:.3g}")
+
+
+def test_permlane_probe():
+    from bergen_amd import encoder
+    assert encoder.permlane_mode() in (0, 1)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+def test_gemm_variants_plain(variant):
+    """Asymmetric operands, sizes that are not tile multiples (ragged M and N edges)."""
+    from bergen_amd import encoder
+    rng = np.random.default_rng(100 + variant)
+    M, N, K = 300, 328, 192
+    a, w = rnd16(rng, M, K), rnd16(rng, N, K)
+    out, _ = encoder.gemm_f16(h16(a), h16(w), variant=variant)
+    assert_gemm_close(out, bert_oracle.gemm_ref(a, w), f"variant {variant} plain")
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4, 5, 6])
+def test_gemm_epilogues(variant):
+    from bergen_amd import encoder
+    rng = np.random.default_rng(200 + variant)
+    M, N, K = 515, 384, 256
+    a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.5)
+    bias_c, bias_r = rnd16(rng, N), rnd16(rng, M)
+    res = rnd16(rng, M, N)
+    out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(bias_c), bias_mode=1, variant=variant)
+    assert_gemm_close(out, bert_oracle.gemm_ref(a, w, bias_c, 1), "bias per column")
+    out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(bias_r), bias_mode=2, variant=variant)
+    assert_gemm_close(out, bert_oracle.gemm_ref(a, w, bias_r, 2), "bias per row")
+    out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(bias_c), residual=h16(res), variant=variant)
+    assert_gemm_close(out, bert_oracle.gemm_ref(a, w, bias_c, 1, res), "bias + residual")
+    out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(bias_c), gelu=True, variant=variant)
+    assert_gemm_close(out, bert_oracle.gemm_ref(a, w, bias_c, 1, gelu=True), "bias + gelu")
+
+
+def test_gemm_identity_and_odd_n():
+    """A = I picks out rows of B^T (catches transposed / permuted output maps); N not a multiple of 4."""
+    from bergen_amd import encoder
+    rng = np.random.default_rng(5)
+    K = 128
+    a = np.eye(K, dtype=np.float16)
+    w = rnd16(rng, 77, K)
+    out, _ = encoder.gemm_f16(h16(a), h16(w), out=torch.zeros((K, 80), dtype=torch.float16, device=DEV)[:, :77])
+    # strided output view: ldc = 80 (multiple of 8), N = 77
+    assert np.array_equal(out.cpu().numpy(), w.T)
+
+
+def test_gemm_bert_shapes_auto_variant():
+    from bergen_amd import encoder
+    rng = np.random.default_rng(6)
+    M = 1000
+    for (N, K, gelu) in [(1536, 768, False), (3072, 768, True), (768, 3072, False)]:
+        a, w, b = rnd16(rng, M, K, scale=0.3), rnd16(rng, N, K, scale=0.05), rnd16(rng, N)
+        out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(b), gelu=gelu)
+        assert_gemm_close(out, bert_oracle.gemm_ref(a, w, b, 1, gelu=gelu), f"N={N} K={K}")
+    # V^T orientation: weights as the row operand, bias per row
+    x, wv, bv = rnd16(rng, 520, 768, scale=0.3), rnd16(rng, 768, 768, scale=0.05), rnd16(rng, 768)
+    out, _ = encoder.gemm_f16(h16(wv), h16(x), bias=h16(bv), bias_mode=2)
+    assert_gemm_close(out, bert_oracle.gemm_ref(wv, x, bv, 2), "V^T projection")
+
+
+def _pack(lens):
+    off, cur = [], 0
+    for n in lens:
+        off.append(cur)
+        cur = (cur + n + 7) // 8 * 8
+    return off, (cur + 32 + 255) // 256 * 256
+
+
+@pytest.mark.parametrize("lens", [[1], [5, 31, 32, 33], [64, 100, 7, 256], [512, 3, 129]])
+def test_attention_against_oracle(lens):
+    from bergen_amd import encoder
+    rng = np.random.default_rng(sum(lens))
+    nh = 2
+    d = nh * 64
+    off, rows = _pack(lens)
+    qk = rnd16(rng, rows, 2 * d)
+    vt = rnd16(rng, d, rows)
+    # make the softmax peaky for some queries: large q.k on a few keys
+    qk[off[0], :64] *= 6
+    ctx = encoder.attention(h16(qk), h16(vt), off, lens, nh, max(lens)).float().cpu().numpy()
+    ref = bert_oracle.attention_ref(qk, vt, off, lens, nh)
+    assert np.isfinite(ctx).all()
+    assert np.abs(ctx - ref).max() <= 4e-3 * np.abs(ref).max(), np.abs(ctx - ref).max()
+    # rows that belong to no sequence are never written
+    keep = np.zeros(rows, bool)
+    for o, n in zip(off, lens):
+        keep[o:o + n] = True
+    assert np.all(ctx[~keep] == 0)
+
+
+def test_layernorm_against_oracle():
+    from bergen_amd import encoder
+    rng = np.random.default_rng(9)
+    for d in (128, 768, 1024):
+        x = rnd16(rng, 37, d, scale=3.0)
+        g, b = rnd16(rng, d) + np.float16(1), rnd16(rng, d)
+        got = encoder.layernorm(h16(x), h16(g), h16(b), 1e-12).float().cpu().numpy()
+        ref = bert_oracle.layernorm_ref(x, g, b, 1e-12)
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-3
+
+
+def _native(cfg, sd):
+    from bergen_amd import BertEncoder
+    return BertEncoder(cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=0)
+
+
+def _check_embeddings(got, ref, what):
+    got = got.float().cpu().numpy().astype(np.float64)
+    cos = (got * ref).sum(-1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(ref, axis=-1))
+    assert cos.min() >= 0.999, f"{what}: min cosine {cos.min():.6f}"
+    assert np.abs(got - ref).max() <= 3e-2 * np.abs(ref).max(), f"{what}: max abs err {np.abs(got - ref).max():.4g}"
+    return float(cos.min()), float(np.abs(got - ref).max())
+
+
+def test_encoder_matches_hf_golden_fixture():
+    """tests/golden/bert_tiny.npz: outputs of HF BertModel + the reference's own poolers (CPU, fp32)."""
+    cfg, sd, z = load_tiny()
+    enc = _native(cfg, sd)
+    ids, mask, types = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "token_type_ids"))
+    hidden = enc(input_ids=ids, attention_mask=mask, token_type_ids=types)[0]
+    m = z["attention_mask"] != 0
+    got = hidden.float().cpu().numpy()
+    assert got.shape == z["hf_hidden"].shape
+    assert np.all(got[~m] == 0)
+    _check_embeddings(hidden[torch.from_numpy(m).to(DEV)], z["hf_hidden"][m].astype(np.float64), "hidden states")
+    kw = {"input_ids": ids, "attention_mask": mask, "token_type_ids": types}
+    _check_embeddings(enc.encode_pooled(kw, "cls"), z["ref_cls"].astype(np.float64), "cls pooling")
+    _check_embeddings(enc.encode_pooled(kw, "mean"), z["ref_mean"].astype(np.float64), "mean pooling")
+    c = enc.counters()
+    assert c["real_tokens"] == int(m.sum()) and c["batch"] == ids.shape[0] and c["forward_ms"] > 0
+    enc.close()
+
+
+def test_encoder_bert_base_shape_against_oracle():
+    """12 x 768 x 12 heads x 3072 (RetroMAE / contriever shape), seeded random weights, ragged batch."""
+    cfg = dict(vocab_size=2000, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=256, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=21)
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=6, max_len=70, seed=22)
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask),
+          "token_type_ids": torch.from_numpy(types)}
+    ref_h = bert_oracle.bert_forward(sd, cfg, ids, mask, types)
+    cos_c, err_c = _check_embeddings(enc.encode_pooled(kw, "cls"), bert_oracle.cls_pool(ref_h), "cls")
+    cos_m, err_m = _check_embeddings(enc.encode_pooled(kw, "mean"), bert_oracle.mean_pool(ref_h, mask), "mean")
+    got_n = enc.encode_pooled(kw, "mean", l2_normalize=True).float().cpu().numpy()
+    assert np.allclose(np.linalg.norm(got_n, axis=1), 1.0, atol=2e-3)
+    print(f"bert-base shape: cls cos {cos_c:.6f} err {err_c:.4g}; mean cos {cos_m:.6f} err {err_m:.4g}")
+    enc.close()
+
+
+def test_encoder_is_batch_composition_invariant():
+    """Packing must not leak between sequences: a sequence encoded alone == inside a ragged batch, bit for bit
+    (same kernels, same per-row arithmetic order)."""
+    cfg, sd, z = load_tiny()
+    enc = _native(cfg, sd)
+    ids, mask, types = z["input_ids"], z["attention_mask"], z["token_type_ids"]
+    kw = lambda s: {"input_ids": torch.from_numpy(ids[s]), "attention_mask": torch.from_numpy(mask[s]),
+                    "token_type_ids": torch.from_numpy(types[s])}
+    full = enc.encode_pooled(kw(slice(None)), "mean").cpu().numpy()
+    for b in (0, 3, ids.shape[0] - 1):
+        alone = enc.encode_pooled(kw(slice(b, b + 1)), "mean").cpu().numpy()
+        assert np.array_equal(alone[0].view(np.uint16), full[b].view(np.uint16)), b
+    # reversed batch order
+    rev = enc.encode_pooled({k: torch.flip(v, [0]) for k, v in kw(slice(None)).items()}, "mean").cpu().numpy()
+    assert np.array_equal(rev[::-1].view(np.uint16), full.view(np.uint16))
+    enc.close()
+
+
+def test_encoder_edge_cases_and_errors():
+    cfg, sd, z = load_tiny()
+    enc = _native(cfg, sd)
+    one = torch.tensor([[5]])
+    e1 = enc.encode_pooled({"input_ids": one}, "cls")  # mask None = all ones, single token
+    ref = bert_oracle.encode(sd, cfg, one.numpy(), np.ones((1, 1), np.int64), pooler="cls")
+    _check_embeddings(e1, ref, "single token")
+    T = cfg["max_position_embeddings"]
+    long_ids = torch.randint(1, cfg["vocab_size"], (2, T), generator=torch.Generator().manual_seed(1))
+    ref = bert_oracle.encode(sd, cfg, long_ids.numpy(), np.ones((2, T), np.int64), pooler="mean")
+    _check_embeddings(enc.encode_pooled({"input_ids": long_ids}, "mean"), ref, "max_position length")
+    with pytest.raises(ValueError):  # all-zero mask
+        enc.encode_pooled({"input_ids": one, "attention_mask": torch.zeros(1, 1, dtype=torch.long)}, "cls")
+    with pytest.raises(ValueError):  # token id out of range
+        enc.encode_pooled({"input_ids": torch.tensor([[cfg["vocab_size"]]])}, "cls")
+    with pytest.raises(ValueError):  # longer than the position table
+        enc.encode_pooled({"input_ids": torch.ones(1, T + 1, dtype=torch.long)}, "cls")
+    with pytest.raises(ValueError):  # CLS pooling with the first token masked
+        enc.encode_pooled({"input_ids": torch.ones(1, 3, dtype=torch.long),
+                           "attention_mask": torch.tensor([[0, 1, 1]])}, "cls")
+    enc.close()
+
+
+def test_dense_plugin_runs_on_the_native_encoder(tmp_path):
+    """Dense + Retrieve end to end on the HIP encoder and the HIP search: encode_and_save -> resident index ->
+    fused search; the ranking must agree with an exact search over the oracle's embeddings."""
+    import bergen_amd
+    cfg, sd, _ = load_tiny()
+
+    class ToyTokenizer:
+        """whitespace 'tokenizer' with HF call semantics (padding='longest', truncation)."""
+
+        def __call__(self, texts, padding=None, truncation=None, max_length=None, return_tensors=None):
+            rows = [[1] + [2 + (hash_(w) % (cfg["vocab_size"] - 2)) for w in t.split()][:max_length - 1] for t in texts]
+            T = max(len(r) for r in rows)
+            ids = torch.tensor([r + [0] * (T - len(r)) for r in rows])
+            mask = torch.tensor([[1] * len(r) + [0] * (T - len(r)) for r in rows])
+            return {"input_ids": ids, "attention_mask": mask, "token_type_ids": torch.zeros_like(ids)}
+
+    def hash_(w):
+        v = 0
+        for ch in w:
+            v = (v * 131 + ord(ch)) % 1000003
+        return v
+
+    rng = np.random.default_rng(3)
+    words = [f"w{i}" for i in range(300)]
+    docs = [" ".join(rng.choice(words, size=int(rng.integers(3, 40)))) for _ in range(200)]
+    queries = [" ".join(d.split()[:6]) for d in docs[:9]]
+    enc = _native(cfg, sd)
+    model = bergen_amd.Dense("toy/bert-tiny", 48, bergen_amd.MeanPooler, bergen_amd.DotProduct, model=enc,
+                             tokenizer=ToyTokenizer())
+
+    class DS(dict):
+        pass
+
+    class Col:
+        def __init__(self, rows):
+            self.rows = rows
+
+        def __len__(self):
+            return len(self.rows)
+
+        def __getitem__(self, i):
+            if isinstance(i, str):
+                return [r[i] for r in self.rows]
+            return self.rows[i]
+
+        def remove_columns(self, cols):
+            return Col([{k: v for k, v in r.items() if k not in cols} for r in self.rows])
+
+    ds = {"doc": Col([{"id": str(i), "content": t} for i, t in enumerate(docs)]),
+          "query": Col([{"id": f"q{i}", "generated_query": t} for i, t in enumerate(queries)])}
+    r = bergen_amd.Retrieve(init_args=model, batch_size=64, batch_size_sim=4, num_workers=0)
+    out = r.retrieve(ds, str(tmp_path / "q"), str(tmp_path / "d"), 10)
+    r.close()
+    tok = ToyTokenizer()
+    bd, bq = tok(docs, max_length=48), tok(queries, max_length=48)
+    ed = bert_oracle.encode(sd, cfg, bd["input_ids"].numpy(), bd["attention_mask"].numpy(), pooler="mean")
+    eq = bert_oracle.encode(sd, cfg, bq["input_ids"].numpy(), bq["attention_mask"].numpy(), pooler="mean")
+    want = np.argsort(-(eq @ ed.T), axis=1)[:, :10]
+    got = np.array([[int(x) for x in row] for row in out["doc_id"]])
+    overlap = np.mean([len(set(g) & set(w)) / 10 for g, w in zip(got, want)])
+    assert overlap >= 0.9, overlap
+    assert (got[:, 0] == want[:, 0]).mean() >= 0.8
+    assert out["score"].shape == (len(queries), 10)
