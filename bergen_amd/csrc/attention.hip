@@ -6,15 +6,18 @@
 // becomes "keys >= len do not exist"; results for real tokens are identical (masked keys carry zero
 // probability in the reference as well).
 //
-// One wave per (sequence, head, 32-query block); four such waves (4 query blocks) per workgroup share the
-// sequence's K / V^T lines through the vector L1.  No LDS, no barriers.
+// One 8-wave workgroup per (sequence, head); wave w takes the 32-query blocks w, w+8, ...  The workgroup
+// first stages the sequence's whole K slice (len x 64) and V^T slice (64 x len) of this head into LDS with
+// coalesced loads — K in the XOR-permuted 128-byte-row image of the GEMM (conflict-free ds_read_b128 fragment
+// reads), V^T in 64-byte rows with an 8-byte-chunk XOR (conflict-free ds_read_b64) — one barrier, then every
+// wave runs its key loop out of LDS with no further global loads or barriers.
 //   S^T = K . Q^T          v_mfma_f32_32x32x16_f16, A = K rows (i = key), B = Q rows (j = query):
 //                          lane l owns query l&31 and 16 of the 32 key scores -> the softmax reductions are
 //                          in-lane plus ONE exchange between the two half-lanes of a query.
 //   online softmax         fp32, v_exp_f32, scale 1/8 folded into the exponent.
-//   O^T += V^T . P         A = V^T rows (i = head dim) read from the TRANSPOSED value matrix VT[d][tokens]
-//                          (written that way by the QKV GEMM) as two 8-byte loads per fragment, B = P (the
-//                          lane's own probabilities, already in operand layout).
+//   O^T += V^T . P         A = V^T rows (i = head dim) from the TRANSPOSED value matrix VT[d][tokens] (written that
+//                          way by the QKV GEMM), two 8-byte LDS reads per fragment, B = P (the lane's own
+//                          probabilities, already in operand layout).
 // Head dim is 64 (bert-base 768/12, bert-large 1024/16, e5 / contriever / bge / RetroMAE alike).
 // Roofline: MFMA (4 T^2 64 flop per head) — ~3 % of the encoder's flops at T = 128.
 #include "bh_device.h"
@@ -31,17 +34,88 @@ __device__ __forceinline__ float half_lanes_sum(float v) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256) bh_attention_kernel(BhAttnArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = blockIdx.z, head = blockIdx.y;
-    const int qb = blockIdx.x * 4 + wave;
+__global__ void __launch_bounds__(512, 4) bh_attention_kernel(BhAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.y, head = blockIdx.x;
     const int len = a.seq_len[s];
     const long long t0 = a.seq_off[s];
-    if (qb * 32 >= len) return;
-    const int ql = lane & 31, h = lane >> 5;
-    const int q0 = qb * 32;
+    const int nkb = (len + 31) >> 5;
+    unsigned char* smK = smem;                // nkb pieces of 32 keys x 128 B (XOR-permuted, see gemm_f16_kernel.h)
+    unsigned char* smV = smem + a.v_lds_off;  // nkb tiles of 64 dims x 32 keys (64-byte rows, 8-byte chunk XOR)
 
+    // ---- stage the sequence's K rows and V^T rows of this head into LDS, once, coalesced; all loads of a
+    // batch are issued before the first LDS store so that their latencies overlap
+    {
+        const _Float16* kg = a.qk + (size_t)t0 * a.ldqk + a.d_model + head * 64;
+        const _Float16* vg = a.vt + (size_t)(head * 64) * a.ldvt + t0;
+        constexpr int UB = 4;  // items per thread per batch: 4 K chunks + 4 V chunks in flight
+        const int n_items = nkb * 256;
+        for (int base = 0; base < n_items; base += 512 * UB) {
+            half8 kv[UB], vv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 512 + tid;
+                if (idx < n_items) {
+                    const int row = idx >> 3, c = idx & 7;  // key row, 16-byte chunk of its 128-byte head slice
+                    const int kr = row < len ? row : len - 1;
+                    kv[u] = *reinterpret_cast<const half8*>(kg + (size_t)kr * a.ldqk + c * 8);
+                    const int kbi = idx >> 8, dd = (idx >> 2) & 63, c16 = idx & 3;  // key block, head dim, 8-key chunk
+                    vv[u] = *reinterpret_cast<const half8*>(vg + (size_t)dd * a.ldvt + kbi * 32 + c16 * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 512 + tid;
+                if (idx < n_items) {
+                    const int row = idx >> 3, c = idx & 7;
+                    const int r = row & 31;
+                    const int g = ((r >> 1) & 1) | ((r >> 3) << 1);
+                    *reinterpret_cast<half8*>(smK + (row >> 5) * 4096 + (r >> 3) * 1024 + (r & 7) * 128 + ((c ^ g) << 4)) =
+                        kv[u];
+                    const int kbi = idx >> 8, dd = (idx >> 2) & 63, c16 = idx & 3;
+                    half4 lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = vv[u][e];
+                        hi[e] = vv[u][4 + e];
+                    }
+                    const int g8 = (dd >> 2) & 7;
+                    unsigned char* vb = smV + kbi * 4096 + dd * 64;
+                    *reinterpret_cast<half4*>(vb + (((2 * c16) ^ g8) << 3)) = lo;
+                    *reinterpret_cast<half4*>(vb + (((2 * c16 + 1) ^ g8) << 3)) = hi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ql = lane & 31, h = lane >> 5;
+    const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+
+    // LDS fragment offsets: K as the conflict-free ds_read_b128 pattern, V^T as conflict-free ds_read_b64
+    unsigned k_off[4];
+    {
+        const int g = ((ql >> 1) & 1) | ((ql >> 3) << 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+            k_off[s4] = (unsigned)((ql >> 3) * 1024 + (ql & 7) * 128 + (((2 * s4 + h) ^ g) << 4));
+    }
+    unsigned v_off[2][2];  // [s2][lo|hi] for head dim ql; head dim 32 + ql sits 2048 bytes further (same XOR term)
+    {
+        const int g8 = (ql >> 2) & 7;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int c8 = 4 * s2 + h;  // keys 16 s2 + 4 h + 0..3; the second half of the fragment sits 8 keys later
+            v_off[s2][0] = (unsigned)(ql * 64 + ((c8 ^ g8) << 3));
+            v_off[s2][1] = (unsigned)(ql * 64 + (((c8 + 2) ^ g8) << 3));
+        }
+    }
+
+    // wave w takes query blocks w, w+8, ... of the sequence
+    for (int qb = wave; qb * 32 < len; qb += 8) {
+    const int q0 = qb * 32;
     // Q fragments (operand B): lane (query ql, half h), k-step s4 covers head dims 16 s4 + 8 h .. + 8
     half8 qf[4];
     {
@@ -51,36 +125,29 @@ __global__ void __launch_bounds__(256) bh_attention_kernel(BhAttnArgs a) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *reinterpret_cast<const half8*>(qp + 16 * s4);
     }
-    const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-    float m_run = -__builtin_inff();               // running max (identical in both half-lanes)
-    float l_run = 0.f;                             // this half-lane's share of the running denominator
+    float m_run = -__builtin_inff();  // running max (identical in both half-lanes)
+    float l_run = 0.f;                // this half-lane's share of the running denominator
     floatx16 o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) o[dt][v] = 0.f;
 
-    const _Float16* kbase = a.qk + (size_t)t0 * a.ldqk + a.d_model + head * 64 + 8 * h;
-    const _Float16* vbase = a.vt + (size_t)(head * 64 + ql) * a.ldvt + t0 + 4 * h;
-    const int nkb = (len + 31) >> 5;
     for (int kb = 0; kb < nkb; ++kb) {
-        // K fragments (operand A): lane (key ql, half h)
-        int kr = kb * 32 + ql;
-        kr = kr < len ? kr : len - 1;
-        const _Float16* kp = kbase + (size_t)kr * a.ldqk;
+        const unsigned char* kt = smK + kb * 4096;
+        const unsigned char* vt = smV + kb * 4096;
         half8 kf[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) kf[s4] = *reinterpret_cast<const half8*>(kp + 16 * s4);
-        // V^T fragments (operand A of the second product): lane (dim ql [+32], half h); key slot (h, e) of
-        // step s2 is key kb*32 + 16 s2 + 8 (e>>2) + 4 h + (e&3)  — the order the probabilities sit in
+        for (int s4 = 0; s4 < 4; ++s4) kf[s4] = *reinterpret_cast<const half8*>(kt + k_off[s4]);
+        // V^T fragments: key slot (h, e) of step s2 is key kb*32 + 16 s2 + 8 (e>>2) + 4 h + (e&3) — the order the
+        // probabilities sit in the lane's registers
         half4 vlo[2][2], vhi[2][2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const _Float16* vp = vbase + (size_t)dt * 32 * a.ldvt + kb * 32 + 16 * s2;
-                vlo[dt][s2] = *reinterpret_cast<const half4*>(vp);
-                vhi[dt][s2] = *reinterpret_cast<const half4*>(vp + 8);
+                vlo[dt][s2] = *reinterpret_cast<const half4*>(vt + dt * 2048 + v_off[s2][0]);
+                vhi[dt][s2] = *reinterpret_cast<const half4*>(vt + dt * 2048 + v_off[s2][1]);
             }
 
         floatx16 sc;
@@ -142,11 +209,23 @@ __global__ void __launch_bounds__(256) bh_attention_kernel(BhAttnArgs a) {
                 *reinterpret_cast<half4*>(op + dt * 32 + 8 * gq) = w;
             }
     }
+    }  // query blocks
 }
 
-hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream) {
+hipError_t bh_launch_attention(const BhAttnArgs& a_in, int batch, int n_heads, int max_len, hipStream_t stream) {
     if (batch <= 0 || max_len <= 0) return hipSuccess;
-    const int qblocks = (max_len + 31) / 32;
-    hipLaunchKernelGGL(bh_attention_kernel, dim3((qblocks + 3) / 4, n_heads, batch), dim3(256), 0, stream, a);
+    const int nkb = (max_len + 31) / 32;
+    if (nkb * 8192 > 160 * 1024) return hipErrorInvalidValue;  // sequences longer than 640 tokens
+    BhAttnArgs a = a_in;
+    a.v_lds_off = nkb * 4096;
+    const size_t smem = (size_t)nkb * 8192;
+    static size_t attr_smem = 0;
+    if (smem > attr_smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_smem = smem;
+    }
+    hipLaunchKernelGGL(bh_attention_kernel, dim3(n_heads, batch), dim3(512), smem, stream, a);
     return hipGetLastError();
 }

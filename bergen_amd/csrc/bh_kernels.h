@@ -66,11 +66,13 @@ struct BhGemmArgs {
     int bias_mode;
     int gelu;    // erf-GELU on the result
     int swap_b;  // filled by the launcher: direction of v_permlane32_swap on this device
+    int stagger_phases, stagger_unit, stagger_first_round;  // start stagger of the first round of blocks (0 = off)
 };
 // variant 0 = auto; see gemm_f16.hip for the explicit tile configurations
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a, int variant, hipStream_t stream);
 hipError_t bh_gemm_probe_permlane(hipStream_t stream);
 int bh_gemm_swap_mode();
+void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of the first round of blocks
 
 struct BhAttnArgs {
     const _Float16* qk;  // [tokens][2*d_model]: queries in columns [0, d), keys in [d, 2d)
@@ -82,6 +84,7 @@ struct BhAttnArgs {
     const long long* seq_off;  // [batch] first row of each sequence (multiple of 8)
     const int* seq_len;        // [batch] tokens per sequence (>= 1)
     int d_model;
+    int v_lds_off;  // filled by the launcher: byte offset of the V^T image in LDS
 };
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 

@@ -202,6 +202,12 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "ring_variant") {
         if (value < 0 || value > 4) return fail(BH_EINVAL, "ring_variant must be 0..4");
         g_opt.ring_variant = (int)value;
+    } else if (s == "gemm_stagger_phases") {
+        if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");
+        bh_gemm_set_stagger((int)value, -1);
+    } else if (s == "gemm_stagger_pct") {
+        if (value < 1 || value > 400) return fail(BH_EINVAL, "gemm_stagger_pct must be 1..400");
+        bh_gemm_set_stagger(-1, (int)value);
     } else if (s == "workgroups_per_cu") {
         if (value != 1) return fail(BH_EINVAL, "workgroups_per_cu must be 1 (LDS ring fills the CU)");
         g_opt.workgroups_per_cu = 1;

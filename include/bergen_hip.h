@@ -163,7 +163,8 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg);
 int bh_encoder_set_tensor(bh_encoder* enc, const char* name, const void* host, int32_t dtype, int64_t numel);
 /* Check that every tensor of the architecture has been set (BH_EINCOMPLETE otherwise). */
 int bh_encoder_commit(bh_encoder* enc);
-/* name in {"gemm_variant" (0 = auto, 1..7 explicit tile configurations; bench sweeps)}. */
+/* name in {"gemm_variant" (0 = auto, 1..5 explicit tile configurations, 6 = generic bounds-checked kernel;
+ * bench sweeps)}. */
 int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
 
 /* One forward pass over a HOST batch in the layout of an HF BatchEncoding (row-major

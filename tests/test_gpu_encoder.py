@@ -45,7 +45,7 @@ def test_permlane_probe():
     assert encoder.permlane_mode() in (0, 1)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_variants_plain(variant):
     """Asymmetric operands, sizes that are not tile multiples (ragged M and N edges)."""
     from bergen_amd import encoder
@@ -56,7 +56,7 @@ def test_gemm_variants_plain(variant):
     assert_gemm_close(out, bert_oracle.gemm_ref(a, w), f"variant {variant} plain")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(variant):
     from bergen_amd import encoder
     rng = np.random.default_rng(200 + variant)
