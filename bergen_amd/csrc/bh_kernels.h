@@ -102,7 +102,8 @@ hipError_t bh_launch_embed_ln(const BhEmbedArgs& a, hipStream_t stream);
 
 struct BhLnArgs {
     const _Float16* in;
-    _Float16* out;  // may alias in
+    const _Float16* residual;  // optional second addend (same shape), may alias out
+    _Float16* out;             // may alias in
     long long n_rows;
     int d;
     float eps;

@@ -378,10 +378,11 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         aa.seq_len = d_len;
         aa.d_model = d;
         BH_HIP_TRY(bh_launch_attention(aa, batch, c.n_heads, max_len, st));
-        // attention output projection + residual, then LayerNorm
-        if ((rc = gemm(e, e->CTX.p, d, L.wo, d, e->Y.p, d, m_pad, d, d, L.bo, 1, e->X.p, d, 0))) return rc;
+        // attention output projection, then LayerNorm(projection + layer input)
+        if ((rc = gemm(e, e->CTX.p, d, L.wo, d, e->Y.p, d, m_pad, d, d, L.bo, 1, nullptr, 0, 0))) return rc;
         BhLnArgs la{};
         la.in = e->Y.p;
+        la.residual = e->X.p;  // X <- LayerNorm(Y + X)
         la.out = e->X.p;
         la.n_rows = m_pad;
         la.d = d;
@@ -389,9 +390,9 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         la.gamma = L.ln1g;
         la.beta = L.ln1b;
         BH_HIP_TRY(bh_launch_layernorm(la, st));
-        // FFN: H = GELU(X W1^T + b1);  Y = H W2^T + b2 + X;  X = LN(Y)
+        // FFN: H = GELU(X W1^T + b1);  Y = H W2^T + b2;  X = LN(Y + X)
         if ((rc = gemm(e, e->X.p, d, L.w1, d, e->H.p, dff, m_pad, dff, d, L.b1, 1, nullptr, 0, 1))) return rc;
-        if ((rc = gemm(e, e->H.p, dff, L.w2, dff, e->Y.p, d, m_pad, d, dff, L.b2, 1, e->X.p, d, 0))) return rc;
+        if ((rc = gemm(e, e->H.p, dff, L.w2, dff, e->Y.p, d, m_pad, d, dff, L.b2, 1, nullptr, 0, 0))) return rc;
         la.gamma = L.ln2g;
         la.beta = L.ln2b;
         BH_HIP_TRY(bh_launch_layernorm(la, st));
@@ -509,6 +510,7 @@ int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float 
     if (d <= 0 || (d & 7) || d > 2048) return bh_fail(BH_EUNSUPPORTED, "d=%d (multiple of 8, <= 2048)", d);
     BhLnArgs la{};
     la.in = static_cast<const _Float16*>(in);
+    la.residual = nullptr;
     la.out = static_cast<_Float16*>(out);
     la.n_rows = n_rows;
     la.d = d;

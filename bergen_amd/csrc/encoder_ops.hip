@@ -4,8 +4,8 @@
 //   bh_embed_ln_kernel   word + position + token-type embedding gather, sum, LayerNorm
 //                        (BertEmbeddings.forward, transformers modeling_bert.py; reached from the
 //                        reference through AutoModel, models/retrievers/dense.py:16)
-//   bh_layernorm_kernel  LayerNorm of (dense output + residual) — the sum is already formed by the GEMM
-//                        epilogue (BertSelfOutput / BertOutput: LayerNorm(dense(x) + input))
+//   bh_layernorm_kernel  LayerNorm(dense output + residual) (BertSelfOutput / BertOutput: LayerNorm(dense(x) +
+//                        input)); the residual is added here, in fp32, rather than in the GEMM epilogue
 //   bh_pool_kernel       ClsPooler.pool / MeanPooler.pool (reference models/retrievers/dense.py:64-75) over
 //                        the packed rows of each sequence, optional L2 normalisation, fp16 [B][d] out
 //   bh_unpack_kernel     packed rows -> padded [B][T][d] last_hidden_state (API compatibility: a stock
@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) bh_layernorm_kernel(BhLnArgs a) {
     if (row >= a.n_rows) return;
     const int nchunk = a.d >> 3;
     const _Float16* src = a.in + (size_t)row * a.d;
+    const _Float16* res = a.residual ? a.residual + (size_t)row * a.d : nullptr;
     float x[MAXC][8];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
@@ -103,6 +104,11 @@ __global__ void __launch_bounds__(256) bh_layernorm_kernel(BhLnArgs a) {
             const half8 v = *reinterpret_cast<const half8*>(src + (size_t)(lane + 64 * c) * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[c][e] = (float)v[e];
+            if (res) {  // LayerNorm(dense output + layer input): the residual add of BertSelfOutput / BertOutput
+                const half8 r = *reinterpret_cast<const half8*>(res + (size_t)(lane + 64 * c) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[c][e] += (float)r[e];
+            }
         }
     row_layernorm(x, nchunk, lane, a.d, a.eps, a.gamma, a.beta);
     store_row(a.out + (size_t)row * a.d, x, nchunk, lane);

@@ -23,7 +23,7 @@
 // costs as much as the 12-stage main loop when it runs serialised behind it, so the production configuration
 // keeps TWO independent 4-wave blocks per CU (256x128 tile, BK = 32, ring 3 = 72 KiB each): one block's
 // VALU/store epilogue overlaps the other block's MFMA main loop.
-#include "gemm_f16_kernel.h"
+#include "gemm_f16_persist.h"
 
 // Probe of v_permlane32_swap's direction (documented: vdst[32:63] <-> vsrc[0:31]).
 __global__ void bh_permlane_probe_kernel(unsigned* out) {
@@ -97,7 +97,9 @@ hipError_t run_cfg(int cfg, const BhGemmArgs& a, int epi, hipStream_t s) {
 }  // namespace
 
 // variant: 0 = auto; 1..5 = explicit tile configuration (gemm_f16_kernel.h); 6 = generic bounds-checked kernel
-// for everything; 11..16 = bench-only ablations (results invalid).
+// for everything; 7 = persistent 256x256 kernel (gemm_f16_persist.h; burst stores); 8 = 7 with stores deferred into
+// the next tile's main loop, 9 = 7 with non-temporal stores (both valid results; ablations); 11..28 = bench-only
+// ablations (results invalid).
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t stream) {
     BhGemmArgs a = a_in;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -109,7 +111,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     a.stagger_phases = 0;
     if (g_stagger_phases > 1) {
         // spread the first round of blocks over ~pct % of one tile time (estimated at 60 % MFMA utilisation)
-        const int cfgv = variant >= 21 ? 2 : variant >= 11 ? 5 : variant == 0 ? 5 : variant;
+        const int cfgv = variant >= 21 ? 2 : variant >= 11 ? 5 : (variant == 0 || (variant >= 7 && variant <= 9)) ? 5 : variant;
         if (cfgv >= 1 && cfgv <= 5) {
             const int bm = kTile[cfgv].bm, bn = kTile[cfgv].bn;
             const int per_cu = (cfgv == 1 || cfgv == 2) ? 2 : 1;
@@ -128,8 +130,17 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     if (a.gelu) epi |= BH_EPI_GELU;
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);
-    if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? 5 : (a.M >= 256 && a.N >= 128) ? 2 : 1;
+    const bool auto_variant = variant == 0;
+    if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? ((epi & BH_EPI_RESIDUAL) ? 5 : 7) : (a.M >= 256 && a.N >= 128) ? 2 : 1;
     if (variant == 6 || !epi_fast || g_swap_b != 0) return bh_gemm_generic(a, epi, stream);
+    const bool persist = variant >= 7 && variant <= 9;
+    // burst stores; non-temporal for the GELU (FFN-up) output, which is far larger than the caches and is read
+    // back only by the next kernel (measured: +8 % on that GEMM, -7 % on the others)
+    const int pst = variant == 8 ? 0 : variant == 9 ? 3 : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
+    if (persist) {
+        if (epi & BH_EPI_RESIDUAL) return bh_gemm_generic(a, epi, stream);  // (the encoder adds residuals in LayerNorm)
+        variant = 5;  // same tile geometry
+    }
     if (variant < 1 || variant > 5) return hipErrorInvalidValue;
     // interior region with the fast kernel, edge strips with the generic one
     const int bm = kTile[variant].bm, bn = kTile[variant].bn;
@@ -138,7 +149,8 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         BhGemmArgs t = a;
         t.M = mi;
         t.N = ni;
-        if ((e = run_cfg(variant, t, epi, stream)) != hipSuccess) return e;
+        e = persist ? bh_gemm_persist(t, epi, pst, stream) : run_cfg(variant, t, epi, stream);
+        if (e != hipSuccess) return e;
     }
     if (ni < a.N) {  // right strip: all rows, columns [ni, N)
         BhGemmArgs t = a;

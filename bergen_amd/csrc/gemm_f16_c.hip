@@ -1,0 +1,34 @@
+// gemm_f16_c.hip — instantiations of the persistent encoder GEMM (gemm_f16_persist.h).
+#include "gemm_f16_persist.h"
+
+namespace {
+int g_n_cu = 0;
+int n_cu() {
+    if (g_n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_n_cu = prop.multiProcessorCount;
+        if (g_n_cu <= 0) g_n_cu = 256;
+    }
+    return g_n_cu;
+}
+}  // namespace
+
+// epi in {0, bias-col, bias-row, bias-col + GELU}; pst: 1 = burst stores (production), 0 = deferred stores,
+// 3 = burst + non-temporal stores (gemm_f16_persist.h)
+#define BH_PERSIST_EPI(P)                                                                                         \
+    switch (epi) {                                                                                                \
+        case 0: return bh_gemm_launch_persist<0, P>(a, n_cu(), s);                                                \
+        case BH_EPI_BIAS_COL: return bh_gemm_launch_persist<BH_EPI_BIAS_COL, P>(a, n_cu(), s);                    \
+        case BH_EPI_BIAS_ROW: return bh_gemm_launch_persist<BH_EPI_BIAS_ROW, P>(a, n_cu(), s);                    \
+        case BH_EPI_BIAS_COL | BH_EPI_GELU: return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_GELU, P>(a, n_cu(), s); \
+    }                                                                                                             \
+    return hipErrorNotSupported;
+
+hipError_t bh_gemm_persist(const BhGemmArgs& a, int epi, int pst, hipStream_t s) {
+    if (pst == 1) { BH_PERSIST_EPI(1) }
+    if (pst == 0) { BH_PERSIST_EPI(0) }
+    if (pst == 3) { BH_PERSIST_EPI(3) }
+    return hipErrorNotSupported;
+}

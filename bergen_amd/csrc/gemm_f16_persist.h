@@ -1,0 +1,318 @@
+// gemm_f16_persist.h — persistent form of the encoder GEMM (256x256 tile, 8 waves, BK = 64, ring 2).
+//
+// Why (profiles/README.md, GEMM ablations): with one 128-KiB block per CU, a K = 768 tile spends as long in its
+// serialised tail — draining 128 KiB of output through the store queue at the CU's share of HBM write bandwidth,
+// plus the pipeline refill of the next block — as in its 12-stage main loop.  Here a workgroup stays resident
+// and walks its tiles:
+//   * the LDS-DMA pipeline never drains: while a tile's last stages are consumed, the stages issued behind them
+//     already belong to the NEXT tile;
+//   * a finished tile's accumulators go through the epilogue math (bias / GELU / fp16 convert) into 64 packed
+//     registers, and the 16-byte stores are issued two per stage inside the NEXT tile's main loop, between its
+//     MFMAs — the store queue drains while the matrix pipe works.
+// Everything else (LDS image, fragment pattern, MFMA orientation, XCD-aware tile order) is gemm_f16_kernel.h's.
+#pragma once
+#include <type_traits>
+
+#include "gemm_f16_kernel.h"
+
+// PST bits: 1 = the stores of a tile are issued in one burst right after its epilogue math (production: measured
+// faster — on gfx950 stores share the vmcnt counter with the LDS-DMA loads, so stores spread over the stages make
+// every stage hand-over wait for store acknowledgements); 0 = stores deferred two per stage into the next tile's
+// main loop (kept as an ablation); 2 = non-temporal stores.
+template <int EPI, int PST = 0>
+__global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BK = 64, WM = 2, WN = 4, TM = 4, TN = 2, R = 2;
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int PIECE = 4096, SUBS = 4, KS = 4;
+    constexpr int STAGE_BYTES = (PA + PB) * PIECE;
+    constexpr int NL = (PA + PB) * SUBS / NW;  // 8 LDS-DMA instructions per wave per stage
+    constexpr int NMF = TM * TN;               // 8 MFMAs per k-step
+    constexpr int NST = TM * TN * 2;           // 16 deferred 16-byte stores per lane per tile
+    constexpr int SLOTS = 8;                   // main-loop stages that carry deferred stores (2 each)
+    static_assert(NST == 2 * SLOTS, "store schedule");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ql = lane & 31, h = lane >> 5;
+
+    // ---- this block's tiles: XCD x (= block % 8) owns a contiguous range of the (m-major, n-minor) tile order;
+    // its blocks j = block / 8 take tiles start + j, start + j + G/8, ... so that the XCD's CUs work on
+    // neighbouring tiles at the same time
+    const int tiles_n = a.N / BN;
+    const int n_tiles = (a.M / BM) * tiles_n;
+    int t_first, t_step, n_my;
+    {
+        const int G8 = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = n_tiles >> 3, r = n_tiles & 7;
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = q + (x < r ? 1 : 0);
+        t_first = start + j;
+        t_step = G8;
+        n_my = cnt > j ? (cnt - j + G8 - 1) / G8 : 0;
+    }
+    if (n_my == 0) return;
+
+    // ---- per-lane LDS-DMA source offsets inside a tile.  Instruction i of a wave fetches 8 rows of piece
+    // 2 i + (wave >> 2) (i < 4: A pieces, i >= 4: B pieces), so its offset is a per-lane base plus a uniform stride.
+    constexpr int NLA = PA * SUBS / NW;  // 4: instructions 0..3 fetch A rows, 4..7 fetch B rows
+    static_assert(NLA * NW == PA * SUBS && NW == 8 && SUBS == 4, "piece schedule");
+    unsigned offA, offB;  // byte offsets of the lane's source inside the tile's A rows / B rows for i = 0 / i = NLA
+    int dst0;             // wave-uniform LDS destination of instruction 0; instruction i adds i * 2 * PIECE
+    {
+        const int sub = wave & 3, p0 = wave >> 2;
+        const int row = 8 * sub + (lane >> 3);
+        const int g = ((row >> 1) & 1) | ((row >> 3) << 1);
+        const int chunk = (lane & 7) ^ g;
+        offA = (unsigned)((p0 * 32 + row) * a.lda * 2 + chunk * 16);
+        offB = (unsigned)((p0 * 32 + row) * a.ldb * 2 + chunk * 16);
+        dst0 = p0 * PIECE + sub * 1024;
+    }
+    const unsigned strideA = (unsigned)(64 * a.lda * 2), strideB = (unsigned)(64 * a.ldb * 2);
+    unsigned rd_off[KS];
+    {
+        const int g = ((ql >> 1) & 1) | ((ql >> 3) << 1);
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+            rd_off[j] = (unsigned)((ql >> 3) * 1024 + (ql & 7) * 128 + (((2 * j + h) ^ g) << 4));
+    }
+
+    const int KT = a.K / BK;
+    const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.A);
+    const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.B);
+
+    // ---- issue cursor (runs R-1 stages ahead of the consumer, across tile boundaries)
+    int it = 0, ikt = 0, islot = 0;  // tile ordinal, k-stage inside it, ring slot
+    const unsigned char *curA, *curB;  // wave-uniform bases of the issue tile's A rows / B rows
+    auto set_issue_tile = [&](int ord) {
+        const int t = t_first + ord * t_step;
+        const int tm0 = (t / tiles_n) * BM, tn0 = (t % tiles_n) * BN;
+        curA = baseA + (size_t)tm0 * a.lda * 2;
+        curB = baseB + (size_t)tn0 * a.ldb * 2;
+    };
+    set_issue_tile(0);
+    auto issue_piece = [&](int i) {
+        // uniform 64-bit base + per-lane 32-bit offset (saddr form of global_load_lds)
+        const unsigned char* ub = (i < NLA ? curA : curB) + (size_t)ikt * (BK * 2);
+        unsigned off = i < NLA ? offA : offB;
+        asm volatile("" : "+v"(off));  // keep ONE live offset register: stops hipcc from hoisting (and spilling)
+                                       // eight precomputed 64-bit per-lane addresses
+        off += i < NLA ? (unsigned)i * strideA : (unsigned)(i - NLA) * strideB;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ub + off),
+            (__attribute__((address_space(3))) void*)(smem + islot * STAGE_BYTES + dst0 + i * 2 * PIECE), 16, 0, 0);
+    };
+    auto issue_advance = [&]() {
+        if (++islot == R) islot = 0;
+        if (++ikt == KT) {
+            if (it + 1 < n_my) {  // the pipeline rolls straight into the next tile
+                ++it;
+                ikt = 0;
+                set_issue_tile(it);
+            } else {
+                ikt = KT - 1;  // no further tile: harmless re-fetch of the last stage keeps vmcnt uniform
+            }
+        }
+    };
+    auto issue_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) issue_piece(i);
+        issue_advance();
+    };
+
+    floatx16 acc[TM][TN];
+    half8 pend[NST];             // previous tile's outputs, packed, waiting to be stored
+    _Float16* pend_ptr = a.C;    // per-lane address of the pending tile's (tm = 0, tn = 0, u = 0) store
+    bool pend_valid = false;
+    const long long ldc32 = a.ldc * 32;
+
+    // Fragments: the weight fragments wb are double-buffered over the k-steps; the activation fragments xa are
+    // single-buffered and refilled "rolling": xa[tm] of the next k-step is read right after the MFMAs that
+    // consume the current xa[tm] have been issued (6 MFMAs of cover before it is needed again).
+    half8 xa[TM], wb[2][TN];
+    auto read_wb = [&](int buf, const unsigned char* st, int j) {
+        const unsigned char* sw = st + (PA + wn * TN) * PIECE + rd_off[j];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) wb[buf][tn] = *reinterpret_cast<const half8*>(sw + tn * PIECE);
+    };
+    auto read_xa = [&](int tm, const unsigned char* st, int j) {
+        xa[tm] = *reinterpret_cast<const half8*>(st + (wm * TM + tm) * PIECE + rd_off[j]);
+    };
+    auto store_pending = [&](int q) {  // q = (tm * TN + tn) * 2 + u
+        const int tm = q >> 2, tn = (q >> 1) & 1, u = q & 1;
+        half8* p = reinterpret_cast<half8*>(pend_ptr + tm * ldc32 + tn * 32 + u * 16);
+        if constexpr ((PST & 2) != 0)
+            __builtin_nontemporal_store(pend[q], p);
+        else
+            *p = pend[q];
+    };
+
+    int cslot = 0;
+    // one pipeline stage of the consumed tile; SLOT >= 0: this stage also issues deferred stores 2*SLOT, 2*SLOT+1
+    auto stage = [&](auto slot_c, bool first) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const unsigned char* st = smem + cslot * STAGE_BYTES;
+        if (++cslot == R) cslot = 0;
+#pragma unroll
+        for (int j = 0; j < KS - 1; ++j) {
+            read_wb((j + 1) & 1, st, j + 1);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    if (j == 0 && first) {  // first MFMA group of a tile starts from zero accumulators
+                        floatx16 z;
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) z[v] = 0.f;
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[0][tn], xa[tm], z, 0, 0, 0);
+                    } else {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j & 1][tn], xa[tm], acc[tm][tn], 0, 0, 0);
+                    }
+                }
+                read_xa(tm, st, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // last k-step.  Every read of this stage must have returned before its slot is handed back:
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wb[1][tn]));
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xa[tm]));
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // next stage landed (ring 2)
+        const unsigned char* nst = smem + cslot * STAGE_BYTES;
+        read_wb(0, nst, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[1][tn], xa[tm], acc[tm][tn], 0, 0, 0);
+                issue_piece(tm * TN + tn);  // NL == NMF: one LDS-DMA instruction per MFMA gap
+            }
+            read_xa(tm, nst, 0);
+            if constexpr (SLOT >= 0 && (PST & 1) == 0) {
+                if (tm == 1 && pend_valid) store_pending(2 * SLOT);
+                if (tm == 3 && pend_valid) store_pending(2 * SLOT + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        issue_advance();
+    };
+    static_assert(NL == NMF, "issue schedule");
+
+    // ---- pipeline start
+#pragma unroll
+    for (int p = 0; p < R - 1; ++p) issue_stage();
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_stage();
+    read_wb(0, smem, 0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) read_xa(tm, smem, 0);
+
+    for (int ti = 0; ti < n_my; ++ti) {
+        const int t = t_first + ti * t_step;
+        const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+        // ---- main loop: the first SLOTS stages are unrolled (static register indices for the deferred stores)
+        {
+            int kt = 0;
+#define BH_ST(S)                                                          \
+    if (kt < KT) {                                                        \
+        stage(std::integral_constant<int, S>{}, S == 0);                  \
+        ++kt;                                                             \
+    }
+            BH_ST(0) BH_ST(1) BH_ST(2) BH_ST(3) BH_ST(4) BH_ST(5) BH_ST(6) BH_ST(7)
+#undef BH_ST
+            for (; kt < KT; ++kt) stage(std::integral_constant<int, -1>{}, false);
+            // K so short that some deferred stores found no stage: flush them now
+            if (pend_valid && (PST & 1) == 0) {
+#pragma unroll
+                for (int s2 = 0; s2 < SLOTS; ++s2)
+                    if (s2 >= KT) {
+                        store_pending(2 * s2);
+                        store_pending(2 * s2 + 1);
+                    }
+            }
+        }
+        // ---- epilogue math of this tile -> pend (stores are issued inside the next tile's main loop)
+        {
+            float bias_row[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                bias_row[tm] = 0.f;
+                if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) bias_row[tm] = (float)a.bias[m0 + (wm * TM + tm) * 32 + ql];
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                half8 b8[2];
+                if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        b8[u] = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    floatx16 c = acc[tm][tn];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * u + e]),
+                                                                      __float_as_uint(c[8 * u + 4 + e]), false, false);
+                            c[8 * u + e] = __uint_as_float(r[0]);
+                            c[8 * u + 4 + e] = __uint_as_float(r[1]);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        half8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = c[8 * u + e] + bias_row[tm];
+                            if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)b8[u][e];
+                            if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
+                            o[e] = (_Float16)v;
+                        }
+                        pend[(tm * TN + tn) * 2 + u] = o;
+                    }
+                }
+            }
+            pend_ptr = a.C + (size_t)(m0 + wm * TM * 32 + ql) * a.ldc + n0 + wn * TN * 32 + 8 * h;
+            pend_valid = true;
+            if constexpr ((PST & 1) != 0) {
+#pragma unroll
+                for (int q = 0; q < NST; ++q) store_pending(q);
+            }
+        }
+    }
+    // ---- drain: the last tile's outputs
+    if constexpr ((PST & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < NST; ++q) store_pending(q);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int PST = 0>
+hipError_t bh_gemm_launch_persist(const BhGemmArgs& a, int n_cu, hipStream_t stream) {
+    constexpr size_t smem = 2 * 16 * 4096;  // ring 2 x (8 + 8) pieces
+    auto kern = bh_gemm_f16_pkernel<EPI, PST>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = (a.M / 256) * (a.N / 256);
+    if (tiles <= 0) return hipSuccess;
+    int grid = n_cu / 8 * 8;  // one resident workgroup per CU, a multiple of the XCD count
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t bh_gemm_persist(const BhGemmArgs& a, int epi, int pst, hipStream_t s);  // gemm_f16_c.hip

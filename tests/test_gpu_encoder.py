@@ -45,7 +45,7 @@ def test_permlane_probe():
     assert encoder.permlane_mode() in (0, 1)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_variants_plain(variant):
     """Asymmetric operands, sizes that are not tile multiples (ragged M and N edges)."""
     from bergen_amd import encoder
@@ -56,7 +56,7 @@ def test_gemm_variants_plain(variant):
     assert_gemm_close(out, bert_oracle.gemm_ref(a, w), f"variant {variant} plain")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_epilogues(variant):
     from bergen_amd import encoder
     rng = np.random.default_rng(200 + variant)
@@ -72,6 +72,23 @@ def test_gemm_epilogues(variant):
     assert_gemm_close(out, bert_oracle.gemm_ref(a, w, bias_c, 1, res), "bias + residual")
     out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(bias_c), gelu=True, variant=variant)
     assert_gemm_close(out, bert_oracle.gemm_ref(a, w, bias_c, 1, gelu=True), "bias + gelu")
+
+
+def test_gemm_persistent_many_tiles_per_block():
+    """Persistent kernel with several tiles per workgroup (deferred stores, cross-tile prefetch), K from one stage
+    (fewer stages than deferred-store slots) to 48 stages; every epilogue it supports."""
+    from bergen_amd import encoder
+    rng = np.random.default_rng(77)
+    for (M, N, K) in [(2048, 1024, 64), (1536, 1280, 320), (4096, 2560, 768), (768, 5120 + 256, 3072)]:
+        a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
+        bc, br = rnd16(rng, N), rnd16(rng, M)
+        for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)),
+                        (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
+                        (dict(bias=h16(br), bias_mode=2), bert_oracle.gemm_ref(a, w, br, 2)),
+                        (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
+            for variant in (7, 8):
+                out, _ = encoder.gemm_f16(h16(a), h16(w), variant=variant, **kw)
+                assert_gemm_close(out, ref, f"persistent v{variant} {M}x{N}x{K} {sorted(kw)}")
 
 
 def test_gemm_identity_and_odd_n():
