@@ -21,10 +21,13 @@ if [ "${2:-}" = "pmc" ]; then
   timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "bh_scan" --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH --steps 1 > "$OUT/pmc_write.log" 2>&1
   echo "== PMC pass 3: SQ"
   timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-include-regex "bh_scan" --output-format csv -d "$OUT/pmc_sq" -o bench -- $BENCH --steps 1 > "$OUT/pmc_sq.log" 2>&1
+  echo "== PMC pass 4: SQ counters of the encoder GEMM / attention kernels"
+  timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-include-regex "bh_gemm|bh_attention" --output-format csv -d "$OUT/pmc_enc" -o bench -- $BENCH --steps 1 > "$OUT/pmc_enc.log" 2>&1
+  python $REPO/profiles/summarize_pmc_enc.py "$OUT/pmc_enc" "$OUT/pmc_encoder_summary.json" > "$OUT/pmc_encoder_summary.log" 2>&1
 fi
 python $REPO/profiles/summarize_pmc.py "$OUT" "$OUT/pmc_summary.json" 21000000 768 > "$OUT/pmc_summary.log" 2>&1
 # keep only small artefacts for the copy-back
 head -c 200000 "$OUT/trace/bench_kernel_trace.csv" > "$OUT/kernel_trace_head.csv" 2>/dev/null
 cp "$OUT/trace/bench_kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
-rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
+rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_enc"
 ls -la "$OUT"
