@@ -16,7 +16,7 @@ there is no CPU fallback.
   ShardedSearcher     row-sharded multi-GPU search (one process per GPU, RCCL all-gather)
   utils               chunk-file / .trec formats, path naming (reference utils.py)
 """
-from . import utils  # noqa: F401
+from . import evaluation, utils  # noqa: F401
 from .config import instantiate  # noqa: F401
 from .dense import ClsPooler, CosineSim, Dense, DotProduct, MeanPooler, Retriever  # noqa: F401
 from .encoder import BertEncoder  # noqa: F401

@@ -85,3 +85,28 @@ def get_ranking_filename(runs_folder, query_dataset, doc_dataset, retriever_name
     query_gen_add = "" if query_generator_name == "copy" else f".{query_generator_name}"
     return (f'{runs_folder}/run.retrieve.top_{retrieve_top_k}.{query_dataset}.{doc_dataset}.{dataset_split}.'
             f'{retriever_name}{query_gen_add}.trec')
+
+
+def merge_indexes(in_paths, out_path):
+    """Merge several index folders into one by symlinking their chunk files under renumbered names — the
+    reference's scripts/multilingual/merge_indexes.py:37-44: chunks of each input keep their order (integer of
+    the digits in the file name), chunk i of an input becomes ``embedding_chunk_{base + i}.pt`` and the next
+    input starts at the last new index + 1.  Returns the list of (link, target) pairs created."""
+    if os.path.exists(out_path) and len(os.listdir(out_path)) > 0:
+        raise FileExistsError(f"Folder {out_path} already exists and is not empty, exiting")
+    for in_path in in_paths:
+        if not os.path.exists(in_path) or len(os.listdir(in_path)) == 0:
+            raise FileNotFoundError(f"All indexes for merging should be precomputed. Index {in_path} does not exist")
+    os.makedirs(out_path, exist_ok=True)
+    made = []
+    current_global_index = 0
+    for in_path in in_paths:
+        newidx = current_global_index
+        for chunk in sorted(os.listdir(in_path), key=lambda x: int(''.join(filter(str.isdigit, x)))):
+            idx = int(''.join(filter(str.isdigit, chunk)))
+            newidx = current_global_index + idx
+            link = os.path.join(out_path, f"embedding_chunk_{newidx}.pt")
+            os.symlink(os.path.abspath(os.path.join(in_path, chunk)), link)
+            made.append((link, os.path.join(in_path, chunk)))
+        current_global_index = newidx + 1
+    return made

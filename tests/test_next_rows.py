@@ -1,0 +1,111 @@
+"""CPU: the "next" rows of SURVEY §8f that sit either side of the hot path — ranking evaluation
+(reference utils.eval_retrieval_kilt) and index-folder merging (reference scripts/multilingual/merge_indexes.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import bergen_amd
+from bergen_amd import evaluation
+
+from oracle import ref_import
+
+
+def test_max_passage_and_metrics_hand_checked(tmp_path):
+    # two passages of page "A" (scores 3, 9), pages B, C; relevant: A and D (D never retrieved)
+    q_ids = ["q1", "q2", "q3"]
+    d_ids = [["A", "B", "A", "C"], ["B", "C"], ["X"]]
+    scores = [[3.0, 5.0, 9.0, 1.0], [2.0, 2.0], [1.0]]
+    run = evaluation.max_passage_run(q_ids, d_ids, scores)
+    assert run["q1"] == {"A": 9.0, "B": 5.0, "C": 1.0}
+    qrel = {"q1": {"A": 1, "D": 1}, "q2": {"B": 1}, "other": {"Z": 1}}
+    m = evaluation.ranking_metrics(run, qrel, top_k=2)
+    # q1: top-1 = A (relevant) -> P_1 1; recall_2 = 1/2.  q2: tie B/C at 2.0 -> trec_eval ranks the larger id (C)
+    # first -> P_1 0, recall_2 = 1/1.  q3 is not in the qrels: ignored.
+    assert m["P_1"] == pytest.approx(0.5) and m["recall_2"] == pytest.approx(0.75)
+
+
+def test_eval_retrieval_kilt_files_and_early_returns(tmp_path):
+    exp, qrels = tmp_path / "exp", tmp_path / "qrels"
+    exp.mkdir()
+    qrels.mkdir()
+    assert evaluation.eval_retrieval_kilt(str(exp), str(qrels), "kilt_nq", "kilt-100w", "dev", ["q"], [["d"]], [[1.0]]) is None
+    json.dump({"doc_dataset_name": "other-corpus", "q": {"d": 1}}, open(qrels / "qrel.kilt_nq.dev.json", "w"))
+    assert evaluation.eval_retrieval_kilt(str(exp), str(qrels), "kilt_nq", "kilt-100w", "dev", ["q"], [["d"]], [[1.0]]) is None
+    json.dump({"doc_dataset_name": "kilt-100w", "q": {"d": 1}, "q2": {"e": 1}}, open(qrels / "qrel.kilt_nq.dev.json", "w"))
+    m = evaluation.eval_retrieval_kilt(str(exp), str(qrels), "kilt_nq", "kilt-100w", "dev", ["q", "q2"],
+                                       [["x", "d", "x"], ["y"]], torch.tensor([[3.0, 2.0, 4.0], [1.0, 0.0, 0.0]])[:, :3].tolist(),
+                                       top_k=5)
+    assert m == {"P_1": 0.0, "recall_5": 0.5}
+    assert json.load(open(exp / "eval_dev_ranking_metrics.json")) == m
+    lines = open(exp / "eval_dev_ranking_run.trec").read().splitlines()
+    assert lines[0] == "q\tQO\tx\t1\t4.0\trun" and lines[1] == "q\tQO\td\t2\t2.0\trun"
+    m2 = evaluation.eval_retrieval_kilt(str(exp), str(qrels), "kilt_nq", "kilt-100w", "dev", ["q"], [["d"]], [[1.0]],
+                                        reranking=True, write_trec=False)
+    assert m2["P_1"] == 1.0 and os.path.exists(exp / "eval_dev_reranking_metrics.json")
+
+
+def test_metrics_on_a_shipped_reference_run_are_well_formed():
+    """A real run + qrels shipped with the reference (read-only).  The run's doc ids are PASSAGE ids (the page-id
+    mapping needs the KILT dataset, not available offline), so this exercises the plumbing at scale — 50 hits for
+    every query, metrics in range — not the published recall@5."""
+    if not ref_import.available():
+        pytest.skip("/root/reference not present")
+    root = ref_import.REFERENCE_ROOT
+    run_file = os.path.join(root, "runs", "run.retrieve.top_50.kilt_eli5.kilt-100w.dev.Shitao_RetroMAE_MSMARCO_distill.trec")
+    if not os.path.exists(run_file):
+        pytest.skip("run file not shipped")
+    q_ids, d_ids, scores = bergen_amd.utils.load_trec(run_file)
+    assert all(len(d) == 50 for d in d_ids)
+    qrel = json.load(open(os.path.join(root, "qrels", "qrel.kilt_eli5.dev.json")))
+    run = evaluation.max_passage_run(q_ids, d_ids, scores)
+    m = evaluation.ranking_metrics(run, qrel, top_k=5)
+    assert 0.0 <= m["P_1"] <= 1.0 and 0.0 <= m["recall_5"] <= 1.0
+    assert sum(1 for q in run if q in qrel) > 0  # the qrels file holds other datasets' queries too
+
+
+def _fake_index(path, idxs):
+    os.makedirs(path)
+    for i in idxs:
+        torch.save(torch.full((2, 4), float(i)).half(), os.path.join(path, f"embedding_chunk_{i}.pt"))
+
+
+def test_merge_indexes_renumbering(tmp_path):
+    a, b, out = tmp_path / "wiki_en_doc_m", tmp_path / "wiki_fr_doc_m", tmp_path / "wiki_all_doc_m"
+    _fake_index(str(a), [292, 584, 600])
+    _fake_index(str(b), [292, 300])
+    made = bergen_amd.utils.merge_indexes([str(a), str(b)], str(out))
+    names = sorted(os.listdir(out), key=bergen_amd.utils.chunk_sort_key)
+    # second index starts at 600 + 1: 601 + 292, 601 + 300
+    assert names == [f"embedding_chunk_{i}.pt" for i in (292, 584, 600, 893, 901)]
+    assert len(made) == 5 and all(os.path.islink(l) for l, _ in made)
+    merged = bergen_amd.utils.load_embeddings(str(out))
+    assert merged.shape == (10, 4) and merged[:, 0].tolist() == [292.0] * 2 + [584.0] * 2 + [600.0] * 2 + [292.0] * 2 + [300.0] * 2
+    with pytest.raises(FileExistsError):
+        bergen_amd.utils.merge_indexes([str(a), str(b)], str(out))
+    with pytest.raises(FileNotFoundError):
+        bergen_amd.utils.merge_indexes([str(a), str(tmp_path / "missing")], str(tmp_path / "o2"))
+
+
+@pytest.mark.needs_reference
+def test_merge_indexes_matches_the_reference_script(tmp_path):
+    """Run the reference's own scripts/multilingual/merge_indexes.py on the same folders."""
+    import yaml
+    idx = tmp_path / "indexes"
+    _fake_index(str(idx / "wiki_en_doc_m"), [292, 584])
+    _fake_index(str(idx / "wiki_fr_doc_m"), [100, 292])
+    cfg = {"dev": {"doc": {"init_args": {"in_dataset_names": ["wiki_en", "wiki_fr"], "in_dataset_splits": ["train", "train"],
+                                          "out_dataset_name": "wiki_all", "split": "train"}}}}
+    y = tmp_path / "ds.yaml"
+    yaml.safe_dump(cfg, open(y, "w"))
+    script = os.path.join(ref_import.REFERENCE_ROOT, "scripts", "multilingual", "merge_indexes.py")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, script, "--dataset_yaml", str(y), "--indexes_path", str(idx), "--retriever", "m"],
+                   check=True, env=env)
+    want = sorted(os.listdir(idx / "wiki_all_doc_m"))
+    ours = tmp_path / "ours"
+    bergen_amd.utils.merge_indexes([str(idx / "wiki_en_doc_m"), str(idx / "wiki_fr_doc_m")], str(ours))
+    assert sorted(os.listdir(ours)) == want
