@@ -12,6 +12,7 @@ there is no CPU fallback.
                       model plug-in, drop-in for models.retrievers.dense.*
   BertEncoder         BERT-architecture forward pass on hand-written HIP kernels (HF AutoModel drop-in)
   FlatIndex           resident HBM index + fused inner-product/top-k search
+  SparseIndex, Splade resident CSR index + exact sparse search; SPLADE plug-in (models.retrievers.splade.Splade)
   merge_topk          device merge of per-shard partial top-k lists
   ShardedSearcher     row-sharded multi-GPU search (one process per GPU, RCCL all-gather)
   utils               chunk-file / .trec formats, path naming (reference utils.py)
@@ -23,5 +24,7 @@ from .encoder import BertEncoder  # noqa: F401
 from .index import FlatIndex, merge_topk  # noqa: F401
 from .retrieve import Retrieve  # noqa: F401
 from .sharded import ShardedSearcher, shard_range  # noqa: F401
+from .sparse import SparseIndex  # noqa: F401
+from .splade import Splade  # noqa: F401
 
 __version__ = "0.1.0"

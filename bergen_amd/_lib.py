@@ -100,6 +100,14 @@ SYMBOLS = {
     "bh_op_attention": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32]),
     "bh_op_layernorm": (ctypes.c_int, [_vp, _vp, _i64, _i32, ctypes.c_float, _vp, _vp]),
     "bh_gemm_permlane_mode": (ctypes.c_int, []),
+    "bh_sparse_create": (ctypes.c_int, [ctypes.POINTER(_vp), _i64, _i32]),
+    "bh_sparse_upload_csr": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32]),
+    "bh_sparse_finalize": (ctypes.c_int, [_vp]),
+    "bh_sparse_rows_uploaded": (_i64, [_vp]),
+    "bh_sparse_nnz": (_i64, [_vp]),
+    "bh_sparse_search": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "bh_sparse_counters": (ctypes.c_int, [_vp, ctypes.POINTER(bh_counters)]),
+    "bh_sparse_destroy": (None, [_vp]),
 }
 
 _lib = None

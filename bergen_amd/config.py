@@ -17,6 +17,7 @@ TARGET_ALIASES = {
     "models.retrievers.dense.ClsPooler": "bergen_amd.dense.ClsPooler",
     "models.retrievers.dense.DotProduct": "bergen_amd.dense.DotProduct",
     "models.retrievers.dense.CosineSim": "bergen_amd.dense.CosineSim",
+    "models.retrievers.splade.Splade": "bergen_amd.splade.Splade",
     "modules.retrieve.Retrieve": "bergen_amd.retrieve.Retrieve",
 }
 

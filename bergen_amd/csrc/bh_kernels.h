@@ -129,3 +129,36 @@ struct BhUnpackArgs {
     int batch, seq_len_padded, d;
 };
 hipError_t bh_launch_unpack(const BhUnpackArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// sparse (SPLADE) retrieval: csr_topk.hip, orchestrated by sparse.hip
+
+struct BhCsrScanArgs {
+    const unsigned* entries;    // [nnz] uint16 term id | fp16 weight << 16, rows sorted by term id
+    const long long* row_ptr;   // [n_rows + 1]
+    long long n_rows;
+    const unsigned* bitmap;     // [n_words] bit t set <=> some query of the tile uses term t
+    const unsigned short* prefix;  // [n_words] number of set bits in the preceding words (= slot of the word's first term)
+    const _Float16* W;          // [(n_slots + 1)][64] tile weights: W[slot][query]; the last row is zeros
+    int n_words, n_slots;
+    int off_prefix, off_w, off_thr;  // byte offsets of the LDS images
+    bh_u64* cand;               // [grid * 16][64][2 * KP] per-wave candidate buffers (scratch)
+    bh_u64* partial;            // [grid][64][KP] out: per-workgroup sorted best-KP keys
+    unsigned* gthr;             // [64] chip-wide score bounds (ordf), initialised to BH_ORD_NEG_INF
+};
+hipError_t bh_launch_csr_scan(const BhCsrScanArgs& a, int kp, int grid, size_t smem, hipStream_t stream);
+
+struct BhCsrMergeArgs {
+    const bh_u64* partial;  // [n_lists][64][KP]
+    int n_lists;
+    const unsigned* entries;
+    const long long* row_ptr;
+    long long n_rows;
+    const _Float16* q_dense;  // [tile queries][vocab] fp16
+    int vocab;
+    int k;
+    long long id_offset;
+    float* out_scores;    // already offset to the tile's first query
+    long long* out_ids;
+};
+hipError_t bh_launch_csr_merge_rescore(const BhCsrMergeArgs& a, int kp, int nq_tile, hipStream_t stream);

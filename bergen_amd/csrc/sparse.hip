@@ -1,0 +1,371 @@
+// sparse.hip — C ABI (include/bergen_hip.h, bh_sparse_*): resident CSR index of SPLADE document vectors and exact
+// sparse search.
+//
+// Reference behaviour being replaced (naver/bergen):
+//   modules/retrieve.py:135-141    chunks saved as sparse COO tensors when 'splade' is in the model name
+//   modules/retrieve.py:84-90      every chunk loaded to HOST RAM (torch.load), re-uploaded per query chunk (:153)
+//                                                                                    -> one CSR index resident in HBM
+//   models/retrievers/splade.py:55-56   torch.sparse.mm(q.to_sparse(), d_chunk.t()).to_dense()   \
+//   modules/retrieve.py:157,169-177     torch.topk per chunk, host cat/topk/gather               /  -> csr_topk.hip
+//   modules/retrieve.py:165-166    IOError when rows are missing                     -> BH_EINCOMPLETE
+// There is no CPU fallback: every entry point that computes needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "bh_host.h"
+#include "bh_kernels.h"
+
+struct bh_sparse_index {
+    int device = 0;
+    int n_cu = 256;
+    int64_t n_rows = 0;
+    int vocab = 0;
+    int64_t rows_have = 0;
+    int64_t nnz = 0;
+    bool finalized = false;
+    hipStream_t stream = nullptr;
+    BhDevBuf<unsigned> entries;
+    BhDevBuf<long long> row_ptr;
+    BhDevBuf<bh_u64> cand, partial;
+    BhDevBuf<unsigned> gthr, bitmap;
+    BhDevBuf<unsigned short> prefix;
+    BhDevBuf<_Float16> W, qdense;
+    BhDevBuf<unsigned char> outbuf;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bh_counters counters{};
+};
+
+namespace {
+
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kTileQ = 64;
+
+int grow_entries(bh_sparse_index* ix, size_t need) {
+    if (need <= ix->entries.cap) return BH_OK;
+    size_t cap = std::max<size_t>(need, ix->entries.cap * 2);
+    cap = std::max<size_t>(cap, 1 << 20);
+    unsigned* np = nullptr;
+    BH_HIP_TRY(hipMalloc((void**)&np, cap * sizeof(unsigned)));
+    if (ix->nnz > 0) {
+        hipError_t e = hipMemcpyAsync(np, ix->entries.p, (size_t)ix->nnz * sizeof(unsigned), hipMemcpyDeviceToDevice,
+                                      ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(np);
+            return bh_fail(BH_EHIP, "growing the entry buffer: %s", hipGetErrorString(e));
+        }
+    }
+    if (ix->entries.p) (void)hipFree(ix->entries.p);
+    ix->entries.p = np;
+    ix->entries.cap = cap;
+    return BH_OK;
+}
+
+inline unsigned short f32_to_f16_bits(float f) {
+    const _Float16 h = (_Float16)f;  // round-to-nearest-even, like torch .half()
+    unsigned short b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+inline float f16_bits_to_f32(unsigned short b) {
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+int pick_kp_sparse(int k) {
+    if (k <= 56) return 64;
+    if (k <= 120) return 128;
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bh_sparse_create(bh_sparse_index** out, int64_t n_rows, int32_t vocab) {
+    if (!out) return bh_fail(BH_EINVAL, "null out");
+    *out = nullptr;
+    if (n_rows < 0 || n_rows >= 0xffffffffll) return bh_fail(BH_EINVAL, "n_rows %lld out of range", (long long)n_rows);
+    if (vocab <= 0 || vocab > 65536) return bh_fail(BH_EUNSUPPORTED, "vocab %d unsupported (1..65536: term ids are 16-bit)", vocab);
+    int dev = 0;
+    BH_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    BH_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bh_fail(BH_EUNSUPPORTED, "device %d is %s; gfx950 required", dev, prop.gcnArchName);
+    bh_sparse_index* ix = new bh_sparse_index();
+    ix->device = dev;
+    ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ix->n_rows = n_rows;
+    ix->vocab = vocab;
+    hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ix->ev[i]);
+    int rc = e == hipSuccess ? ix->row_ptr.ensure((size_t)n_rows + 1) : bh_fail(BH_EHIP, "stream/event: %s", hipGetErrorString(e));
+    if (rc == BH_OK) {
+        const long long zero = 0;
+        e = hipMemcpy(ix->row_ptr.p, &zero, sizeof zero, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = bh_fail(BH_EHIP, "row_ptr init: %s", hipGetErrorString(e));
+    }
+    if (rc != BH_OK) {
+        bh_sparse_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return BH_OK;
+}
+
+void bh_sparse_destroy(bh_sparse_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    ix->entries.release();
+    ix->row_ptr.release();
+    ix->cand.release();
+    ix->partial.release();
+    ix->gthr.release();
+    ix->bitmap.release();
+    ix->prefix.release();
+    ix->W.release();
+    ix->qdense.release();
+    ix->outbuf.release();
+    for (auto& e : ix->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+int64_t bh_sparse_rows_uploaded(const bh_sparse_index* ix) { return ix ? ix->rows_have : 0; }
+int64_t bh_sparse_nnz(const bh_sparse_index* ix) { return ix ? ix->nnz : 0; }
+
+int bh_sparse_upload_csr(bh_sparse_index* ix, int64_t row0, int64_t n, const int64_t* indptr, const int32_t* terms,
+                         const void* values, int32_t val_dtype) {
+    if (!ix) return bh_fail(BH_EINVAL, "null index");
+    if (ix->finalized) return bh_fail(BH_EINVAL, "index already finalized");
+    if (n < 0 || row0 != ix->rows_have)
+        return bh_fail(BH_EINVAL, "rows must be appended in order: expected row0=%lld, got %lld", (long long)ix->rows_have,
+                       (long long)row0);
+    if (row0 + n > ix->n_rows)
+        return bh_fail(BH_EINVAL, "rows [%lld, %lld) outside the index (n_rows=%lld)", (long long)row0, (long long)(row0 + n),
+                       (long long)ix->n_rows);
+    if (val_dtype != BH_F16 && val_dtype != BH_F32) return bh_fail(BH_EINVAL, "bad val_dtype %d", val_dtype);
+    if (n == 0) return BH_OK;
+    if (!indptr || indptr[0] != 0) return bh_fail(BH_EINVAL, "indptr must start at 0");
+    const int64_t nnz_in = indptr[n];
+    if (nnz_in < 0 || (nnz_in > 0 && (!terms || !values))) return bh_fail(BH_EINVAL, "null terms / values");
+    BH_HIP_TRY(hipSetDevice(ix->device));
+    // pack (term, fp16 weight), drop explicit zeros (to_sparse() stores none), sort each row by term id
+    std::vector<unsigned> packed;
+    packed.reserve((size_t)nnz_in);
+    std::vector<long long> rp((size_t)n);
+    const unsigned short* v16 = static_cast<const unsigned short*>(values);
+    const float* v32 = static_cast<const float*>(values);
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t b = indptr[r], e = indptr[r + 1];
+        if (e < b || e > nnz_in) return bh_fail(BH_EINVAL, "indptr not monotone at row %lld", (long long)(row0 + r));
+        const size_t start = packed.size();
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t t = terms[i];
+            if (t < 0 || t >= ix->vocab) return bh_fail(BH_EINVAL, "term id %d out of range at row %lld", t, (long long)(row0 + r));
+            const unsigned short hb = val_dtype == BH_F16 ? v16[i] : f32_to_f16_bits(v32[i]);
+            if ((hb & 0x7fffu) == 0) continue;  // +-0
+            packed.push_back((unsigned)t | ((unsigned)hb << 16));
+        }
+        std::sort(packed.begin() + start, packed.end(), [](unsigned x, unsigned y) { return (x & 0xffffu) < (y & 0xffffu); });
+        for (size_t i = start + 1; i < packed.size(); ++i)
+            if ((packed[i] & 0xffffu) == (packed[i - 1] & 0xffffu))
+                return bh_fail(BH_EINVAL, "duplicate term %u in row %lld (coalesce the tensor first)", packed[i] & 0xffffu,
+                               (long long)(row0 + r));
+        rp[(size_t)r] = ix->nnz + (long long)packed.size();
+    }
+    int rc = grow_entries(ix, (size_t)ix->nnz + packed.size());
+    if (rc) return rc;
+    if (!packed.empty())
+        BH_HIP_TRY(hipMemcpyAsync(ix->entries.p + ix->nnz, packed.data(), packed.size() * sizeof(unsigned),
+                                  hipMemcpyHostToDevice, ix->stream));
+    BH_HIP_TRY(hipMemcpyAsync(ix->row_ptr.p + row0 + 1, rp.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice,
+                              ix->stream));
+    BH_HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->nnz += (int64_t)packed.size();
+    ix->rows_have += n;
+    return BH_OK;
+}
+
+int bh_sparse_finalize(bh_sparse_index* ix) {
+    if (!ix) return bh_fail(BH_EINVAL, "null index");
+    if (ix->rows_have != ix->n_rows)
+        return bh_fail(BH_EINCOMPLETE, "!!! Index is not complete. Please re-index. Missing %lld documents in the index. !!!",
+                       (long long)(ix->n_rows - ix->rows_have));
+    ix->finalized = true;
+    return BH_OK;
+}
+
+int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                     float* out_scores, int64_t* out_ids) {
+    if (!ix) return bh_fail(BH_EINVAL, "null index");
+    if (!ix->finalized) {
+        if (ix->rows_have != ix->n_rows)
+            return bh_fail(BH_EINCOMPLETE,
+                           "!!! Index is not complete. Please re-index. Missing %lld documents in the index. !!!",
+                           (long long)(ix->n_rows - ix->rows_have));
+        return bh_fail(BH_EINVAL, "index not finalized");
+    }
+    if (nq < 0 || k <= 0) return bh_fail(BH_EINVAL, "nq=%d k=%d", nq, k);
+    if (q_dtype != BH_F16 && q_dtype != BH_F32) return bh_fail(BH_EINVAL, "bad q_dtype %d", q_dtype);
+    const int kp = pick_kp_sparse(k);
+    if (kp < 0) return bh_fail(BH_EUNSUPPORTED, "k=%d unsupported for sparse search (max 120)", k);
+    if (nq == 0) return BH_OK;
+    if (!q_host || !out_scores || !out_ids) return bh_fail(BH_EINVAL, "null buffer");
+    BH_HIP_TRY(hipSetDevice(ix->device));
+    const int V = ix->vocab, n_words = (V + 31) / 32;
+    const int off_prefix = n_words * 4;
+    const int off_w = (off_prefix + n_words * 2 + 15) / 16 * 16;
+    const int max_slots = (kLdsBytes - 256 - off_w) / 128 - 1;
+    if (max_slots < 8) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile weights", V);
+    const int grid = ix->n_cu;
+    int rc;
+    if ((rc = ix->cand.ensure((size_t)grid * 16 * 64 * 2 * kp))) return rc;
+    if ((rc = ix->partial.ensure((size_t)grid * 64 * kp))) return rc;
+    if ((rc = ix->gthr.ensure(64))) return rc;
+    if ((rc = ix->bitmap.ensure((size_t)n_words))) return rc;
+    if ((rc = ix->prefix.ensure((size_t)n_words))) return rc;
+    if ((rc = ix->W.ensure((size_t)(max_slots + 1) * 64))) return rc;
+    if ((rc = ix->qdense.ensure((size_t)kTileQ * V))) return rc;
+    const size_t out_bytes = (size_t)nq * k * (sizeof(float) + sizeof(long long));
+    if ((rc = ix->outbuf.ensure(out_bytes + 16))) return rc;
+    float* d_scores = reinterpret_cast<float*>(ix->outbuf.p);
+    long long* d_ids = reinterpret_cast<long long*>(ix->outbuf.p + (((size_t)nq * k * sizeof(float) + 15) / 16 * 16));
+    if ((size_t)((unsigned char*)d_ids - ix->outbuf.p) + (size_t)nq * k * 8 > ix->outbuf.cap) {
+        if ((rc = ix->outbuf.ensure(out_bytes + 64))) return rc;
+        d_scores = reinterpret_cast<float*>(ix->outbuf.p);
+        d_ids = reinterpret_cast<long long*>(ix->outbuf.p + (((size_t)nq * k * sizeof(float) + 15) / 16 * 16));
+    }
+    hipStream_t st = ix->stream;
+    const unsigned short* q16 = static_cast<const unsigned short*>(q_host);
+    const float* q32 = static_cast<const float*>(q_host);
+    auto qbits = [&](int q, int t) -> unsigned short {
+        return q_dtype == BH_F16 ? q16[(size_t)q * V + t] : f32_to_f16_bits(q32[(size_t)q * V + t]);
+    };
+
+    std::vector<unsigned> bm((size_t)n_words);
+    std::vector<unsigned short> pf((size_t)n_words);
+    std::vector<unsigned short> Wh((size_t)(max_slots + 1) * 64);
+    std::vector<unsigned short> qd((size_t)kTileQ * V);
+    std::vector<unsigned> gt(64, 0x007fffffu);
+    bh_counters& c = ix->counters;
+    c = bh_counters{};
+    c.n_rows = ix->n_rows;
+    c.dim = V;
+    c.dim_padded = V;
+    c.n_workgroups = grid;
+    c.k_padded = kp;
+    c.query_tile = kTileQ;
+    double scan_ms = 0, merge_ms = 0, bytes = 0;
+    int n_pass = 0;
+    BH_HIP_TRY(hipEventRecord(ix->ev[0], st));
+    int q0 = 0;
+    while (q0 < nq) {
+        // ---- tile: as many queries as fit (<= 64 queries, <= max_slots distinct terms)
+        std::fill(bm.begin(), bm.end(), 0u);
+        int nt = 0, n_slots = 0;
+        while (q0 + nt < nq && nt < kTileQ) {
+            int add = 0;
+            const int q = q0 + nt;
+            for (int t = 0; t < V; ++t)
+                if ((qbits(q, t) & 0x7fffu) && !(bm[t >> 5] >> (t & 31) & 1u)) ++add;
+            if (n_slots + add > max_slots) {
+                if (nt == 0)
+                    return bh_fail(BH_EUNSUPPORTED, "query %d has %d non-zero terms; at most %d fit the LDS tile", q, add, max_slots);
+                break;
+            }
+            for (int t = 0; t < V; ++t)
+                if (qbits(q, t) & 0x7fffu) bm[t >> 5] |= 1u << (t & 31);
+            n_slots += add;
+            ++nt;
+        }
+        int run = 0;
+        for (int w = 0; w < n_words; ++w) {
+            pf[w] = (unsigned short)run;
+            run += __builtin_popcount(bm[w]);
+        }
+        std::fill(Wh.begin(), Wh.begin() + (size_t)(n_slots + 1) * 64, (unsigned short)0);
+        std::fill(qd.begin(), qd.begin() + (size_t)nt * V, (unsigned short)0);
+        for (int j = 0; j < nt; ++j)
+            for (int t = 0; t < V; ++t) {
+                const unsigned short b = qbits(q0 + j, t);
+                if (!(b & 0x7fffu)) continue;
+                const int slot = pf[t >> 5] + __builtin_popcount(bm[t >> 5] & ((1u << (t & 31)) - 1u));
+                Wh[(size_t)slot * 64 + j] = b;
+                qd[(size_t)j * V + t] = b;
+            }
+        BH_HIP_TRY(hipMemcpyAsync(ix->bitmap.p, bm.data(), (size_t)n_words * 4, hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(hipMemcpyAsync(ix->prefix.p, pf.data(), (size_t)n_words * 2, hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(hipMemcpyAsync(ix->W.p, Wh.data(), (size_t)(n_slots + 1) * 128, hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(hipMemcpyAsync(ix->qdense.p, qd.data(), (size_t)nt * V * 2, hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(hipMemcpyAsync(ix->gthr.p, gt.data(), 64 * 4, hipMemcpyHostToDevice, st));
+        BhCsrScanArgs sa{};
+        sa.entries = ix->entries.p;
+        sa.row_ptr = ix->row_ptr.p;
+        sa.n_rows = ix->n_rows;
+        sa.bitmap = ix->bitmap.p;
+        sa.prefix = ix->prefix.p;
+        sa.W = ix->W.p;
+        sa.n_words = n_words;
+        sa.n_slots = n_slots;
+        sa.off_prefix = off_prefix;
+        sa.off_w = off_w;
+        sa.off_thr = off_w + (n_slots + 1) * 128;
+        sa.cand = ix->cand.p;
+        sa.partial = ix->partial.p;
+        sa.gthr = ix->gthr.p;
+        const size_t smem = (size_t)sa.off_thr + 256;
+        // (the host copies above are staged synchronously by the runtime: pageable memory)
+        BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+        BH_HIP_TRY(bh_launch_csr_scan(sa, kp, grid, smem, st));
+        BH_HIP_TRY(hipEventRecord(ix->ev[2], st));
+        BhCsrMergeArgs ma{};
+        ma.partial = ix->partial.p;
+        ma.n_lists = grid;
+        ma.entries = ix->entries.p;
+        ma.row_ptr = ix->row_ptr.p;
+        ma.n_rows = ix->n_rows;
+        ma.q_dense = ix->qdense.p;
+        ma.vocab = V;
+        ma.k = k;
+        ma.id_offset = id_offset;
+        ma.out_scores = d_scores + (size_t)q0 * k;
+        ma.out_ids = d_ids + (size_t)q0 * k;
+        BH_HIP_TRY(bh_launch_csr_merge_rescore(ma, kp, nt, st));
+        BH_HIP_TRY(hipEventRecord(ix->ev[3], st));
+        BH_HIP_TRY(hipStreamSynchronize(st));  // the host tables are rebuilt for the next tile
+        float ms = 0;
+        BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]));
+        scan_ms += ms;
+        BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]));
+        merge_ms += ms;
+        // nnz*(2+2) + (N+1)*8 per query-tile pass (+ the tile's own tables and results)
+        bytes += (double)ix->nnz * 4.0 + (double)(ix->n_rows + 1) * 8.0 + (double)nt * k * 12.0;
+        ++n_pass;
+        q0 += nt;
+    }
+    BH_HIP_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    BH_HIP_TRY(hipMemcpyAsync(out_ids, d_ids, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
+    BH_HIP_TRY(hipStreamSynchronize(st));
+    c.n_passes = n_pass;
+    c.scan_ms = scan_ms;
+    c.merge_ms = merge_ms;
+    c.total_ms = scan_ms + merge_ms;
+    c.algorithmic_bytes = bytes;
+    return BH_OK;
+}
+
+int bh_sparse_counters(const bh_sparse_index* ix, bh_counters* out) {
+    if (!ix || !out) return bh_fail(BH_EINVAL, "null argument");
+    *out = ix->counters;
+    return BH_OK;
+}
+
+}  // extern "C"

@@ -29,6 +29,7 @@ from tqdm import tqdm
 from . import utils
 from .config import instantiate
 from .index import FlatIndex
+from .sparse import SparseIndex
 
 _INCOMPLETE = '!!! Index is not complete. Please re-index. Missing {} documents in the index. !!!'
 
@@ -111,7 +112,7 @@ class Retrieve:
             if i % save_every_n_batches == 0 and i != 0 or i == total_n_batches - 1:
                 chunk_save_path = self.get_chunk_path(save_path, i)
                 embs = torch.cat(embs_list)
-                if 'splade' in self.model.model_name:
+                if 'splade' in self.model.model_name or getattr(self.model, 'sparse', False):
                     embs = embs.to_sparse()
                 torch.save(embs, chunk_save_path)
                 embs_list = list()
@@ -159,11 +160,34 @@ class Retrieve:
             for f in tqdm(files, total=len(files), desc='Load embeddings into HBM...'):
                 yield self._dense_chunk(utils.load_chunk(f))
 
-        first = self._dense_chunk(utils.load_chunk(files[0]))
+        first = utils.load_chunk(files[0])
         dim = first.shape[1]
+        sparse = bool(first.is_sparse)
         del first
-        ix = self._build_resident(chunks(), dataset_size, dim, metric)
+        if sparse:  # SPLADE chunks (retrieve.py:138-139): keep them sparse, resident CSR index
+            ix = self._build_resident_sparse((utils.load_chunk(f) for f in tqdm(files, total=len(files),
+                                                                               desc='Load sparse embeddings into HBM...')),
+                                             dataset_size, dim)
+        else:
+            ix = self._build_resident(chunks(), dataset_size, dim, metric)
         self._resident[doc_embeds_path] = (ix, signature)
+        return ix
+
+    def _build_resident_sparse(self, chunk_iter, dataset_size, vocab):
+        ix = SparseIndex(dataset_size, vocab, device=self.device)
+        num_emb = 0
+        try:
+            for emb_chunk in chunk_iter:
+                n_c = emb_chunk.shape[0]
+                if num_emb + n_c <= dataset_size:
+                    ix.upload(emb_chunk, row0=num_emb)
+                num_emb += n_c
+            if num_emb != dataset_size:  # retrieve.py:165-166
+                raise IOError(_INCOMPLETE.format(dataset_size - num_emb))
+            ix.finalize()
+        except Exception:
+            ix.close()
+            raise
         return ix
 
     # ------------------------------------------------------------------ search
@@ -178,12 +202,14 @@ class Retrieve:
             raise NotImplementedError("bm25 is out of scope of the dense backend (SURVEY §2)")
 
         query_embeds = utils.load_embeddings(query_embeds_path)
-        if query_embeds.is_sparse:
-            query_embeds = query_embeds.to_dense()
+        sparse_queries = bool(query_embeds.is_sparse)
+        if sparse_queries:
+            query_embeds = query_embeds.to_dense()  # [Q, vocab], as the reference holds it (retrieve.py:75-76)
         if hasattr(self.model, "model") and hasattr(self.model.model, "to"):
             self.model.model = self.model.model.to('cpu')  # free HBM for the index (retrieve.py:78)
 
-        index = self._resident_index(doc_embeds_path, dataset_size=len(dataset['doc']), metric=_metric_of(self.model))
+        metric = "sparse" if (sparse_queries or getattr(self.model, "sparse", False)) else _metric_of(self.model)
+        index = self._resident_index(doc_embeds_path, dataset_size=len(dataset['doc']), metric=metric)
 
         # separate query embedding in chunks (retrieve.py:81) — one fused search per chunk
         chunks = torch.split(query_embeds, self.batch_size_sim, dim=0)
@@ -226,12 +252,17 @@ class Retrieve:
         if num_emb != dataset_size:
             raise IOError(_INCOMPLETE.format(dataset_size - num_emb))
         dim = int(emb_q.shape[1])
-        ix = self._build_resident((self._dense_chunk(c) for c in doc_embeds), dataset_size, dim, _metric_of(self.model))
+        if len(doc_embeds) and doc_embeds[0].is_sparse:
+            ix = self._build_resident_sparse(iter(doc_embeds), dataset_size, dim)
+        else:
+            ix = self._build_resident((self._dense_chunk(c) for c in doc_embeds), dataset_size, dim, _metric_of(self.model))
         try:
             q = emb_q.to_dense() if emb_q.is_sparse else emb_q
             s, i = ix.search(q.detach().cpu().contiguous(), top_k_documents)
         finally:
             ix.close()
+        if return_embeddings and len(doc_embeds) and doc_embeds[0].is_sparse:
+            raise NotImplementedError("return_embeddings is not supported for sparse indexes")
         final_top_k_scores = torch.from_numpy(s)
         final_top_k_indices = torch.from_numpy(i)
         if return_embeddings:

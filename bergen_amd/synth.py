@@ -48,3 +48,53 @@ def random_batch(cfg, batch, max_len, seed, min_len=1):
     ids = ids * mask  # pad id 0
     types = (rng.integers(0, cfg["type_vocab_size"], size=(batch, T)) * mask).astype(np.int64)
     return ids, mask, types
+
+
+def random_sparse_corpus(n_docs, vocab, seed, mean_nnz=180, lo=16, hi=400, zipf_a=1.1):
+    """Synthetic SPLADE-like document vectors: nnz ~ clipped-Poisson(mean_nnz) in [lo, hi], term
+    ids Zipf(zipf_a)-distributed over the vocabulary without replacement inside a document, weights
+    log1p(exponential) rounded to fp16.  Returns CSR (indptr int64, terms int32 sorted per row, weights float16)."""
+    rng = np.random.default_rng(seed)
+    nnz = np.clip(rng.poisson(mean_nnz, size=n_docs), lo, min(hi, vocab)).astype(np.int64)
+    indptr = np.zeros(n_docs + 1, np.int64)
+    np.cumsum(nnz, out=indptr[1:])
+    p = 1.0 / np.arange(1, vocab + 1) ** zipf_a
+    perm = rng.permutation(vocab)  # which term id has which popularity rank
+    cdf = np.cumsum(p / p.sum())
+    terms = np.empty(indptr[-1], np.int32)
+    for r in range(n_docs):
+        need = int(nnz[r])
+        got = np.unique(perm[np.searchsorted(cdf, rng.random(need * 2)).clip(0, vocab - 1)])
+        while got.size < need:
+            got = np.unique(np.concatenate([got, perm[np.searchsorted(cdf, rng.random(need)).clip(0, vocab - 1)]]))
+        terms[indptr[r]:indptr[r + 1]] = np.sort(rng.choice(got, size=need, replace=False))
+    w = np.log1p(rng.exponential(1.0, size=indptr[-1])).astype(np.float16)
+    w[w == 0] = np.float16(0.01)
+    return indptr, terms, w
+
+
+def csr_to_dense(indptr, terms, weights, vocab, dtype=np.float32):
+    n = len(indptr) - 1
+    out = np.zeros((n, vocab), dtype)
+    for r in range(n):
+        out[r, terms[indptr[r]:indptr[r + 1]]] = weights[indptr[r]:indptr[r + 1]]
+    return out
+
+
+def random_sparse_corpus_fast(n_docs, vocab, seed, mean_nnz=180, lo=16, hi=400, zipf_a=1.1):
+    """Vectorised variant of random_sparse_corpus for benchmark-sized corpora: terms are drawn WITH replacement and
+    duplicates inside a document are dropped (so documents come out slightly shorter than drawn)."""
+    rng = np.random.default_rng(seed)
+    nnz = np.clip(rng.poisson(mean_nnz, size=n_docs), lo, min(hi, vocab)).astype(np.int64)
+    p = 1.0 / np.arange(1, vocab + 1) ** zipf_a
+    cdf = np.cumsum(p / p.sum())
+    perm = rng.permutation(vocab)
+    doc = np.repeat(np.arange(n_docs, dtype=np.int64), nnz)
+    term = perm[np.searchsorted(cdf, rng.random(doc.size)).clip(0, vocab - 1)].astype(np.int64)
+    key = np.unique(doc * 65536 + term)  # sorted by (doc, term), duplicates removed
+    doc, term = key >> 16, (key & 65535).astype(np.int32)
+    indptr = np.zeros(n_docs + 1, np.int64)
+    np.cumsum(np.bincount(doc, minlength=n_docs), out=indptr[1:])
+    w = np.log1p(rng.exponential(1.0, size=term.size)).astype(np.float16)
+    w[w == 0] = np.float16(0.01)
+    return indptr, term, w

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_VERSION 110 /* 0.1.1: + bi-encoder forward pass */
+#define BH_VERSION 120 /* 0.1.2: + bi-encoder forward pass, sparse (SPLADE) index */
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -196,6 +196,35 @@ int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float 
                     const void* beta);
 /* 0 / 1 = direction of v_permlane32_swap found on the device (diagnostic), -1 on failure. */
 int bh_gemm_permlane_mode(void);
+
+/* Sparse (SPLADE) index: resident CSR corpus + exact sparse search ------------------------- */
+
+typedef struct bh_sparse_index bh_sparse_index;
+
+/* n_rows documents over a vocabulary of `vocab` terms (<= 65536), weights stored as fp16 (the
+ * reference stores fp16 sparse COO chunks, modules/retrieve.py:138-139).  Replaces the host
+ * list of sparse chunk tensors of reference modules/retrieve.py:84-90. */
+int bh_sparse_create(bh_sparse_index** out, int64_t n_rows, int32_t vocab);
+/* Append rows [row0, row0+n) given as a HOST CSR block: indptr[n+1] (starting at 0), term ids,
+ * weights (fp16 or fp32; fp32 is rounded like .half()).  Rows must arrive in order
+ * (row0 == rows uploaded so far); explicit zeros are dropped, rows are sorted by term id. */
+int bh_sparse_upload_csr(bh_sparse_index* ix, int64_t row0, int64_t n, const int64_t* indptr,
+                         const int32_t* terms, const void* values, int32_t val_dtype);
+/* BH_EINCOMPLETE if fewer than n_rows rows were uploaded (reference IOError, retrieve.py:165-166). */
+int bh_sparse_finalize(bh_sparse_index* ix);
+int64_t bh_sparse_rows_uploaded(const bh_sparse_index* ix);
+int64_t bh_sparse_nnz(const bh_sparse_index* ix);
+/* Exact search with DENSE host queries [nq, vocab] (what the reference holds after
+ * `load_embeddings(...).to_dense()`, retrieve.py:75-76): for each query the k documents with
+ * the largest sparse dot product, canonical order (score desc, row asc).  Canonical score =
+ * fp32(RNE) of the fp64 sum over the document's terms, in increasing term id, of
+ * q[term] * weight (both as fp16 values).  k <= 120.  Replaces Splade.similarity_fn
+ * (models/retrievers/splade.py:55-56) + torch.topk + host merge (retrieve.py:146-185). */
+int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k,
+                     int64_t id_offset, float* out_scores, int64_t* out_ids);
+/* Counters of the last bh_sparse_search (dim = vocab; algorithmic_bytes = passes * (nnz*4 + (N+1)*8)). */
+int bh_sparse_counters(const bh_sparse_index* ix, bh_counters* out);
+void bh_sparse_destroy(bh_sparse_index* ix);
 
 #ifdef __cplusplus
 }

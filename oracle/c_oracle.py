@@ -18,8 +18,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle.so")
-        src = os.path.join(_HERE, "flat_ip_oracle.c")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        srcs = [os.path.join(_HERE, f) for f in ("flat_ip_oracle.c", "sparse_oracle.c")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             build()
         _LIB = ctypes.CDLL(path)
         _LIB.oracle_ref_chunked_search.restype = ctypes.c_int
@@ -108,3 +108,25 @@ def floats_to_halfs(a):
     out = np.empty(a.shape, np.uint16)
     lib().oracle_floats_to_halfs(_p(a), _p(out), ctypes.c_int64(a.size))
     return out.view(np.float16)
+
+
+def sparse_canonical_search(indptr, terms, weights, vocab, q, k, id_offset=0):
+    """bh_sparse_search's contract on the CPU (sparse_oracle.c).  CSR documents (indptr int64 [n+1], terms int32,
+    weights fp16 / fp32->fp16), dense queries q [nq, vocab].  Rows are sorted by term id here if they are not."""
+    indptr = np.ascontiguousarray(indptr, np.int64)
+    terms = np.ascontiguousarray(terms, np.int32).copy()
+    wb = _as_half_bits(np.asarray(weights)).copy()
+    for r in range(len(indptr) - 1):
+        b, e = indptr[r], indptr[r + 1]
+        o = np.argsort(terms[b:e], kind="stable")
+        terms[b:e] = terms[b:e][o]
+        wb[b:e] = wb[b:e][o]
+    qb = _as_half_bits(q)
+    nq = qb.shape[0]
+    assert qb.shape[1] == vocab
+    out_s = np.empty((nq, k), np.float32)
+    out_i = np.empty((nq, k), np.int64)
+    lib().oracle_sparse_canonical_search(_p(indptr), _p(terms), _p(wb), ctypes.c_int64(len(indptr) - 1),
+                                         ctypes.c_int32(vocab), _p(qb), ctypes.c_int64(nq), ctypes.c_int(k),
+                                         ctypes.c_int64(id_offset), _p(out_s), _p(out_i))
+    return out_s, out_i

@@ -70,7 +70,8 @@ def load():
     ref_utils = importlib.import_module("utils")
     ref_retrieve = importlib.import_module("modules.retrieve")
     ref_dense = importlib.import_module("models.retrievers.dense")
-    _loaded = types.SimpleNamespace(utils=ref_utils, retrieve=ref_retrieve, dense=ref_dense,
+    ref_splade = importlib.import_module("models.retrievers.splade")
+    _loaded = types.SimpleNamespace(utils=ref_utils, retrieve=ref_retrieve, dense=ref_dense, splade=ref_splade,
                                     Retrieve=ref_retrieve.Retrieve)
     return _loaded
 

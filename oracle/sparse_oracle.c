@@ -1,0 +1,63 @@
+/*
+ * sparse_oracle.c — CPU restatement of BERGEN's exact SPLADE (sparse) search.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing in the product path (bergen_amd/) may call into this file (see oracle/__init__.py).
+ *
+ * What it restates (naver/bergen @ 2026-01-30):
+ *   - Splade.similarity_fn      models/retrievers/splade.py:55-56
+ *         torch.sparse.mm(query_embds.to_sparse(), doc_embds.t()).to_dense()  = sum over the vocabulary of
+ *         q[v] * d[v] for every (query, document) pair;
+ *   - Retrieve.load_collection_and_retrieve   modules/retrieve.py:146-185: per-chunk top-k, +offset, host merge
+ *         (the merge is order-independent under the canonical total order, so one global top-k is the same).
+ * torch.sparse.mm / torch.topk are third-party (unpinned in the reference) and torch.topk's tie order is
+ * arbitrary; this is the contract of include/bergen_hip.h bh_sparse_search:
+ *   score = fp32(RNE) of the fp64 sum, over the document's stored entries in increasing term id, of
+ *           q[term] * weight with both factors fp16 values (products exact in fp64);
+ *   order = (score descending, row ascending).
+ * Parity status: pinned against the reference's own Splade.similarity_fn + Retrieve code run in this container
+ * (oracle/make_golden_sparse.py -> tests/golden/sparse_small.npz).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+float oracle_half_to_float(uint16_t h); /* flat_ip_oracle.c */
+
+typedef struct {
+    float s;
+    int64_t row;
+} hit_t;
+
+static int before(float sa, int64_t ra, float sb, int64_t rb) { return sa > sb || (sa == sb && ra < rb); }
+
+/* indptr[n+1], terms[nnz] (sorted by term id inside a row), wbits[nnz] fp16 bit patterns; q: [nq][vocab] fp16 bits */
+void oracle_sparse_canonical_search(const int64_t* indptr, const int32_t* terms, const uint16_t* wbits, int64_t n,
+                                    int32_t vocab, const uint16_t* q, int64_t nq, int k, int64_t id_offset,
+                                    float* out_scores, int64_t* out_ids) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        hit_t* best = (hit_t*)malloc((size_t)k * sizeof(hit_t));
+        int m = 0;
+        const uint16_t* qv = q + (size_t)qi * vocab;
+        for (int64_t r = 0; r < n; ++r) {
+            double s = 0.0;
+            for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e)
+                s += (double)oracle_half_to_float(qv[terms[e]]) * (double)oracle_half_to_float(wbits[e]);
+            const float sf = (float)s;
+            if (m == k && !before(sf, r, best[k - 1].s, best[k - 1].row)) continue;
+            int pos = m < k ? m : k - 1;
+            while (pos > 0 && before(sf, r, best[pos - 1].s, best[pos - 1].row)) {
+                best[pos] = best[pos - 1];
+                --pos;
+            }
+            best[pos].s = sf;
+            best[pos].row = r;
+            if (m < k) ++m;
+        }
+        for (int j = 0; j < k; ++j) {
+            out_scores[(size_t)qi * k + j] = j < m ? best[j].s : -INFINITY;
+            out_ids[(size_t)qi * k + j] = j < m ? id_offset + best[j].row : -1;
+        }
+        free(best);
+    }
+}

@@ -1,0 +1,158 @@
+"""GPU parity tests of the sparse (SPLADE) path: the CSR scan / merge-rescore kernels through the C ABI against the
+canonical oracle (oracle/sparse_oracle.c) and the golden fixture produced by the reference's own code.
+Integer / index work and canonical scores: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from bergen_amd import synth
+from oracle import c_oracle
+from oracle.compare import assert_bit_exact
+
+from test_sparse_oracle import load_sparse_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(amd, indptr, terms, w, V, pieces=1):
+    n = len(indptr) - 1
+    ix = amd.SparseIndex(n, V, device=0)
+    cuts = np.linspace(0, n, pieces + 1).astype(int)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ix.upload((indptr[a:b + 1] - indptr[a], terms[indptr[a]:indptr[b]], w[indptr[a]:indptr[b]]))
+    return ix.finalize()
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import bergen_amd
+    return bergen_amd
+
+
+def test_golden_fixture(amd):
+    z, V, q = load_sparse_golden()
+    ix = _index(amd, z["d_indptr"], z["d_terms"], z["d_weights"], V, pieces=3)
+    s, i = ix.search(q, int(z["k"]))
+    assert_bit_exact(s, i, z["canonical_scores"], z["canonical_ids"], "HIP sparse vs canonical fixture")
+    assert np.allclose(s, z["ref_scores"], rtol=2e-6, atol=1e-6)  # the reference's own torch.sparse.mm scores
+    c = ix.counters()
+    assert c["n_passes"] == 1 and c["scan_ms"] > 0 and c["algorithmic_bytes"] >= ix.nnz * 4
+    ix.close()
+
+
+@pytest.mark.parametrize("n,V,nq,k,qnnz", [(5000, 30522, 70, 50, 24), (300, 1000, 5, 10, 6), (20000, 30522, 130, 100, 40),
+                                           (40, 65536, 3, 56, 10), (3000, 5000, 64, 120, 200)])
+def test_random_matches_oracle(amd, n, V, nq, k, qnnz):
+    dp, dt, dw = synth.random_sparse_corpus(n, V, seed=n + k, mean_nnz=min(120, V // 8), lo=0, hi=min(300, V // 3))
+    qp, qt, qw = synth.random_sparse_corpus(nq, V, seed=n + 7, mean_nnz=qnnz, lo=1, hi=min(4 * qnnz, V // 3))
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    ix = _index(amd, dp, dt, dw, V, pieces=2)
+    s, i = ix.search(q, k)
+    want_s, want_i = c_oracle.sparse_canonical_search(dp, dt, dw, V, q, k)
+    assert_bit_exact(s, i, want_s, want_i, f"sparse n={n} V={V} nq={nq} k={k}")
+    ix.close()
+
+
+def test_ties_empty_rows_no_overlap_and_fp32_sources(amd):
+    V = 2000
+    dp, dt, dw = synth.random_sparse_corpus(1500, V, seed=3, mean_nnz=40, lo=0, hi=90)
+    dense = synth.csr_to_dense(dp, dt, dw, V)
+    dense[700] = dense[20]        # exact duplicates: canonical order must pick the smaller row first
+    dense[701] = dense[20]
+    dense[100:140] = 0            # empty documents (score 0 for every query)
+    q = np.zeros((4, V), np.float32)
+    q[0, dt[dp[20]:dp[21]][:5]] = 1.25
+    q[1, :] = 0                    # a query with no terms: all scores 0 -> rows 0..k-1
+    q[2, dt[dp[5]:dp[6]][:3]] = 0.333333  # fp32 query values are rounded like .half()
+    q[3, 7] = 2.0
+    ix = amd.SparseIndex(1500, V, device=0)
+    ix.upload(torch.from_numpy(dense[:800]).to_sparse())          # torch sparse COO chunk, fp32 values
+    ix.upload(dense[800:].astype(np.float16))                     # dense numpy block
+    ix.finalize()
+    s, i = ix.search(q, 30)
+    p2 = np.zeros(1501, np.int64)
+    nz = dense != 0
+    np.cumsum(nz.sum(1), out=p2[1:])
+    r, c = np.nonzero(nz)
+    want_s, want_i = c_oracle.sparse_canonical_search(p2, c.astype(np.int32), dense[r, c].astype(np.float16), V,
+                                                      q.astype(np.float16), 30)
+    assert_bit_exact(s, i, want_s, want_i, "ties / empties")
+    assert np.array_equal(i[1], np.arange(30)) and np.all(s[1] == 0)
+    j = list(i[0]).index(20)
+    assert list(i[0][j:j + 3]) == [20, 700, 701]
+    ix.close()
+
+
+def test_many_query_terms_split_the_tile_and_id_offset(amd):
+    V = 30522
+    dp, dt, dw = synth.random_sparse_corpus(4000, V, seed=9)
+    qp, qt, qw = synth.random_sparse_corpus(64, V, seed=10, mean_nnz=300, lo=200, hi=400)  # > LDS slots for 64 queries
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    ix = _index(amd, dp, dt, dw, V)
+    s, i = ix.search(q, 20, id_offset=1_000_000)
+    assert ix.counters()["n_passes"] > 1
+    want_s, want_i = c_oracle.sparse_canonical_search(dp, dt, dw, V, q, 20, id_offset=1_000_000)
+    assert_bit_exact(s, i, want_s, want_i, "tile split")
+    ix.close()
+
+
+def test_error_behaviour(amd):
+    ix = amd.SparseIndex(10, 100, device=0)
+    blk = np.zeros((4, 100), np.float32)
+    blk[:, 3] = 1
+    ix.upload(blk)
+    with pytest.raises(ValueError):
+        ix.upload(blk, row0=7)                      # rows must be appended in order
+    with pytest.raises(IOError) as e:               # reference message (retrieve.py:166)
+        ix.search(np.zeros((1, 100), np.float16), 5)
+    assert "Index is not complete" in str(e.value) and "Missing 6 documents" in str(e.value)
+    with pytest.raises(IOError):
+        ix.finalize()
+    ix.upload(blk)
+    ix.upload(blk[:2])
+    ix.finalize()
+    with pytest.raises(Exception):
+        ix.search(np.zeros((1, 100), np.float16), 121)   # k > 120 unsupported
+    s, i = ix.search(np.ones((1, 100), np.float16), 20)  # k > n_rows: tail is (-inf, -1)
+    assert np.array_equal(i[0, :10], np.arange(10)) and np.all(i[0, 10:] == -1) and np.all(np.isinf(s[0, 10:]))
+    with pytest.raises(ValueError):
+        amd.SparseIndex(4, 100, device=0).upload((np.array([0, 1]), np.array([100]), np.array([1.0], np.float32)))
+    ix.close()
+
+
+def test_retrieve_stage_on_sparse_chunks(amd, tmp_path):
+    """bergen_amd.Retrieve over an index folder of sparse COO chunks (as the reference writes them for SPLADE):
+    resident CSR index + fused sparse search, same return dict."""
+    V, N, Q, k = 3000, 700, 9, 15
+    dp, dt, dw = synth.random_sparse_corpus(N, V, seed=21, mean_nnz=40, lo=1, hi=90)
+    qp, qt, qw = synth.random_sparse_corpus(Q, V, seed=22, mean_nnz=10, lo=1, hi=30)
+    d_dense = torch.from_numpy(synth.csr_to_dense(dp, dt, dw, V)).half()
+    q_dense = torch.from_numpy(synth.csr_to_dense(qp, qt, qw, V)).half()
+    dpath, qpath = tmp_path / "d", tmp_path / "q"
+    os.makedirs(dpath)
+    os.makedirs(qpath)
+    torch.save(d_dense[:300].to_sparse(), dpath / "embedding_chunk_4.pt")
+    torch.save(d_dense[300:].to_sparse(), dpath / "embedding_chunk_9.pt")
+    torch.save(q_dense.to_sparse(), qpath / "embedding_chunk_0.pt")
+
+    class Col:
+        def __init__(self, ids):
+            self.ids = ids
+
+        def __len__(self):
+            return len(self.ids)
+
+        def __getitem__(self, key):
+            return self.ids if key == "id" else None
+
+    model = type("M", (), {"model_name": "naver/splade-fake", "sparse": True, "model": torch.nn.Identity()})()
+    r = amd.Retrieve(init_args=model, batch_size=64, batch_size_sim=4)
+    ds = {"doc": Col([f"d{i}" for i in range(N)]), "query": Col([f"q{i}" for i in range(Q)])}
+    out = r.retrieve(ds, str(qpath), str(dpath), k)
+    want_s, want_i = c_oracle.sparse_canonical_search(dp, dt, dw, V, q_dense.numpy(), k)
+    assert np.array_equal(out["score"].numpy().view(np.uint32), want_s.view(np.uint32))
+    assert out["doc_id"] == [[f"d{j}" for j in row] for row in want_i]
+    assert out["q_id"] == [f"q{i}" for i in range(Q)]
+    r.close()
