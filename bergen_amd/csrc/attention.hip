@@ -15,8 +15,9 @@
 //                          lane l owns query l&31 and 16 of the 32 key scores -> the softmax reductions are
 //                          in-lane plus ONE exchange between the two half-lanes of a query.
 //   online softmax         fp32, v_exp_f32, scale 1/8 folded into the exponent.
-//   O^T += V^T . P         A = V^T rows (i = head dim) from the TRANSPOSED value matrix VT[d][tokens] (written that
-//                          way by the QKV GEMM), two 8-byte LDS reads per fragment, B = P (the lane's own
+//   O^T += V^T . P         A = V^T rows (i = head dim) from the TRANSPOSED value matrix (written that way by the V
+//                          GEMM, blocked by 64 tokens: [tokens/64][d][64], so that a head's slice of a token
+//                          block is 8 KiB contiguous), two 8-byte LDS reads per fragment, B = P (the lane's own
 //                          probabilities, already in operand layout).
 // Head dim is 64 (bert-base 768/12, bert-large 1024/16, e5 / contriever / bge / RetroMAE alike).
 // Roofline: MFMA (4 T^2 64 flop per head) — ~3 % of the encoder's flops at T = 128.
@@ -34,41 +35,64 @@ __device__ __forceinline__ float half_lanes_sum(float v) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(512, 4) bh_attention_kernel(BhAttnArgs a) {
+// NWV = waves per workgroup: 8 in general, 4 for sequences of at most 128 tokens (half the LDS, twice the
+// workgroups per CU, no idle waves behind the staging barrier).
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 64 * NWV;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.y, head = blockIdx.x;
+    const int s = a.seq_idx ? a.seq_idx[blockIdx.y] : (int)blockIdx.y, head = blockIdx.x;
     const int len = a.seq_len[s];
     const long long t0 = a.seq_off[s];
     const int nkb = (len + 31) >> 5;
     unsigned char* smK = smem;                // nkb pieces of 32 keys x 128 B (XOR-permuted, see gemm_f16_kernel.h)
     unsigned char* smV = smem + a.v_lds_off;  // nkb tiles of 64 dims x 32 keys (64-byte rows, 8-byte chunk XOR)
 
+    // Q fragments (operand B) of the wave's first query block: lane (query ql, half h), k-step s4 covers head dims
+    // 16 s4 + 8 h .. + 8.  Requested before the staging so that their latency overlaps it.
+    const int ql = lane & 31, h = lane >> 5;
+    auto load_q = [&](half8 (&qf)[4], int q0) {
+        int qr = q0 + ql;
+        qr = qr < len ? qr : len - 1;
+        const _Float16* qp = a.qk + (size_t)(t0 + qr) * a.ldqk + head * 64 + 8 * h;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *reinterpret_cast<const half8*>(qp + 16 * s4);
+    };
+    half8 qf[4];
+    load_q(qf, wave * 32 < len ? wave * 32 : 0);
+
     // ---- stage the sequence's K rows and V^T rows of this head into LDS, once, coalesced; all loads of a
     // batch are issued before the first LDS store so that their latencies overlap
     {
         const _Float16* kg = a.qk + (size_t)t0 * a.ldqk + a.d_model + head * 64;
-        const _Float16* vg = a.vt + (size_t)(head * 64) * a.ldvt + t0;
+        const _Float16* vg = a.vt + (size_t)(head * 64) * a.ldvt + t0;  // row-major V^T
+        const _Float16* vb = a.vt + (size_t)(head * 64) * 64;           // blocked V^T: + block * d_model * 64
         constexpr int UB = 4;  // items per thread per batch: 4 K chunks + 4 V chunks in flight
         const int n_items = nkb * 256;
-        for (int base = 0; base < n_items; base += 512 * UB) {
+        for (int base = 0; base < n_items; base += NT * UB) {
             half8 kv[UB], vv[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * 512 + tid;
+                const int idx = base + u * NT + tid;
                 if (idx < n_items) {
                     const int row = idx >> 3, c = idx & 7;  // key row, 16-byte chunk of its 128-byte head slice
                     const int kr = row < len ? row : len - 1;
                     kv[u] = *reinterpret_cast<const half8*>(kg + (size_t)kr * a.ldqk + c * 8);
                     const int kbi = idx >> 8, dd = (idx >> 2) & 63, c16 = idx & 3;  // key block, head dim, 8-key chunk
-                    vv[u] = *reinterpret_cast<const half8*>(vg + (size_t)dd * a.ldvt + kbi * 32 + c16 * 8);
+                    if (a.vt_blocked) {  // an 8-token chunk never straddles a 64-token block (t0 % 8 == 0)
+                        const long long tok = t0 + kbi * 32 + c16 * 8;
+                        vv[u] = *reinterpret_cast<const half8*>(vb + (size_t)(tok >> 6) * a.d_model * 64 + dd * 64 + (tok & 63));
+                    } else {
+                        vv[u] = *reinterpret_cast<const half8*>(vg + (size_t)dd * a.ldvt + kbi * 32 + c16 * 8);
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * 512 + tid;
+                const int idx = base + u * NT + tid;
                 if (idx < n_items) {
                     const int row = idx >> 3, c = idx & 7;
                     const int r = row & 31;
@@ -91,7 +115,6 @@ __global__ void __launch_bounds__(512, 4) bh_attention_kernel(BhAttnArgs a) {
         }
     }
     __syncthreads();
-    const int ql = lane & 31, h = lane >> 5;
     const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
     // LDS fragment offsets: K as the conflict-free ds_read_b128 pattern, V^T as conflict-free ds_read_b64
@@ -113,18 +136,10 @@ __global__ void __launch_bounds__(512, 4) bh_attention_kernel(BhAttnArgs a) {
         }
     }
 
-    // wave w takes query blocks w, w+8, ... of the sequence
-    for (int qb = wave; qb * 32 < len; qb += 8) {
+    // wave w takes query blocks w, w + NWV, ... of the sequence
+    for (int qb = wave; qb * 32 < len; qb += NWV) {
     const int q0 = qb * 32;
-    // Q fragments (operand B): lane (query ql, half h), k-step s4 covers head dims 16 s4 + 8 h .. + 8
-    half8 qf[4];
-    {
-        int qr = q0 + ql;
-        qr = qr < len ? qr : len - 1;
-        const _Float16* qp = a.qk + (size_t)(t0 + qr) * a.ldqk + head * 64 + 8 * h;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *reinterpret_cast<const half8*>(qp + 16 * s4);
-    }
+    if (qb != wave) load_q(qf, q0);
     float m_run = -__builtin_inff();  // running max (identical in both half-lanes)
     float l_run = 0.f;                // this half-lane's share of the running denominator
     floatx16 o[2];
@@ -212,8 +227,10 @@ __global__ void __launch_bounds__(512, 4) bh_attention_kernel(BhAttnArgs a) {
     }  // query blocks
 }
 
-hipError_t bh_launch_attention(const BhAttnArgs& a_in, int batch, int n_heads, int max_len, hipStream_t stream) {
-    if (batch <= 0 || max_len <= 0) return hipSuccess;
+namespace {
+template <int NWV>
+hipError_t launch_attn(const BhAttnArgs& a_in, int n_seq, int n_heads, int max_len, hipStream_t stream) {
+    if (n_seq <= 0) return hipSuccess;
     const int nkb = (max_len + 31) / 32;
     if (nkb * 8192 > 160 * 1024) return hipErrorInvalidValue;  // sequences longer than 640 tokens
     BhAttnArgs a = a_in;
@@ -221,11 +238,31 @@ hipError_t bh_launch_attention(const BhAttnArgs& a_in, int batch, int n_heads, i
     const size_t smem = (size_t)nkb * 8192;
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel<NWV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_smem = smem;
     }
-    hipLaunchKernelGGL(bh_attention_kernel, dim3(n_heads, batch), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL(bh_attention_kernel<NWV>, dim3(n_heads, n_seq), dim3(64 * NWV), smem, stream, a);
     return hipGetLastError();
+}
+}  // namespace
+
+// All sequences in one launch (8-wave workgroups, LDS sized for max_len).
+hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream) {
+    if (batch <= 0 || max_len <= 0) return hipSuccess;
+    if (max_len <= 128) return launch_attn<4>(a, batch, n_heads, max_len, stream);
+    return launch_attn<8>(a, batch, n_heads, max_len, stream);
+}
+
+// Two launches over a length-bucketed batch: seq_idx_dev holds the n_short sequences of at most 128 tokens first,
+// then the n_long longer ones.
+hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a_in, const int* seq_idx_dev, int n_short, int n_long,
+                                        int max_len_long, int n_heads, hipStream_t stream) {
+    BhAttnArgs a = a_in;
+    a.seq_idx = seq_idx_dev;
+    hipError_t e = launch_attn<4>(a, n_short, n_heads, 128, stream);
+    if (e != hipSuccess) return e;
+    a.seq_idx = seq_idx_dev + n_short;
+    return launch_attn<8>(a, n_long, n_heads, max_len_long > 129 ? max_len_long : 129, stream);
 }

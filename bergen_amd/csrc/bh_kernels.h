@@ -66,6 +66,7 @@ struct BhGemmArgs {
     int bias_mode;
     int gelu;    // erf-GELU on the result
     int swap_b;  // filled by the launcher: direction of v_permlane32_swap on this device
+    long long c_block_rows;  // != 0: C is stored blocked by 64 columns with this many rows per block (persistent kernel only)
     int stagger_phases, stagger_unit, stagger_first_round;  // start stagger of the first round of blocks (0 = off)
 };
 // variant 0 = auto; see gemm_f16.hip for the explicit tile configurations
@@ -77,16 +78,21 @@ void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of 
 struct BhAttnArgs {
     const _Float16* qk;  // [tokens][2*d_model]: queries in columns [0, d), keys in [d, 2d)
     long long ldqk;
-    const _Float16* vt;  // [d_model][ldvt]: values, transposed (column = token)
+    const _Float16* vt;  // values, transposed: vt_blocked == 0: [d_model][ldvt] (column = token);
+                         // vt_blocked != 0: [tokens / 64][d_model][64] (64-token blocks, each d_model x 64)
     long long ldvt;
+    int vt_blocked;
     _Float16* ctx;  // [tokens][d_model]
     long long ldc;
     const long long* seq_off;  // [batch] first row of each sequence (multiple of 8)
     const int* seq_len;        // [batch] tokens per sequence (>= 1)
     int d_model;
-    int v_lds_off;  // filled by the launcher: byte offset of the V^T image in LDS
+    int v_lds_off;       // filled by the launcher: byte offset of the V^T image in LDS
+    const int* seq_idx;  // filled by the launcher: optional indirection blockIdx.y -> sequence (length buckets)
 };
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
+hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
+                                        int max_len_long, int n_heads, hipStream_t stream);
 
 struct BhEmbedArgs {
     const int* tok;  // [n_rows] token id / position id / token-type id of each packed row

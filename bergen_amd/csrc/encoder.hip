@@ -133,8 +133,10 @@ int build_slots(bh_encoder* e) {
 }
 
 int gemm(bh_encoder* e, const _Float16* A, long long lda, const _Float16* B, long long ldb, _Float16* C, long long ldc,
-         int M, int N, int K, const _Float16* bias, int bias_mode, const _Float16* residual, long long ldr, int gelu) {
+         int M, int N, int K, const _Float16* bias, int bias_mode, const _Float16* residual, long long ldr, int gelu,
+         long long c_block_rows = 0) {
     BhGemmArgs g{};
+    g.c_block_rows = c_block_rows;
     g.A = A;
     g.lda = lda;
     g.B = B;
@@ -292,14 +294,27 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         len_sq += (double)n * n;
     }
     const int m_pad = round_up(cursor + 32, 256);  // +32: the attention's last key block may read past a sequence
-    // tok | pos | typ  [m_pad each] | seq_len [batch] | slot [batch*seq_len] (pool == 2 only)
+    // tok | pos | typ  [m_pad each] | seq_len [batch] | seq_idx [batch] | slot [batch*seq_len] (pool == 2 only)
     const size_t n_slot = pool == 2 ? (size_t)batch * seq_len : 0;
-    std::vector<int> ib((size_t)3 * m_pad + batch + n_slot, 0);
+    std::vector<int> ib((size_t)3 * m_pad + 2 * (size_t)batch + n_slot, 0);
     int* tok = ib.data();
     int* pos = tok + m_pad;
     int* typ = pos + m_pad;
     int* slen = typ + m_pad;
-    int* slot = slen + batch;
+    int* sidx = slen + batch;
+    int* slot = sidx + batch;
+    // attention length buckets: sequences of at most 128 tokens first, then the longer ones
+    int n_short = 0, max_len_long = 0;
+    for (int b = 0; b < batch; ++b)
+        if (len[b] <= 128) sidx[n_short++] = b;
+    {
+        int w = n_short;
+        for (int b = 0; b < batch; ++b)
+            if (len[b] > 128) {
+                sidx[w++] = b;
+                max_len_long = std::max(max_len_long, len[b]);
+            }
+    }
     for (int b = 0; b < batch; ++b) {
         slen[b] = len[b];
         long long r = off[b];
@@ -343,7 +358,8 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     const int* d_pos = d_tok + m_pad;
     const int* d_typ = d_pos + m_pad;
     const int* d_len = d_typ + m_pad;
-    const int* d_slot = d_len + batch;
+    const int* d_sidx = d_len + batch;
+    const int* d_slot = d_sidx + batch;
 
     BH_HIP_TRY(hipEventRecord(e->ev0, st));
     BhEmbedArgs ea{};
@@ -361,23 +377,27 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     ea.out = e->X.p;
     BH_HIP_TRY(bh_launch_embed_ln(ea, st));
 
+    // the blocked V^T layout is written by the persistent GEMM only (256-row tiles of the weight operand)
+    const bool vt_blocked = (d % 256 == 0) && (e->gemm_variant == 0 || (e->gemm_variant >= 7 && e->gemm_variant <= 9));
     for (int l = 0; l < c.n_layers; ++l) {
         const Layer& L = e->layers[l];
         // Q | K projections: QK[m][2d] = X Wqk^T + bqk
         if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * d, m_pad, 2 * d, d, L.bqk, 1, nullptr, 0, 0))) return rc;
-        // V projection, written TRANSPOSED: VT[d][m] = Wv X^T + bv (bias per row)
-        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, d, m_pad, d, L.bv, 2, nullptr, 0, 0))) return rc;
+        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][d][64] = Wv X^T + bv (bias per row)
+        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, d, m_pad, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? d : 0)))
+            return rc;
         BhAttnArgs aa{};
         aa.qk = e->QK.p;
         aa.ldqk = 2 * d;
         aa.vt = e->VT.p;
         aa.ldvt = m_pad;
+        aa.vt_blocked = vt_blocked ? 1 : 0;
         aa.ctx = e->CTX.p;
         aa.ldc = d;
         aa.seq_off = e->seq_off.p;
         aa.seq_len = d_len;
         aa.d_model = d;
-        BH_HIP_TRY(bh_launch_attention(aa, batch, c.n_heads, max_len, st));
+        BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st));
         // attention output projection, then LayerNorm(projection + layer input)
         if ((rc = gemm(e, e->CTX.p, d, L.wo, d, e->Y.p, d, m_pad, d, d, L.bo, 1, nullptr, 0, 0))) return rc;
         BhLnArgs la{};

@@ -134,6 +134,8 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? ((epi & BH_EPI_RESIDUAL) ? 5 : 7) : (a.M >= 256 && a.N >= 128) ? 2 : 1;
     if (variant == 6 || !epi_fast || g_swap_b != 0) return bh_gemm_generic(a, epi, stream);
     const bool persist = variant >= 7 && variant <= 9;
+    if (a.c_block_rows && !(persist && a.M % 256 == 0 && a.N % 256 == 0 && !(epi & BH_EPI_RESIDUAL)))
+        return hipErrorInvalidValue;  // blocked output is a persistent-kernel feature (whole 256x256 tiles only)
     // burst stores; non-temporal for the GELU (FFN-up) output, which is far larger than the caches and is read
     // back only by the next kernel (measured: +8 % on that GEMM, -7 % on the others)
     const int pst = variant == 8 ? 0 : variant == 9 ? 3 : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;

@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     half8 pend[NST];             // previous tile's outputs, packed, waiting to be stored
     _Float16* pend_ptr = a.C;    // per-lane address of the pending tile's (tm = 0, tn = 0, u = 0) store
     bool pend_valid = false;
-    const long long ldc32 = a.ldc * 32;
+    // output addressing: row-major (row stride ldc), or — c_block_rows != 0 — blocked by 64 columns:
+    // element (m, n) at C[(n / 64) * c_block_rows * 64 + m * 64 + n % 64]  (the attention kernel's V^T layout)
+    const long long ldc_eff = a.c_block_rows ? 64 : a.ldc;
+    const long long ldc32 = ldc_eff * 32;
 
     // Fragments: the weight fragments wb are double-buffered over the k-steps; the activation fragments xa are
     // single-buffered and refilled "rolling": xa[tm] of the next k-step is read right after the MFMAs that
@@ -240,6 +243,12 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
         }
         // ---- epilogue math of this tile -> pend (stores are issued inside the next tile's main loop)
         {
+            _Float16* tile_ptr;  // per-lane address of this tile's (tm = 0, tn = 0, u = 0) store
+            if (a.c_block_rows)  // a wave's 64 output columns are exactly one 64-column block
+                tile_ptr = a.C + (size_t)((n0 + wn * TN * 32) >> 6) * a.c_block_rows * 64 +
+                           (size_t)(m0 + wm * TM * 32 + ql) * 64 + 8 * h;
+            else
+                tile_ptr = a.C + (size_t)(m0 + wm * TM * 32 + ql) * a.ldc + n0 + wn * TN * 32 + 8 * h;
             float bias_row[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -276,15 +285,21 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                             if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
                             o[e] = (_Float16)v;
                         }
-                        pend[(tm * TN + tn) * 2 + u] = o;
+                        if constexpr ((PST & 1) != 0) {  // burst: store at once, nothing stays live
+                            half8* p = reinterpret_cast<half8*>(tile_ptr + tm * ldc32 + tn * 32 + u * 16);
+                            if constexpr ((PST & 2) != 0)
+                                __builtin_nontemporal_store(o, p);
+                            else
+                                *p = o;
+                        } else {
+                            pend[(tm * TN + tn) * 2 + u] = o;
+                        }
                     }
                 }
             }
-            pend_ptr = a.C + (size_t)(m0 + wm * TM * 32 + ql) * a.ldc + n0 + wn * TN * 32 + 8 * h;
-            pend_valid = true;
-            if constexpr ((PST & 1) != 0) {
-#pragma unroll
-                for (int q = 0; q < NST; ++q) store_pending(q);
+            if constexpr ((PST & 1) == 0) {
+                pend_ptr = tile_ptr;
+                pend_valid = true;
             }
         }
     }
