@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(1024) bh_csr_scan_topk_kernel(BhCsrScanArgs a)
     // Software pipeline over documents: while document d is processed, the first PF chunks (64 entries each) of the
     // wave's NEXT document are already in flight and the row pointers of the one after that are being fetched, so
     // the dependent chain row pointer -> entries -> LDS lookups never sits exposed.
-    constexpr int PF = 4;
+    constexpr int PF = 2;
     long long n_seen = 0;
     long long d = gw;
     long long e0 = 0, e1 = 0, ne0 = 0, ne1 = 0;
@@ -206,19 +206,20 @@ __global__ void __launch_bounds__(1024) bh_csr_scan_topk_kernel(BhCsrScanArgs a)
         for (int r = 0; r < EPLK; ++r) buf[r * 64 + lane] = e[r];
     }
     __syncthreads();  // (workgroup-scope release/acquire: the lists were written by waves of this CU)
-    constexpr int EPLM = NWV * KP / 64;
     for (int qq = wave; qq < 64; qq += NWV) {
-        u64 e[EPLM];
+        u64 acc[EPLK];
 #pragma unroll
-        for (int w2 = 0; w2 < NWV; ++w2) {
+        for (int r = 0; r < EPLK; ++r) acc[r] = 0ull;
+        for (int w2 = 0; w2 < NWV; ++w2) {  // fold the 16 sorted lists one at a time (bitonic merge, best KP kept)
             const u64* lst = a.cand + ((size_t)((long long)blockIdx.x * NWV + w2) * 64 + qq) * CAP;
+            u64 bb[EPLK];
 #pragma unroll
-            for (int r = 0; r < EPLK; ++r) e[w2 * EPLK + r] = lst[r * 64 + lane];
+            for (int r = 0; r < EPLK; ++r) bb[r] = lst[r * 64 + lane];
+            bh_wave_merge_top<EPLK>(acc, bb, lane);
         }
-        bh_wave_sort_desc<EPLM>(e, lane);
         u64* out = a.partial + ((size_t)blockIdx.x * 64 + qq) * KP;
 #pragma unroll
-        for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = e[r];
+        for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = acc[r];
     }
 }
 

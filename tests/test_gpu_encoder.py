@@ -312,3 +312,19 @@ def test_dense_plugin_runs_on_the_native_encoder(tmp_path):
     assert overlap >= 0.9, overlap
     assert (got[:, 0] == want[:, 0]).mean() >= 0.8
     assert out["score"].shape == (len(queries), 10)
+
+
+def test_encoder_bert_large_shape_against_oracle():
+    """e5-large-v2 architecture (BASELINE configs[4]): 1024 hidden x 16 heads x 4096 FFN (4 of its 24 layers, to keep
+    the fp64 oracle fast), mean pooling — d = 1024 exercises the blocked V^T layout and the 1024-wide row kernels."""
+    cfg = dict(vocab_size=1500, hidden_size=1024, num_hidden_layers=4, num_attention_heads=16, intermediate_size=4096,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=51)
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=5, max_len=150, seed=52, min_len=100)
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask),
+          "token_type_ids": torch.from_numpy(types)}
+    ref_h = bert_oracle.bert_forward(sd, cfg, ids, mask, types)
+    _check_embeddings(enc.encode_pooled(kw, "mean"), bert_oracle.mean_pool(ref_h, mask), "bert-large mean")
+    _check_embeddings(enc.encode_pooled(kw, "cls"), bert_oracle.cls_pool(ref_h), "bert-large cls")
+    enc.close()
