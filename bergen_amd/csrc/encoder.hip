@@ -252,7 +252,7 @@ int bh_encoder_commit(bh_encoder* e) {
 int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
     if (!e || !name) return bh_fail(BH_EINVAL, "null argument");
     if (std::string(name) == "gemm_variant") {
-        if (value < 0 || value > 26) return bh_fail(BH_EINVAL, "gemm_variant must be 0..26");
+        if (value < 0 || value > 32) return bh_fail(BH_EINVAL, "gemm_variant must be 0..32");
         e->gemm_variant = (int)value;
         return BH_OK;
     }

@@ -111,7 +111,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     a.stagger_phases = 0;
     if (g_stagger_phases > 1) {
         // spread the first round of blocks over ~pct % of one tile time (estimated at 60 % MFMA utilisation)
-        const int cfgv = variant >= 21 ? 2 : variant >= 11 ? 5 : (variant == 0 || (variant >= 7 && variant <= 9)) ? 5 : variant;
+        const int cfgv = variant >= 21 ? 2 : variant >= 11 ? 5 : (variant == 0 || (variant >= 7 && variant <= 9) || variant >= 31) ? 5 : variant;
         if (cfgv >= 1 && cfgv <= 5) {
             const int bm = kTile[cfgv].bm, bn = kTile[cfgv].bn;
             const int per_cu = (cfgv == 1 || cfgv == 2) ? 2 : 1;
@@ -122,7 +122,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
             a.stagger_first_round = 256 * per_cu;
         }
     }
-    if (variant >= 11) return bh_gemm_ablate(a, variant, stream);
+    if (variant >= 11 && variant < 31) return bh_gemm_ablate(a, variant, stream);
     int epi = 0;
     if (a.bias && a.bias_mode == 1) epi |= BH_EPI_BIAS_COL;
     if (a.bias && a.bias_mode == 2) epi |= BH_EPI_BIAS_ROW;
@@ -133,12 +133,12 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     const bool auto_variant = variant == 0;
     if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? ((epi & BH_EPI_RESIDUAL) ? 5 : 7) : (a.M >= 256 && a.N >= 128) ? 2 : 1;
     if (variant == 6 || !epi_fast || g_swap_b != 0) return bh_gemm_generic(a, epi, stream);
-    const bool persist = variant >= 7 && variant <= 9;
+    const bool persist = (variant >= 7 && variant <= 9) || variant == 31 || variant == 32;
     if (a.c_block_rows && !(persist && a.M % 256 == 0 && a.N % 256 == 0 && !(epi & BH_EPI_RESIDUAL)))
         return hipErrorInvalidValue;  // blocked output is a persistent-kernel feature (whole 256x256 tiles only)
     // burst stores; non-temporal for the GELU (FFN-up) output, which is far larger than the caches and is read
     // back only by the next kernel (measured: +8 % on that GEMM, -7 % on the others)
-    const int pst = variant == 8 ? 0 : variant == 9 ? 3 : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
+    const int pst = variant == 31 ? 5 : variant == 32 ? 9 : variant == 8 ? 0 : variant == 9 ? 3 : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
     if (persist) {
         if (epi & BH_EPI_RESIDUAL) return bh_gemm_generic(a, epi, stream);  // (the encoder adds residuals in LayerNorm)
         variant = 5;  // same tile geometry

@@ -18,7 +18,8 @@
 // PST bits: 1 = the stores of a tile are issued in one burst right after its epilogue math (production: measured
 // faster — on gfx950 stores share the vmcnt counter with the LDS-DMA loads, so stores spread over the stages make
 // every stage hand-over wait for store acknowledgements); 0 = stores deferred two per stage into the next tile's
-// main loop (kept as an ablation); 2 = non-temporal stores.
+// main loop (kept as an ablation); 2 = non-temporal stores; 4 / 8 = bench-only (results invalid): epilogue math
+// without its stores / no epilogue at all.
 template <int EPI, int PST = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -56,6 +57,11 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
         n_my = cnt > j ? (cnt - j + G8 - 1) / G8 : 0;
     }
     if (n_my == 0) return;
+    // optional start stagger (bench knob): spreads the workgroups' store bursts over time
+    if (a.stagger_phases > 1) {
+        const int phase = (int)((blockIdx.x >> 3) % (unsigned)a.stagger_phases);
+        for (int i = 0; i < phase * a.stagger_unit; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- per-lane LDS-DMA source offsets inside a tile.  Instruction i of a wave fetches 8 rows of piece
     // 2 i + (wave >> 2) (i < 4: A pieces, i >= 4: B pieces), so its offset is a per-lane base plus a uniform stride.
@@ -242,7 +248,12 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
             }
         }
         // ---- epilogue math of this tile -> pend (stores are issued inside the next tile's main loop)
-        {
+        if constexpr ((PST & 8) != 0) {  // ablation: no epilogue at all
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(acc[tm][tn]));
+        } else {
             _Float16* tile_ptr;  // per-lane address of this tile's (tm = 0, tn = 0, u = 0) store
             if (a.c_block_rows)  // a wave's 64 output columns are exactly one 64-column block
                 tile_ptr = a.C + (size_t)((n0 + wn * TN * 32) >> 6) * a.c_block_rows * 64 +
@@ -285,7 +296,9 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                             if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
                             o[e] = (_Float16)v;
                         }
-                        if constexpr ((PST & 1) != 0) {  // burst: store at once, nothing stays live
+                        if constexpr ((PST & 4) != 0) {  // ablation: epilogue math without the stores
+                            asm volatile("" ::"v"(o));
+                        } else if constexpr ((PST & 1) != 0) {  // burst: store at once, nothing stays live
                             half8* p = reinterpret_cast<half8*>(tile_ptr + tm * ldc32 + tn * 32 + u * 16);
                             if constexpr ((PST & 2) != 0)
                                 __builtin_nontemporal_store(o, p);

@@ -28,14 +28,11 @@ def run(name, m, n, k, gelu, variants, tag=""):
 
 
 M = 66560
-print("== epilogue ablations (17/27: epilogue math without stores; 18/28: DMA + barriers only, no epilogue)")
-run("ffn1", M, 3072, 768, True, [5, 14, 17, 18, 2, 24, 27, 28])
-run("ffn1_nogelu", M, 3072, 768, False, [5, 2])
-print("== start stagger")
-for phases, pct in [(0, 100), (2, 100), (4, 100), (8, 100), (8, 200), (16, 100), (4, 50)]:
+print("== start stagger, persistent kernel (variant 7)")
+for phases, pct in [(0, 100), (2, 100), (4, 100), (8, 100), (4, 50), (2, 50), (3, 100), (0, 100)]:
     _lib.set_option("gemm_stagger_phases", phases)
     _lib.set_option("gemm_stagger_pct", pct)
     for shape in [("ffn1", M, 3072, 768, True), ("qk", M, 1536, 768, False), ("ffn2", M, 768, 3072, False)]:
-        run(*shape, [5, 2, 4], tag=f"stagger {phases}x{pct}%")
+        run(*shape, [7], tag=f"stagger {phases}x{pct}%")
 _lib.set_option("gemm_stagger_phases", 0)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gemm_stagger.json"), "w"), indent=1)
