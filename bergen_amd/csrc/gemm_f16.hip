@@ -99,7 +99,7 @@ hipError_t run_cfg(int cfg, const BhGemmArgs& a, int epi, hipStream_t s) {
 // variant: 0 = auto; 1..5 = explicit tile configuration (gemm_f16_kernel.h); 6 = generic bounds-checked kernel
 // for everything; 7 = persistent 256x256 kernel (gemm_f16_persist.h; burst stores); 8 = 7 with stores deferred into
 // the next tile's main loop, 9 = 7 with non-temporal stores (both valid results; ablations); 11..28 = bench-only
-// ablations (results invalid).
+// ablations (results invalid); 10 = 7 with the last partial round of tiles re-cut into 128x128 tiles (experiment, measured neutral).
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t stream) {
     BhGemmArgs a = a_in;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -131,11 +131,13 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);
     const bool auto_variant = variant == 0;
+    const bool variant_balanced = variant == 10;  // 7 + balanced remainder, explicitly
+    if (variant == 10) variant = 7;
     if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? ((epi & BH_EPI_RESIDUAL) ? 5 : 7) : (a.M >= 256 && a.N >= 128) ? 2 : 1;
     if (variant == 6 || !epi_fast || g_swap_b != 0) return bh_gemm_generic(a, epi, stream);
     const bool persist = (variant >= 7 && variant <= 9) || variant == 31 || variant == 32;
     if (a.c_block_rows && !(persist && a.M % 256 == 0 && a.N % 256 == 0 && !(epi & BH_EPI_RESIDUAL)))
-        return hipErrorInvalidValue;  // blocked output is a persistent-kernel feature (whole 256x256 tiles only)
+        return hipErrorInvalidValue;  // blocked output: whole 256x256 tiles only (fast epilogues)
     // burst stores; non-temporal for the GELU (FFN-up) output, which is far larger than the caches and is read
     // back only by the next kernel (measured: +8 % on that GEMM, -7 % on the others)
     const int pst = variant == 31 ? 5 : variant == 32 ? 9 : variant == 8 ? 0 : variant == 9 ? 3 : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
@@ -151,8 +153,52 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         BhGemmArgs t = a;
         t.M = mi;
         t.N = ni;
-        e = persist ? bh_gemm_persist(t, epi, pst, stream) : run_cfg(variant, t, epi, stream);
-        if (e != hipSuccess) return e;
+        // Wave quantisation: T tiles on n_cu persistent workgroups take ceil(T / n_cu) tile times (804 tiles of an
+        // N = 768 projection = 3.14 -> 4 rounds).  In auto mode the tiles beyond the last FULL round go to a second
+        // launch with 128x128 tiles (two blocks per CU): a quarter of the work per tile, spread over the whole chip.
+        // Variant 10 only: measured neutral (a small tile still pays the full K-loop latency), kept as an experiment.
+        int n_cu = 256;
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            static int cached = 0;
+            if (cached == 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            if (cached > 0) n_cu = cached;
+        }
+        const int tm_ = mi / 256, tn_ = ni / 256;
+        const long long T = (long long)tm_ * tn_;
+        const long long full = T / n_cu * n_cu;
+        if (persist && variant_balanced && full > 0 && full < T) {  // (measured neutral: the re-cut tiles keep the
+                                                                    // K-loop latency; not used by auto)
+            BhGemmArgs r = t;  // remainder
+            if (tm_ >= tn_) {  // split along M: whole M panels of tn_ tiles
+                const int pm = (int)(full / tn_);
+                t.M = pm * 256;
+                r.A = t.A + (size_t)t.M * t.lda;
+                r.M = mi - t.M;
+                if (t.c_block_rows)
+                    r.C = t.C + (size_t)t.M * 64;  // blocked layout: rows are 64 elements apart inside a block
+                else
+                    r.C = t.C + (size_t)t.M * t.ldc;
+                if (t.bias && t.bias_mode == 2) r.bias = t.bias + t.M;
+            } else {  // split along N: whole N panels of tm_ tiles
+                const int pn = (int)(full / tm_);
+                t.N = pn * 256;
+                r.B = t.B + (size_t)t.N * t.ldb;
+                r.N = ni - t.N;
+                if (t.c_block_rows)
+                    r.C = t.C + (size_t)(t.N / 64) * t.c_block_rows * 64;
+                else
+                    r.C = t.C + t.N;
+                if (t.bias && t.bias_mode == 1) r.bias = t.bias + t.N;
+            }
+            if ((e = bh_gemm_persist(t, epi, pst, stream)) != hipSuccess) return e;
+            if ((e = run_cfg(1, r, epi, stream)) != hipSuccess) return e;
+        } else {
+            e = persist ? bh_gemm_persist(t, epi, pst, stream) : run_cfg(variant, t, epi, stream);
+            if (e != hipSuccess) return e;
+        }
     }
     if (ni < a.N) {  // right strip: all rows, columns [ni, N)
         BhGemmArgs t = a;

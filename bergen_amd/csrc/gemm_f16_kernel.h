@@ -245,7 +245,10 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) bh_gemm_f16_kernel(BhGemmAr
             const int m = m0 + (wm * TM + tm) * 32 + ql;
             float bias_row = 0.f;
             if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) bias_row = (float)a.bias[m];
-            _Float16* crow = a.C + (size_t)m * a.ldc;
+            // row-major output, or (c_block_rows != 0) blocked by 64 columns: (m, n) at
+            // C[(n / 64) * c_block_rows * 64 + m * 64 + n % 64]; a 16-byte store never straddles a block
+            _Float16* crow = a.c_block_rows ? a.C + (size_t)m * 64 : a.C + (size_t)m * a.ldc;
+            const size_t cblk = (size_t)a.c_block_rows * 64;
             const _Float16* rrow = nullptr;
             if constexpr ((EPI & BH_EPI_RESIDUAL) != 0) rrow = a.residual + (size_t)m * a.ldr;
 #pragma unroll
@@ -286,6 +289,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) bh_gemm_f16_kernel(BhGemmAr
                     for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
                     if constexpr ((ABL & 16) != 0) {  // ablation: epilogue math without the stores
                         if (a.bias_mode == 12345) *reinterpret_cast<half8*>(crow + n) = o;
+                    } else if (a.c_block_rows) {
+                        *reinterpret_cast<half8*>(crow + (size_t)(n >> 6) * cblk + (n & 63)) = o;
                     } else {
                         *reinterpret_cast<half8*>(crow + n) = o;
                     }

@@ -45,7 +45,7 @@ def test_permlane_probe():
     assert encoder.permlane_mode() in (0, 1)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm_variants_plain(variant):
     """Asymmetric operands, sizes that are not tile multiples (ragged M and N edges)."""
     from bergen_amd import encoder
@@ -79,14 +79,15 @@ def test_gemm_persistent_many_tiles_per_block():
     (fewer stages than deferred-store slots) to 48 stages; every epilogue it supports."""
     from bergen_amd import encoder
     rng = np.random.default_rng(77)
-    for (M, N, K) in [(2048, 1024, 64), (1536, 1280, 320), (4096, 2560, 768), (768, 5120 + 256, 3072)]:
+    # (the last two shapes have more tiles than CUs and a partial last round: the balanced variants split them)
+    for (M, N, K) in [(2048, 1024, 64), (1536, 1280, 320), (4096 + 1024, 4096, 128), (768, 256 * 100, 192)]:
         a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
         bc, br = rnd16(rng, N), rnd16(rng, M)
         for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)),
                         (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
                         (dict(bias=h16(br), bias_mode=2), bert_oracle.gemm_ref(a, w, br, 2)),
                         (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
-            for variant in (7, 8):
+            for variant in (7, 8, 10, 0):
                 out, _ = encoder.gemm_f16(h16(a), h16(w), variant=variant, **kw)
                 assert_gemm_close(out, ref, f"persistent v{variant} {M}x{N}x{K} {sorted(kw)}")
 
@@ -327,4 +328,22 @@ def test_encoder_bert_large_shape_against_oracle():
     ref_h = bert_oracle.bert_forward(sd, cfg, ids, mask, types)
     _check_embeddings(enc.encode_pooled(kw, "mean"), bert_oracle.mean_pool(ref_h, mask), "bert-large mean")
     _check_embeddings(enc.encode_pooled(kw, "cls"), bert_oracle.cls_pool(ref_h), "bert-large cls")
+    enc.close()
+
+
+def test_encoder_large_batch():
+    """> 65 536 packed tokens: every projection has more 256x256 tiles than the chip has CUs (several tiles per
+    persistent workgroup, partial last round), the transposed V projection writes its blocked layout across them."""
+    cfg = dict(vocab_size=800, hidden_size=256, num_hidden_layers=1, num_attention_heads=4, intermediate_size=512,
+               max_position_embeddings=128, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=61)
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=760, max_len=128, seed=62, min_len=60)
+    assert int(mask.sum()) > 66000
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask),
+          "token_type_ids": torch.from_numpy(types)}
+    got = enc.encode_pooled(kw, "mean")
+    assert enc.counters()["packed_rows"] > 65536 + 256
+    ref = bert_oracle.encode(sd, cfg, ids, mask, types, pooler="mean")
+    _check_embeddings(got, ref, "large batch")
     enc.close()
