@@ -60,7 +60,16 @@ class Retrieve:
                  pyserini_num_threads=1,
                  continue_batch=None,
                  device=0,
-                 num_workers=4):
+                 num_workers=4,
+                 encode_rank=0,
+                 encode_world=1):
+        # encode_rank / encode_world: multi-GPU encoding.  The reference's only multi-GPU mechanism is
+        # torch.nn.DataParallel around the encoder (dense.py:32-35: scatter inputs, re-broadcast every weight and
+        # gather [B, T, d] outputs to GPU 0 on every forward).  Here each of `encode_world` processes (one per GPU)
+        # encodes a contiguous range of BATCHES of the dataset into the same index folder — no collective; the
+        # union of the chunk files is a valid index (same naming, ordering by the integer in the file name).
+        self.encode_rank = int(encode_rank)
+        self.encode_world = int(encode_world)
         self.continue_batch = continue_batch
         self.batch_size = batch_size
         self.batch_size_sim = batch_size_sim
@@ -98,8 +107,18 @@ class Retrieve:
         embs_list = list()
         dev = 'cuda' if torch.cuda.is_available() else 'cpu'
         self.model.model = self.model.model.to(dev)
-        for i, batch in tqdm(enumerate(dataloader), total=total_n_batches, desc=f'Encoding: {self.model.model_name}',
-                             file=sys.stderr):
+        # this process's contiguous range of batches [b_lo, b_hi)
+        per_rank = -(-total_n_batches // self.encode_world)
+        b_lo = min(total_n_batches, self.encode_rank * per_rank)
+        b_hi = min(total_n_batches, b_lo + per_rank)
+        if self.encode_world > 1:
+            from torch.utils.data import Subset
+            rows = range(b_lo * self.batch_size, min(len(dataset), b_hi * self.batch_size))
+            dataloader = DataLoader(Subset(dataset, rows), batch_size=self.batch_size,
+                                    collate_fn=lambda batch: self.model.collate_fn(batch, query_or_doc),
+                                    num_workers=self.num_workers)
+        for i, batch in tqdm(enumerate(dataloader, start=b_lo), total=b_hi - b_lo,
+                             desc=f'Encoding: {self.model.model_name}', file=sys.stderr):
             if self.continue_batch != None:
                 if i <= self.continue_batch:
                     continue
@@ -109,7 +128,7 @@ class Retrieve:
                 emb = emb.detach().cpu()
             embs_list.append(emb)
             # save chunk (retrieve.py:135-141)
-            if i % save_every_n_batches == 0 and i != 0 or i == total_n_batches - 1:
+            if i % save_every_n_batches == 0 and i != 0 or i == b_hi - 1:  # (b_hi = total_n_batches for one process)
                 chunk_save_path = self.get_chunk_path(save_path, i)
                 embs = torch.cat(embs_list)
                 if 'splade' in self.model.model_name or getattr(self.model, 'sparse', False):

@@ -152,3 +152,45 @@ def test_map_doc_ids_only_touches_hits():
     idx = torch.tensor([[5, 99, 0], [7, 5, -1]])
     assert Retrieve._map_doc_ids(ds, idx) == [["d5", "d99", "d0"], ["d7", "d5"]]
     assert Retrieve._map_doc_ids({"id": [str(i) for i in range(10)]}, torch.tensor([[3, 1]])) == [["3", "1"]]
+
+
+def test_multi_process_encoding_writes_one_valid_index(tmp_path):
+    """encode_rank / encode_world: every process encodes a contiguous range of batches into the same folder; the union
+    equals the single-process index (same rows in the same order under the reference's chunk ordering)."""
+    import torch
+    import bergen_amd
+
+    class FakeModel:
+        model_name = "fake/enc"
+
+        def __init__(self):
+            self.model = torch.nn.Identity()
+
+        def collate_fn(self, batch, query_or_doc=None):
+            return {"x": torch.tensor([[float(s["content"])] for s in batch])}
+
+        def __call__(self, query_or_doc, kwargs):
+            return {"embedding": torch.cat([kwargs["x"], kwargs["x"] * 2], dim=1).half()}
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return {"content": str(i)}
+
+    n, bs = 1003, 16
+    one = tmp_path / "one"
+    r = bergen_amd.Retrieve(init_args=FakeModel(), batch_size=bs, num_workers=0)
+    r.encode_and_save(DS(n), str(one), "doc", chunk_size=160)
+    want = bergen_amd.utils.load_embeddings(str(one))
+    assert want.shape == (n, 2) and want[:, 0].tolist() == [float(i) for i in range(n)]
+    many = tmp_path / "many"
+    for rank in range(3):
+        rr = bergen_amd.Retrieve(init_args=FakeModel(), batch_size=bs, num_workers=0, encode_rank=rank, encode_world=3)
+        rr.encode_and_save(DS(n), str(many), "doc", chunk_size=160)
+    got = bergen_amd.utils.load_embeddings(str(many))
+    assert torch.equal(got, want)
