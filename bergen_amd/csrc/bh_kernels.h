@@ -168,3 +168,23 @@ struct BhCsrMergeArgs {
     long long* out_ids;
 };
 hipError_t bh_launch_csr_merge_rescore(const BhCsrMergeArgs& a, int kp, int nq_tile, hipStream_t stream);
+
+struct BhCsrMfmaArgs {
+    const unsigned* entries;
+    const long long* row_ptr;
+    long long n_rows;
+    const unsigned* bitmap;        // [n_words]
+    const unsigned short* prefix;  // [n_words]
+    const unsigned* sinfo;         // [n_slots] head: 0x80000000 | head index; tail: pair offset << 8 | pair count
+    const unsigned* pairs;         // [n_pairs] tail pairs: fp16 weight << 16 | query
+    const _Float16* WhT;           // [64 queries][64 head terms] weights of the head terms
+    int n_words, n_slots, n_pairs;
+    int off_prefix, off_sinfo, off_pairs, off_thr, off_tiles;  // byte offsets of the LDS images
+    bh_u64* cand;                  // [grid * 8][64][2 * KP]
+    bh_u64* partial;               // [grid][64][KP]
+    unsigned* gthr;                // [64]
+    int ablate;                    // bench-only: 1 = no scatter, 2 = no candidate handling (results invalid)
+};
+hipError_t bh_launch_csr_scan_mfma(const BhCsrMfmaArgs& a, int kp, int grid, size_t smem, hipStream_t stream);
+void bh_sparse_set_kernel(int which);  // 1 = csr_mfma.hip (default), 0 = csr_topk.hip
+void bh_sparse_set_ablate(int bits);   // bench-only

@@ -1,0 +1,336 @@
+// csr_mfma.hip — second-generation sparse (SPLADE) scan: the tile's frequent terms go through the matrix cores.
+//
+// Why (profiles/README.md, "sparse search, first measurement"): in csr_topk.hip every (document entry x tile term) hit
+// costs a ~14-cycle broadcast round for the whole wave; with realistically skewed term statistics nearly every
+// entry hits, because the frequent terms are in most documents AND in most queries.  Those frequent ("head") terms
+// are exactly where the work is dense: a [32 documents x 64 head terms] x [64 head terms x 64 queries] product.
+//
+//   * per query tile the host picks the H = 64 terms used by the most queries (head); WhT[query][head] holds their
+//     weights (MFMA operand B, loaded once into registers); every other term of the tile is a "tail" term with a
+//     short list of (query, weight) pairs.
+//   * a wave (8 per workgroup) owns a contiguous range of 32-document groups, i.e. one contiguous stream of entries,
+//     read in super-chunks of 24 x 64 entries (24 loads in flight per wave, double-buffered across groups);
+//     every entry (lane = entry) is looked up in the tile's term set (bitmap + rank in LDS, then one info word
+//     per slot), its document found from the group's row pointers (one ballot for the chunk + a walk over the few
+//     document boundaries inside it);
+//     head hits are SCATTERED in parallel into a dense fp16 tile D[32 docs][64 head terms] in LDS (one ds_write_b16
+//     per hit lane, no serial loop), tail hits add  weight * w  into an fp32 tile S[32 docs][64 queries] in LDS with
+//     ds_add_f32 (lanes walk their term's short pair list).
+//   * then 8 MFMAs (v_mfma_f32_32x32x16_f16): scores[32 docs][64 queries] = S + D . WhT^T, accumulators initialised
+//     from S; lane (query, half) ends with 16 documents' scores per 32-query block — the dense scan's situation —
+//     and the dense scan's threshold / candidate-buffer / bitonic-compaction logic follows, with wave-local bounds
+//     shared through LDS and one global table (a wave's KP-th best is a valid lower bound of the final KP-th best).
+// Exactness as before: candidates by fp32 score (tail sums in atomic order: fp32-noise-level differences only matter
+// at the KP >= k + 8 margin), canonical fp64 re-score in bh_csr_merge_rescore_kernel (csr_topk.hip).
+// Roofline: HBM — algorithmic bytes per launch = nnz*4 + (N+1)*8.
+#include "bh_device.h"
+#include "bh_kernels.h"
+
+namespace {
+template <int EPL>
+__device__ __forceinline__ void load_keys_m(u64 (&e)[EPL], const u64* buf, unsigned n, int lane) {
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const unsigned idx = r * 64 + lane;
+        e[r] = idx < n ? buf[idx] : 0ull;
+    }
+}
+}  // namespace
+
+template <int KP>
+__global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWV = 8;
+    constexpr int CAP = 2 * KP;
+    constexpr int EPLC = CAP / 64, EPLK = KP / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, h = lane >> 5;
+    const long long gw = (long long)blockIdx.x * NWV + wave, TW = (long long)gridDim.x * NWV;
+
+    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile)
+    unsigned* bitmap = reinterpret_cast<unsigned*>(smem);
+    unsigned short* prefix = reinterpret_cast<unsigned short*>(smem + a.off_prefix);
+    unsigned* sinfo = reinterpret_cast<unsigned*>(smem + a.off_sinfo);
+    unsigned* pairs = reinterpret_cast<unsigned*>(smem + a.off_pairs);
+    unsigned* thr_lds = reinterpret_cast<unsigned*>(smem + a.off_thr);
+    unsigned char* Dt = smem + a.off_tiles + wave * 12288;
+    float* St = reinterpret_cast<float*>(Dt + 4096);
+    for (int i = tid; i < a.n_words; i += 512) {
+        bitmap[i] = a.bitmap[i];
+        prefix[i] = a.prefix[i];
+    }
+    for (int i = tid; i < a.n_slots; i += 512) sinfo[i] = a.sinfo[i];
+    for (int i = tid; i < a.n_pairs; i += 512) pairs[i] = a.pairs[i];
+    if (tid < 64) thr_lds[tid] = BH_ORD_NEG_INF;
+    __syncthreads();
+
+    // ---- B fragments of the head-term weights, resident in registers: lane (query ql [+32 w2], k-group h),
+    // k-step s covers head terms 16 s + 8 h .. + 8
+    half8 wf[2][4];
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            wf[w2][s] = *reinterpret_cast<const half8*>(a.WhT + (size_t)(w2 * 32 + ql) * 64 + 16 * s + 8 * h);
+    // A-fragment read offsets in the D tile (same XOR-permuted 128-byte-row image as the GEMM: conflict-free)
+    unsigned d_off[4];
+    {
+        const int g = ((ql >> 1) & 1) | ((ql >> 3) << 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d_off[s] = (unsigned)((ql >> 3) * 1024 + (ql & 7) * 128 + (((2 * s + h) ^ g) << 4));
+    }
+
+    float thr[2];
+    unsigned cnt[2];
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+        thr[w2] = -__builtin_inff();
+        cnt[w2] = 0;
+    }
+    u64* cand_w = a.cand + (size_t)gw * 64 * CAP;
+
+    auto compact = [&](int w2, int qq) {
+        const int qi = w2 * 32 + qq;
+        const unsigned n = __builtin_amdgcn_readlane(cnt[w2], qq);
+        u64* buf = cand_w + (size_t)qi * CAP;
+        u64 e[EPLC];
+        load_keys_m<EPLC>(e, buf, n, lane);
+        bh_wave_sort_desc<EPLC>(e, lane);
+#pragma unroll
+        for (int r = 0; r < EPLK; ++r) buf[r * 64 + lane] = e[r];
+        if (ql == qq) cnt[w2] = n < (unsigned)KP ? n : (unsigned)KP;
+        const u64 kth = bh_shfl64(e[EPLK - 1], 63);
+        if (kth != 0ull) {
+            // document groups arrive in ascending order inside a wave: a later document that merely ties the
+            // KP-th best loses on row index, so the exclusive compare against the wave's own bound is exact
+            const float nt = bh_key_score(kth);
+            if (ql == qq) thr[w2] = fmaxf(thr[w2], nt);
+            if (lane == qq) atomicMax(&thr_lds[qi], bh_ordf(nt));
+        }
+    };
+
+    // ---- this wave's contiguous range of 32-document groups; its entries form one contiguous stream
+    const long long n_groups = (a.n_rows + 31) / 32;
+    const long long per_wave = (n_groups + TW - 1) / TW;
+    const long long grp_lo = gw * per_wave < n_groups ? gw * per_wave : n_groups;
+    const long long grp_hi = grp_lo + per_wave < n_groups ? grp_lo + per_wave : n_groups;
+
+    // row pointers of a group: lane l holds rp[g0 + l] (l <= 32, clamped to n_rows), relative to the group's first
+    // entry; groups past the wave's range are empty
+    auto load_group = [&](long long grp, long long& base, unsigned& rel) {
+        if (grp < grp_hi) {
+            const long long g0 = grp * 32;
+            base = a.row_ptr[g0];
+            long long r = g0 + (lane < 33 ? lane : 32);
+            r = r <= a.n_rows ? r : a.n_rows;
+            rel = (unsigned)(a.row_ptr[r] - base);
+        } else {
+            base = 0;
+            rel = 0u;
+        }
+    };
+    // one super-chunk = SC chunks of 64 entries; all SC loads are issued back to back (6 KiB in flight per wave)
+    constexpr int SC = 24;
+    auto issue_sc = [&](unsigned (&buf)[SC], const unsigned* eb, unsigned total, unsigned sc) {
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            const unsigned idx = (sc * SC + c) * 64 + lane;
+            buf[c] = idx < total ? eb[idx] : 0u;
+        }
+    };
+    // scatter one super-chunk of the current group into the D / S tiles
+    auto process_sc = [&](const unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc) {
+#pragma unroll
+        for (int c = 0; c < SC; ++c) {
+            const unsigned c0 = (sc * SC + c) * 64;
+            if (c0 >= total) break;  // wave-uniform
+            if (a.ablate & 1) {      // bench-only: stream the entries, no scatter
+                asm volatile("" ::"v"(buf[c]));
+                continue;
+            }
+            const unsigned p = c0 + lane;
+            const bool valid = p < total;
+            const unsigned ent = buf[c];
+            const unsigned term = ent & 0xffffu;
+            const unsigned word = bitmap[term >> 5];
+            const unsigned bit = 1u << (term & 31);
+            const bool hit = valid && (word & bit);
+            if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;  // wave-uniform
+            // document of the entry = number of row pointers rel[1..32] that are <= p.  The chunk's first entry sits in
+            // document fd (one ballot + popcount over the row pointers held one per lane); a 64-entry chunk rarely
+            // contains more than one or two document boundaries, which are walked with wave-uniform v_readlane.
+            int fd = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane >= 1 && lane <= 32 && rel <= c0));
+            int dd = fd;
+            for (int nb = fd + 1; nb <= 32; ++nb) {
+                const unsigned bpos = __builtin_amdgcn_readlane(rel, nb);
+                if (bpos > c0 + 63u) break;
+                dd += p >= bpos ? 1 : 0;
+            }
+            if (dd > 31) dd = 31;  // (only lanes past the group's end, which are not hits)
+            if (hit) {
+                const int slot = (int)prefix[term >> 5] + __builtin_popcount(word & (bit - 1u));
+                const unsigned info = sinfo[slot];
+                if (info & 0x80000000u) {  // head term: one fp16 store into the dense tile
+                    const unsigned hx = info & 63u;
+                    const int g = ((dd >> 1) & 1) | ((dd >> 3) << 1);
+                    *reinterpret_cast<unsigned short*>(Dt + (dd >> 3) * 1024 + (dd & 7) * 128 + (((hx >> 3) ^ g) << 4) +
+                                                       (hx & 7) * 2) = (unsigned short)(ent >> 16);
+                } else {  // tail term: walk its (query, weight) pairs
+                    const float val = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent >> 16));
+                    const unsigned off = info >> 8, n = info & 0xffu;
+                    float* srow = St + dd * 64;
+                    for (unsigned pp = 0; pp < n; ++pp) {
+                        const unsigned pr = pairs[off + pp];
+                        const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+                        atomicAdd(&srow[pr & 63u], val * w);
+                    }
+                }
+            }
+        }
+    };
+
+    long long n_groups_seen = 0;
+    long long base, nbase;
+    unsigned rel, nrel;
+    load_group(grp_lo, base, rel);
+    unsigned bufA[SC], bufB[SC];
+    issue_sc(bufA, a.entries + base, __builtin_amdgcn_readlane(rel, 32), 0u);
+    for (long long grp = grp_lo; grp < grp_hi; ++grp, ++n_groups_seen) {
+        const long long g0 = grp * 32;
+        const unsigned total = __builtin_amdgcn_readlane(rel, 32);
+        const unsigned nsc = (total + SC * 64 - 1) / (SC * 64);
+        const unsigned nsc_eff = nsc < 2 ? 2u : ((nsc + 1) & ~1u);  // processed in pairs: A -> B -> A
+        load_group(grp + 1, nbase, nrel);  // (used by the last prefetch of this group)
+        // ---- clear the tiles
+        {
+            const uint4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 12; ++i) *reinterpret_cast<uint4*>(Dt + i * 1024 + lane * 16) = z;
+        }
+        const unsigned* ent_base = a.entries + base;
+        // ---- scatter phase, software-pipelined over super-chunks: while one buffer is scattered the next
+        // super-chunk (of this group, or the first one of the wave's next group) is in flight
+        for (unsigned sc = 0; sc < nsc_eff; sc += 2) {
+            issue_sc(bufB, ent_base, total, sc + 1);  // (all-invalid past the group's end: no memory traffic)
+            process_sc(bufA, rel, total, sc);
+            if (sc + 2 < nsc_eff)
+                issue_sc(bufA, ent_base, total, sc + 2);
+            else
+                issue_sc(bufA, a.entries + nbase, __builtin_amdgcn_readlane(nrel, 32), 0u);
+            process_sc(bufB, rel, total, sc + 1);
+        }
+        // ---- scores = S + D . WhT^T
+        floatx16 acc[2];
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[w2][v] = St[((v & 3) + 8 * (v >> 2) + 4 * h) * 64 + w2 * 32 + ql];
+        half8 df[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) df[s] = *reinterpret_cast<const half8*>(Dt + d_off[s]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(df[s], wf[w2][s], acc[w2], 0, 0, 0);
+
+        // ---- threshold filter (as the dense scan: lane (query, half) holds 16 documents per 32-query block)
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            if (a.ablate & 2) {  // bench-only: no candidate handling
+                asm volatile("" ::"v"(acc[w2]));
+                continue;
+            }
+            float m = acc[w2][0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[w2][v]);
+            if (__builtin_amdgcn_ballot_w64(m > thr[w2]) != 0ull) {
+                u64 need = __builtin_amdgcn_ballot_w64(cnt[w2] > (unsigned)(CAP - 32)) & 0xffffffffull;
+                while (need) {
+                    const int qq = __builtin_ctzll(need);
+                    need &= need - 1;
+                    compact(w2, qq);
+                }
+                u64* buf = cand_w + (size_t)(w2 * 32 + ql) * CAP;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const long long row = g0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    const bool hit = (acc[w2][v] > thr[w2]) && (row < a.n_rows);
+                    const u64 hm = __builtin_amdgcn_ballot_w64(hit);
+                    if (hm != 0ull) {
+                        const unsigned hl = ((unsigned)hm >> ql) & 1u;
+                        const unsigned hh = ((unsigned)(hm >> 32) >> ql) & 1u;
+                        if (hit) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
+                        cnt[w2] += hl + hh;
+                    }
+                }
+            }
+        }
+        // ---- pick up bounds published by other waves (workgroup: LDS, chip: global), now and then
+        if ((n_groups_seen & 3) == 3) {
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                unsigned b = thr_lds[w2 * 32 + ql];
+                if ((n_groups_seen & 15) == 15) {
+                    const unsigned gl = __hip_atomic_load(a.gthr + w2 * 32 + ql, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (b > gl && h == 0)
+                        __hip_atomic_fetch_max(a.gthr + w2 * 32 + ql, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b = b > gl ? b : gl;
+                }
+                // a document that TIES another wave's bound may still win on row index: inclusive compare
+                if (b > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(b - 1u));
+            }
+        }
+        base = nbase;
+        rel = nrel;
+    }
+
+    // ---- final: every wave sorts its buffers, then the workgroup folds its 8 lists per query
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+        for (int qq = 0; qq < 32; ++qq) {
+            const unsigned n = __builtin_amdgcn_readlane(cnt[w2], qq);
+            u64* buf = cand_w + (size_t)(w2 * 32 + qq) * CAP;
+            u64 e[EPLC];
+            load_keys_m<EPLC>(e, buf, n, lane);
+            bh_wave_sort_desc<EPLC>(e, lane);
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) buf[r * 64 + lane] = e[r];
+        }
+    __syncthreads();
+    for (int qi = wave; qi < 64; qi += NWV) {
+        u64 best[EPLK];
+#pragma unroll
+        for (int r = 0; r < EPLK; ++r) best[r] = 0ull;
+        for (int w2 = 0; w2 < NWV; ++w2) {
+            const u64* lst = a.cand + ((size_t)((long long)blockIdx.x * NWV + w2) * 64 + qi) * CAP;
+            u64 bb[EPLK];
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) bb[r] = lst[r * 64 + lane];
+            bh_wave_merge_top<EPLK>(best, bb, lane);
+        }
+        u64* out = a.partial + ((size_t)blockIdx.x * 64 + qi) * KP;
+#pragma unroll
+        for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = best[r];
+    }
+}
+
+hipError_t bh_launch_csr_scan_mfma(const BhCsrMfmaArgs& a, int kp, int grid, size_t smem, hipStream_t stream) {
+    static size_t attr[2] = {0, 0};
+    const void* fn = kp == 64 ? reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<64>)
+                              : reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<128>);
+    size_t& done = attr[kp == 64 ? 0 : 1];
+    if (smem > done) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        done = smem;
+    }
+    if (kp == 64)
+        hipLaunchKernelGGL(bh_csr_scan_mfma_kernel<64>, dim3(grid), dim3(512), smem, stream, a);
+    else if (kp == 128)
+        hipLaunchKernelGGL(bh_csr_scan_mfma_kernel<128>, dim3(grid), dim3(512), smem, stream, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -202,6 +202,12 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "ring_variant") {
         if (value < 0 || value > 4) return fail(BH_EINVAL, "ring_variant must be 0..4");
         g_opt.ring_variant = (int)value;
+    } else if (s == "sparse_kernel") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_kernel must be 0 (broadcast) or 1 (mfma)");
+        bh_sparse_set_kernel((int)value);
+    } else if (s == "sparse_ablate") {
+        if (value < 0 || value > 3) return fail(BH_EINVAL, "sparse_ablate must be 0..3");
+        bh_sparse_set_ablate((int)value);
     } else if (s == "gemm_stagger_phases") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");
         bh_gemm_set_stagger((int)value, -1);

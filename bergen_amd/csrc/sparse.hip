@@ -32,13 +32,17 @@ struct bh_sparse_index {
     BhDevBuf<bh_u64> cand, partial;
     BhDevBuf<unsigned> gthr, bitmap;
     BhDevBuf<unsigned short> prefix;
-    BhDevBuf<_Float16> W, qdense;
+    BhDevBuf<_Float16> W, qdense, WhT;
+    BhDevBuf<unsigned> sinfo, pairs;
     BhDevBuf<unsigned char> outbuf;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bh_counters counters{};
 };
 
 namespace {
+
+int g_sparse_ablate = 0;
+int g_sparse_kernel = 1;  // 1 = csr_mfma.hip (head terms through MFMA), 0 = csr_topk.hip (broadcast per hit)
 
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kTileQ = 64;
@@ -83,6 +87,9 @@ int pick_kp_sparse(int k) {
 }
 
 }  // namespace
+
+void bh_sparse_set_kernel(int which) { g_sparse_kernel = which ? 1 : 0; }
+void bh_sparse_set_ablate(int bits) { g_sparse_ablate = bits; }
 
 extern "C" {
 
@@ -131,6 +138,9 @@ void bh_sparse_destroy(bh_sparse_index* ix) {
     ix->prefix.release();
     ix->W.release();
     ix->qdense.release();
+    ix->WhT.release();
+    ix->sinfo.release();
+    ix->pairs.release();
     ix->outbuf.release();
     for (auto& e : ix->ev)
         if (e) (void)hipEventDestroy(e);
@@ -227,7 +237,6 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     if (max_slots < 8) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile weights", V);
     const int grid = ix->n_cu;
     int rc;
-    if ((rc = ix->cand.ensure((size_t)grid * 16 * 64 * 2 * kp))) return rc;
     if ((rc = ix->partial.ensure((size_t)grid * 64 * kp))) return rc;
     if ((rc = ix->gthr.ensure(64))) return rc;
     if ((rc = ix->bitmap.ensure((size_t)n_words))) return rc;
@@ -246,15 +255,29 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     hipStream_t st = ix->stream;
     const unsigned short* q16 = static_cast<const unsigned short*>(q_host);
     const float* q32 = static_cast<const float*>(q_host);
-    auto qbits = [&](int q, int t) -> unsigned short {
-        return q_dtype == BH_F16 ? q16[(size_t)q * V + t] : f32_to_f16_bits(q32[(size_t)q * V + t]);
-    };
+    // non-zero terms of every query, once (fp16 bit patterns)
+    std::vector<std::vector<std::pair<int, unsigned short>>> qnz((size_t)nq);
+    for (int q = 0; q < nq; ++q)
+        for (int t = 0; t < V; ++t) {
+            const unsigned short b = q_dtype == BH_F16 ? q16[(size_t)q * V + t] : f32_to_f16_bits(q32[(size_t)q * V + t]);
+            if (b & 0x7fffu) qnz[(size_t)q].emplace_back(t, b);
+        }
+    const bool mfma = g_sparse_kernel == 1;
+    const int waves_per_wg = mfma ? 8 : 16;
+    if ((rc = ix->cand.ensure((size_t)grid * waves_per_wg * 64 * 2 * kp))) return rc;
+    // LDS budget of the MFMA kernel: tables + 8 waves x (4 KiB D tile + 8 KiB S tile)
+    const int mfma_fixed = n_words * 6 + 16 + 256 + 8 * 12288;
+    const int mfma_table_bytes = kLdsBytes - mfma_fixed;  // for sinfo (4 B per slot) + pairs (4 B per pair)
+    if (mfma && mfma_table_bytes < 4096) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile tables", V);
 
     std::vector<unsigned> bm((size_t)n_words);
     std::vector<unsigned short> pf((size_t)n_words);
     std::vector<unsigned short> Wh((size_t)(max_slots + 1) * 64);
     std::vector<unsigned short> qd((size_t)kTileQ * V);
     std::vector<unsigned> gt(64, 0x007fffffu);
+    std::vector<int> term_cnt((size_t)V, 0);
+    std::vector<unsigned> sinfo_h, pairs_h;
+    std::vector<unsigned short> WhT_h((size_t)64 * 64);
     bh_counters& c = ix->counters;
     c = bh_counters{};
     c.n_rows = ix->n_rows;
@@ -268,22 +291,24 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     BH_HIP_TRY(hipEventRecord(ix->ev[0], st));
     int q0 = 0;
     while (q0 < nq) {
-        // ---- tile: as many queries as fit (<= 64 queries, <= max_slots distinct terms)
+        // ---- tile: as many queries as fit (<= 64 queries; distinct terms / pairs within the kernel's LDS budget)
         std::fill(bm.begin(), bm.end(), 0u);
-        int nt = 0, n_slots = 0;
+        int nt = 0, n_slots = 0, n_pairs_tot = 0;
         while (q0 + nt < nq && nt < kTileQ) {
+            const auto& nz = qnz[(size_t)(q0 + nt)];
             int add = 0;
-            const int q = q0 + nt;
-            for (int t = 0; t < V; ++t)
-                if ((qbits(q, t) & 0x7fffu) && !(bm[t >> 5] >> (t & 31) & 1u)) ++add;
-            if (n_slots + add > max_slots) {
+            for (auto& tv : nz)
+                if (!(bm[tv.first >> 5] >> (tv.first & 31) & 1u)) ++add;
+            const bool fits = mfma ? ((n_slots + add) * 4 + (n_pairs_tot + (int)nz.size()) * 4 <= mfma_table_bytes)
+                                   : (n_slots + add <= max_slots);
+            if (!fits) {
                 if (nt == 0)
-                    return bh_fail(BH_EUNSUPPORTED, "query %d has %d non-zero terms; at most %d fit the LDS tile", q, add, max_slots);
+                    return bh_fail(BH_EUNSUPPORTED, "query %d has %d non-zero terms: too many for the LDS tile", q0, (int)nz.size());
                 break;
             }
-            for (int t = 0; t < V; ++t)
-                if (qbits(q, t) & 0x7fffu) bm[t >> 5] |= 1u << (t & 31);
+            for (auto& tv : nz) bm[tv.first >> 5] |= 1u << (tv.first & 31);
             n_slots += add;
+            n_pairs_tot += (int)nz.size();
             ++nt;
         }
         int run = 0;
@@ -291,40 +316,109 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             pf[w] = (unsigned short)run;
             run += __builtin_popcount(bm[w]);
         }
-        std::fill(Wh.begin(), Wh.begin() + (size_t)(n_slots + 1) * 64, (unsigned short)0);
+        auto slot_of = [&](int t) { return (int)pf[t >> 5] + __builtin_popcount(bm[t >> 5] & ((1u << (t & 31)) - 1u)); };
         std::fill(qd.begin(), qd.begin() + (size_t)nt * V, (unsigned short)0);
         for (int j = 0; j < nt; ++j)
-            for (int t = 0; t < V; ++t) {
-                const unsigned short b = qbits(q0 + j, t);
-                if (!(b & 0x7fffu)) continue;
-                const int slot = pf[t >> 5] + __builtin_popcount(bm[t >> 5] & ((1u << (t & 31)) - 1u));
-                Wh[(size_t)slot * 64 + j] = b;
-                qd[(size_t)j * V + t] = b;
-            }
+            for (auto& tv : qnz[(size_t)(q0 + j)]) qd[(size_t)j * V + tv.first] = tv.second;
         BH_HIP_TRY(hipMemcpyAsync(ix->bitmap.p, bm.data(), (size_t)n_words * 4, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->prefix.p, pf.data(), (size_t)n_words * 2, hipMemcpyHostToDevice, st));
-        BH_HIP_TRY(hipMemcpyAsync(ix->W.p, Wh.data(), (size_t)(n_slots + 1) * 128, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->qdense.p, qd.data(), (size_t)nt * V * 2, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->gthr.p, gt.data(), 64 * 4, hipMemcpyHostToDevice, st));
-        BhCsrScanArgs sa{};
-        sa.entries = ix->entries.p;
-        sa.row_ptr = ix->row_ptr.p;
-        sa.n_rows = ix->n_rows;
-        sa.bitmap = ix->bitmap.p;
-        sa.prefix = ix->prefix.p;
-        sa.W = ix->W.p;
-        sa.n_words = n_words;
-        sa.n_slots = n_slots;
-        sa.off_prefix = off_prefix;
-        sa.off_w = off_w;
-        sa.off_thr = off_w + (n_slots + 1) * 128;
-        sa.cand = ix->cand.p;
-        sa.partial = ix->partial.p;
-        sa.gthr = ix->gthr.p;
-        const size_t smem = (size_t)sa.off_thr + 256;
-        // (the host copies above are staged synchronously by the runtime: pageable memory)
         BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
-        BH_HIP_TRY(bh_launch_csr_scan(sa, kp, grid, smem, st));
+        if (!mfma) {
+            std::fill(Wh.begin(), Wh.begin() + (size_t)(n_slots + 1) * 64, (unsigned short)0);
+            for (int j = 0; j < nt; ++j)
+                for (auto& tv : qnz[(size_t)(q0 + j)]) Wh[(size_t)slot_of(tv.first) * 64 + j] = tv.second;
+            BH_HIP_TRY(hipMemcpyAsync(ix->W.p, Wh.data(), (size_t)(n_slots + 1) * 128, hipMemcpyHostToDevice, st));
+            BhCsrScanArgs sa{};
+            sa.entries = ix->entries.p;
+            sa.row_ptr = ix->row_ptr.p;
+            sa.n_rows = ix->n_rows;
+            sa.bitmap = ix->bitmap.p;
+            sa.prefix = ix->prefix.p;
+            sa.W = ix->W.p;
+            sa.n_words = n_words;
+            sa.n_slots = n_slots;
+            sa.off_prefix = off_prefix;
+            sa.off_w = off_w;
+            sa.off_thr = off_w + (n_slots + 1) * 128;
+            sa.cand = ix->cand.p;
+            sa.partial = ix->partial.p;
+            sa.gthr = ix->gthr.p;
+            BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+            BH_HIP_TRY(bh_launch_csr_scan(sa, kp, grid, (size_t)sa.off_thr + 256, st));
+        } else {
+            // head = the (up to) 64 terms used by the most queries of the tile; the rest are tail terms with pair lists
+            std::vector<int> terms;
+            for (int j = 0; j < nt; ++j)
+                for (auto& tv : qnz[(size_t)(q0 + j)])
+                    if (term_cnt[(size_t)tv.first]++ == 0) terms.push_back(tv.first);
+            std::vector<int> order(terms);
+            std::sort(order.begin(), order.end(), [&](int x, int y) {
+                return term_cnt[(size_t)x] != term_cnt[(size_t)y] ? term_cnt[(size_t)x] > term_cnt[(size_t)y] : x < y;
+            });
+            const int n_head = (int)std::min<size_t>(64, order.size());
+            sinfo_h.assign((size_t)std::max(1, n_slots), 0u);
+            pairs_h.clear();
+            std::fill(WhT_h.begin(), WhT_h.end(), (unsigned short)0);
+            // tail pair lists: offsets by slot
+            std::vector<int> head_idx_of_slot((size_t)std::max(1, n_slots), -1);
+            for (int i = 0; i < n_head; ++i) head_idx_of_slot[(size_t)slot_of(order[(size_t)i])] = i;
+            std::vector<unsigned> off((size_t)n_slots + 1, 0u);
+            for (int t : terms) {
+                const int sl = slot_of(t);
+                if (head_idx_of_slot[(size_t)sl] < 0) off[(size_t)sl + 1] = (unsigned)term_cnt[(size_t)t];
+            }
+            for (int i2 = 0; i2 < n_slots; ++i2) off[(size_t)i2 + 1] += off[(size_t)i2];
+            pairs_h.assign((size_t)std::max<unsigned>(1u, off[(size_t)n_slots]), 0u);
+            std::vector<unsigned> fill(off.begin(), off.end() - 1);
+            for (int j = 0; j < nt; ++j)
+                for (auto& tv : qnz[(size_t)(q0 + j)]) {
+                    const int sl = slot_of(tv.first);
+                    const int hi = head_idx_of_slot[(size_t)sl];
+                    if (hi >= 0)
+                        WhT_h[(size_t)j * 64 + hi] = tv.second;
+                    else
+                        pairs_h[(size_t)fill[(size_t)sl]++] = ((unsigned)tv.second << 16) | (unsigned)j;
+                }
+            for (int i2 = 0; i2 < n_slots; ++i2) {
+                const int hi = head_idx_of_slot[(size_t)i2];
+                sinfo_h[(size_t)i2] = hi >= 0 ? (0x80000000u | (unsigned)hi) : ((off[(size_t)i2] << 8) | (off[(size_t)i2 + 1] - off[(size_t)i2]));
+            }
+            for (int t : terms) term_cnt[(size_t)t] = 0;
+            const int n_pairs = (int)off[(size_t)n_slots];
+            if ((rc = ix->sinfo.ensure(sinfo_h.size()))) return rc;
+            if ((rc = ix->pairs.ensure(pairs_h.size()))) return rc;
+            if ((rc = ix->WhT.ensure(64 * 64))) return rc;
+            BH_HIP_TRY(hipMemcpyAsync(ix->sinfo.p, sinfo_h.data(), sinfo_h.size() * 4, hipMemcpyHostToDevice, st));
+            BH_HIP_TRY(hipMemcpyAsync(ix->pairs.p, pairs_h.data(), pairs_h.size() * 4, hipMemcpyHostToDevice, st));
+            BH_HIP_TRY(hipMemcpyAsync(ix->WhT.p, WhT_h.data(), 64 * 64 * 2, hipMemcpyHostToDevice, st));
+            BhCsrMfmaArgs ma2{};
+            ma2.entries = ix->entries.p;
+            ma2.row_ptr = ix->row_ptr.p;
+            ma2.n_rows = ix->n_rows;
+            ma2.bitmap = ix->bitmap.p;
+            ma2.prefix = ix->prefix.p;
+            ma2.sinfo = ix->sinfo.p;
+            ma2.pairs = ix->pairs.p;
+            ma2.WhT = ix->WhT.p;
+            ma2.n_words = n_words;
+            ma2.n_slots = n_slots;
+            ma2.n_pairs = n_pairs;
+            ma2.off_prefix = n_words * 4;
+            ma2.off_sinfo = (ma2.off_prefix + n_words * 2 + 15) / 16 * 16;
+            ma2.off_pairs = ma2.off_sinfo + n_slots * 4;
+            ma2.off_thr = ma2.off_pairs + n_pairs * 4;
+            ma2.off_tiles = (ma2.off_thr + 256 + 15) / 16 * 16;
+            ma2.cand = ix->cand.p;
+            ma2.partial = ix->partial.p;
+            ma2.gthr = ix->gthr.p;
+            ma2.ablate = g_sparse_ablate;
+            const size_t smem2 = (size_t)ma2.off_tiles + 8 * 12288;
+            if (smem2 > (size_t)kLdsBytes) return bh_fail(BH_EHIP, "internal: sparse tile exceeds LDS (%zu bytes)", smem2);
+            BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+            BH_HIP_TRY(bh_launch_csr_scan_mfma(ma2, kp, grid, smem2, st));
+        }
         BH_HIP_TRY(hipEventRecord(ix->ev[2], st));
         BhCsrMergeArgs ma{};
         ma.partial = ix->partial.p;
@@ -346,7 +440,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         scan_ms += ms;
         BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]));
         merge_ms += ms;
-        // nnz*(2+2) + (N+1)*8 per query-tile pass (+ the tile's own tables and results)
+        // nnz*(2+2) + (N+1)*8 per query-tile pass (+ the tile's results)
         bytes += (double)ix->nnz * 4.0 + (double)(ix->n_rows + 1) * 8.0 + (double)nt * k * 12.0;
         ++n_pass;
         q0 += nt;

@@ -24,10 +24,14 @@ def main():
     ap.add_argument("--block", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=256)
     ap.add_argument("--k", type=int, default=50)
+    ap.add_argument("--kernel", type=int, default=1, help="1 = csr_mfma.hip (default), 0 = csr_topk.hip")
+    ap.add_argument("--ablate", action="store_true", help="also time the bench-only ablations of the scan kernel")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sparse_bench.json"))
     args = ap.parse_args()
     import bergen_amd
-    from bergen_amd import synth
+    from bergen_amd import _lib, synth
+    _lib.init(0)
+    _lib.set_option("sparse_kernel", args.kernel)
     V = 30522
     t0 = time.perf_counter()
     blk = synth.random_sparse_corpus_fast(args.block, V, seed=4)
@@ -53,6 +57,14 @@ def main():
         if best is None or dt < best[0]:
             best = (dt, c)
     dt, c = best
+    abl = {}
+    if args.ablate:
+        for bits, what in ((1, "no scatter (stream + MFMA + candidates)"), (2, "no candidate handling"), (3, "stream + MFMA only")):
+            _lib.set_option("sparse_ablate", bits)
+            ix.search(q, args.k)
+            ca = ix.counters()
+            abl[what] = ca["scan_ms"] / ca["n_passes"]
+        _lib.set_option("sparse_ablate", 0)
     gbps = c["algorithmic_bytes"] / (c["scan_ms"] * 1e-3) / 1e9
     # parity spot check on the first block (ids of later copies of the same rows tie and sort after)
     from oracle import c_oracle
@@ -63,12 +75,12 @@ def main():
     s2, i2 = sub.search(q[:8], args.k)
     ws, wi = c_oracle.sparse_canonical_search(blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]], V, q[:8], args.k)
     ok = bool(np.array_equal(i2, wi) and np.array_equal(s2.view(np.uint32), ws.view(np.uint32)))
-    res = {"docs": args.docs, "nnz": ix.nnz, "vocab": V, "queries": args.queries, "k": args.k,
+    res = {"kernel": "csr_mfma" if args.kernel else "csr_topk (broadcast)", "docs": args.docs, "nnz": ix.nnz, "vocab": V, "queries": args.queries, "k": args.k,
            "queries_per_s": args.queries / dt, "wall_ms": dt * 1e3, "passes": c["n_passes"],
            "scan_ms_per_pass": c["scan_ms"] / c["n_passes"], "merge_ms_per_pass": c["merge_ms"] / c["n_passes"],
            "roofline": {"bound": "hbm", "kernel": "bh_csr_scan_topk_kernel", "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
                         "frac": gbps / 8000.0, "algorithmic_bytes_per_launch": c["algorithmic_bytes"] / c["n_passes"]},
-           "generate_s": gen_s, "upload_s": up_s, "parity_spot_check": "pass" if ok else "FAIL"}
+           "ablation_scan_ms_per_pass": abl, "generate_s": gen_s, "upload_s": up_s, "parity_spot_check": "pass" if ok else "FAIL"}
     print(json.dumps(res), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(res, open(args.out, "w"), indent=1)

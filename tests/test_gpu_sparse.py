@@ -25,10 +25,15 @@ def _index(amd, indptr, terms, w, V, pieces=1):
     return ix.finalize()
 
 
-@pytest.fixture(scope="module")
-def amd():
+@pytest.fixture(scope="module", params=[1, 0], ids=["mfma-kernel", "broadcast-kernel"])
+def amd(request):
+    """Both scan kernels (csr_mfma.hip = default, csr_topk.hip) must give the same bit-exact results."""
     import bergen_amd
-    return bergen_amd
+    from bergen_amd import _lib
+    _lib.init(0)
+    _lib.set_option("sparse_kernel", request.param)
+    yield bergen_amd
+    _lib.set_option("sparse_kernel", 1)
 
 
 def test_golden_fixture(amd):
