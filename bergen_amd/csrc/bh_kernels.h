@@ -66,6 +66,12 @@ struct BhGemmArgs {
     int bias_mode;
     int gelu;    // erf-GELU on the result
     int swap_b;  // filled by the launcher: direction of v_permlane32_swap on this device
+    // segmented-max epilogue (persistent kernel, SPLADE head): C is not stored; relu(C + bias) is max-reduced over the
+    // COLUMNS (packed tokens) of each sequence into seg_out[sequence][m] (uint32 view of non-negative floats, zeroed
+    // by the caller).  seg_grp[n / 8] = sequence << 4 | number of valid tokens among columns 8(n/8) .. 8(n/8)+7.
+    const int* seg_grp;
+    unsigned* seg_out;
+    long long ld_seg;
     long long c_block_rows;  // != 0: C is stored blocked by 64 columns with this many rows per block (persistent kernel only)
     int stagger_phases, stagger_unit, stagger_first_round;  // start stagger of the first round of blocks (0 = off)
 };
@@ -188,3 +194,11 @@ struct BhCsrMfmaArgs {
 hipError_t bh_launch_csr_scan_mfma(const BhCsrMfmaArgs& a, int kp, int grid, size_t smem, hipStream_t stream);
 void bh_sparse_set_kernel(int which);  // 1 = csr_mfma.hip (default), 0 = csr_topk.hip
 void bh_sparse_set_ablate(int bits);   // bench-only
+
+struct BhSpladeFinishArgs {
+    const unsigned* seg;  // [batch][ld_seg] max over the sequence's tokens of relu(logit), as uint32 bit patterns
+    long long ld_seg;
+    _Float16* out;        // [batch][vocab] = log(1 + max)
+    int batch, vocab;
+};
+hipError_t bh_launch_splade_finish(const BhSpladeFinishArgs& a, hipStream_t stream);

@@ -58,6 +58,14 @@ struct bh_encoder {
     int gemm_variant = 0;
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
+    BhDevBuf<unsigned> SEG;  // SPLADE head: per (sequence, term) running max of relu(logit)
+    // optional masked-LM head (BertOnlyMLMHead: transform dense + GELU + LayerNorm, decoder); SPLADE pooling (pool 3)
+    _Float16* mlm_arena = nullptr;
+    _Float16 *mlm_wt = nullptr, *mlm_bt = nullptr, *mlm_g = nullptr, *mlm_b = nullptr, *mlm_wdec = nullptr, *mlm_bdec = nullptr;
+    int vpad = 0;  // decoder rows padded to whole 256-row tiles (zero weights, zero bias)
+    std::map<std::string, std::pair<_Float16*, int64_t>> mlm_slots;
+    std::map<std::string, bool> mlm_have;
+    bool has_mlm = false;
     BhDevBuf<int> ibuf;          // tok | pos | typ | seq_len | slot
     BhDevBuf<long long> seq_off;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -129,6 +137,39 @@ int build_slots(bh_encoder* e) {
         S[pre + "output.LayerNorm.bias"] = {L.ln2b, (int64_t)d};
     }
     if ((size_t)(p - e->arena) > total) return bh_fail(BH_EHIP, "internal: weight arena overflow");
+    return BH_OK;
+}
+
+// The MLM head's weights live in their own arena, allocated when the first cls.predictions.* tensor arrives
+// (a plain BertModel checkpoint never pays for it).
+int build_mlm_slots(bh_encoder* e) {
+    if (e->mlm_arena) return BH_OK;
+    const bh_encoder_config& c = e->cfg;
+    const size_t d = c.hidden;
+    e->vpad = round_up(c.vocab_size, 256);
+    const size_t total = d * d + 3 * d + (size_t)e->vpad * d + (size_t)e->vpad + 64;
+    BH_HIP_TRY(hipSetDevice(e->device));
+    BH_HIP_TRY(hipMalloc((void**)&e->mlm_arena, total * sizeof(_Float16)));
+    BH_HIP_TRY(hipMemset(e->mlm_arena, 0, total * sizeof(_Float16)));
+    _Float16* p = e->mlm_arena;
+    auto take = [&](size_t n) {
+        _Float16* r = p;
+        p += (n + 7) / 8 * 8;
+        return r;
+    };
+    e->mlm_wt = take(d * d);
+    e->mlm_bt = take(d);
+    e->mlm_g = take(d);
+    e->mlm_b = take(d);
+    e->mlm_wdec = take((size_t)e->vpad * d);
+    e->mlm_bdec = take((size_t)e->vpad);
+    auto& S = e->mlm_slots;
+    S["cls.predictions.transform.dense.weight"] = {e->mlm_wt, (int64_t)(d * d)};
+    S["cls.predictions.transform.dense.bias"] = {e->mlm_bt, (int64_t)d};
+    S["cls.predictions.transform.LayerNorm.weight"] = {e->mlm_g, (int64_t)d};
+    S["cls.predictions.transform.LayerNorm.bias"] = {e->mlm_b, (int64_t)d};
+    S["cls.predictions.decoder.weight"] = {e->mlm_wdec, (int64_t)c.vocab_size * (int64_t)d};
+    S["cls.predictions.decoder.bias"] = {e->mlm_bdec, (int64_t)c.vocab_size};
     return BH_OK;
 }
 
@@ -209,7 +250,9 @@ void bh_encoder_destroy(bh_encoder* e) {
     e->OUT.release();
     e->ibuf.release();
     e->seq_off.release();
+    e->SEG.release();
     if (e->arena) (void)hipFree(e->arena);
+    if (e->mlm_arena) (void)hipFree(e->mlm_arena);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -223,7 +266,17 @@ int bh_encoder_set_tensor(bh_encoder* e, const char* name, const void* host, int
     for (const char* pre : {"bert.", "model."})  // tolerate task-model prefixes
         if (key.rfind(pre, 0) == 0 && !e->slots.count(key)) key = key.substr(strlen(pre));
     auto it = e->slots.find(key);
-    if (it == e->slots.end()) return bh_fail(BH_EINVAL, "unknown tensor '%s'", name);
+    bool is_mlm = false;
+    if (it == e->slots.end() && key.rfind("cls.predictions.", 0) == 0) {
+        if (key == "cls.predictions.bias") key = "cls.predictions.decoder.bias";  // HF keeps the same tensor under both names
+        int rc = build_mlm_slots(e);
+        if (rc) return rc;
+        it = e->mlm_slots.find(key);
+        if (it == e->mlm_slots.end()) return bh_fail(BH_EINVAL, "unknown tensor '%s'", name);
+        is_mlm = true;
+    } else if (it == e->slots.end()) {
+        return bh_fail(BH_EINVAL, "unknown tensor '%s'", name);
+    }
     if (it->second.second != numel)
         return bh_fail(BH_EINVAL, "tensor '%s': expected %lld elements, got %lld", name, (long long)it->second.second,
                        (long long)numel);
@@ -236,7 +289,7 @@ int bh_encoder_set_tensor(bh_encoder* e, const char* name, const void* host, int
         for (int64_t i = 0; i < numel; ++i) tmp[(size_t)i] = (_Float16)src[i];  // round-to-nearest-even, like .half()
         BH_HIP_TRY(hipMemcpy(it->second.first, tmp.data(), (size_t)numel * 2, hipMemcpyHostToDevice));
     }
-    e->have[key] = true;
+    (is_mlm ? e->mlm_have : e->have)[key] = true;
     e->committed = false;
     return BH_OK;
 }
@@ -245,6 +298,18 @@ int bh_encoder_commit(bh_encoder* e) {
     if (!e) return bh_fail(BH_EINVAL, "null encoder");
     for (auto& kv : e->slots)
         if (!e->have.count(kv.first)) return bh_fail(BH_EINCOMPLETE, "encoder weight '%s' was never set", kv.first.c_str());
+    e->has_mlm = false;
+    if (e->mlm_arena) {
+        for (const char* k : {"cls.predictions.transform.dense.weight", "cls.predictions.transform.dense.bias",
+                              "cls.predictions.transform.LayerNorm.weight", "cls.predictions.transform.LayerNorm.bias"})
+            if (!e->mlm_have.count(k)) return bh_fail(BH_EINCOMPLETE, "MLM head weight '%s' was never set", k);
+        if (!e->mlm_have.count("cls.predictions.decoder.weight")) {
+            // tied decoder (config.tie_word_embeddings, the BERT default): the word-embedding matrix
+            BH_HIP_TRY(hipSetDevice(e->device));
+            BH_HIP_TRY(hipMemcpy(e->mlm_wdec, e->word, (size_t)e->cfg.vocab_size * e->cfg.hidden * 2, hipMemcpyDeviceToDevice));
+        }
+        e->has_mlm = true;  // a missing decoder bias stays zero
+    }
     e->committed = true;
     return BH_OK;
 }
@@ -265,7 +330,8 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if (!e) return bh_fail(BH_EINVAL, "null encoder");
     if (!e->committed) return bh_fail(BH_EINCOMPLETE, "encoder weights not committed (bh_encoder_commit)");
     if (batch < 0 || seq_len <= 0) return bh_fail(BH_EINVAL, "batch=%d seq_len=%d", batch, seq_len);
-    if (pool < 0 || pool > 2) return bh_fail(BH_EINVAL, "pool must be 0 (cls), 1 (mean) or 2 (hidden states)");
+    if (pool < 0 || pool > 3) return bh_fail(BH_EINVAL, "pool must be 0 (cls), 1 (mean), 2 (hidden states) or 3 (splade)");
+    if (pool == 3 && !e->has_mlm) return bh_fail(BH_EINCOMPLETE, "pool 3 (splade) needs the cls.predictions.* weights");
     if (batch == 0) return BH_OK;
     if (!input_ids || !out) return bh_fail(BH_EINVAL, "null buffer");
     const bh_encoder_config& c = e->cfg;
@@ -295,7 +361,8 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     }
     const int m_pad = round_up(cursor + 32, 256);  // +32: the attention's last key block may read past a sequence
     // tok | pos | typ  [m_pad each] | seq_len [batch] | seq_idx [batch] | slot [batch*seq_len] (pool == 2 only)
-    const size_t n_slot = pool == 2 ? (size_t)batch * seq_len : 0;
+    //   (pool == 3: slot is the [m_pad / 8] table of 8-row groups instead: sequence << 4 | valid rows in the group)
+    const size_t n_slot = pool == 2 ? (size_t)batch * seq_len : pool == 3 ? (size_t)m_pad / 8 : 0;
     std::vector<int> ib((size_t)3 * m_pad + 2 * (size_t)batch + n_slot, 0);
     int* tok = ib.data();
     int* pos = tok + m_pad;
@@ -315,6 +382,10 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
                 max_len_long = std::max(max_len_long, len[b]);
             }
     }
+    if (pool == 3)
+        for (int b = 0; b < batch; ++b)
+            for (long long r = off[b]; r < off[b] + len[b]; r += 8)
+                slot[r / 8] = (b << 4) | (int)std::min<long long>(8, off[b] + len[b] - r);
     for (int b = 0; b < batch; ++b) {
         slen[b] = len[b];
         long long r = off[b];
@@ -346,7 +417,8 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if ((rc = e->H.ensure(M * dff))) return rc;
     if ((rc = e->ibuf.ensure(ib.size()))) return rc;
     if ((rc = e->seq_off.ensure(batch))) return rc;
-    const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : (size_t)batch * d;
+    const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size : (size_t)batch * d;
+    if (pool == 3 && (rc = e->SEG.ensure((size_t)batch * e->vpad))) return rc;
     _Float16* out_dev = static_cast<_Float16*>(out);
     if (!out_on_device) {
         if ((rc = e->OUT.ensure(out_elems))) return rc;
@@ -417,7 +489,47 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         la.beta = L.ln2b;
         BH_HIP_TRY(bh_launch_layernorm(la, st));
     }
-    if (pool == 2) {
+    if (pool == 3) {
+        // masked-LM head (BertOnlyMLMHead) + SPLADE pooling, reference models/retrievers/splade.py:36-43:
+        //   T = LayerNorm(GELU(X Wt^T + bt));  logit = T Wdec^T + bdec;  emb[b][v] = max_t log(1 + relu(logit[b][t][v]))
+        // The [tokens][vocab] logits are never written: the decoder GEMM (terms as rows, tokens as columns) keeps a
+        // running per-(sequence, term) max of relu(logit) in its epilogue, and log(1 + .) is applied to the maxima.
+        if ((rc = gemm(e, e->X.p, d, e->mlm_wt, d, e->Y.p, d, m_pad, d, d, e->mlm_bt, 1, nullptr, 0, 1))) return rc;
+        BhLnArgs la{};
+        la.in = e->Y.p;
+        la.residual = nullptr;
+        la.out = e->Y.p;
+        la.n_rows = m_pad;
+        la.d = d;
+        la.eps = c.ln_eps;
+        la.gamma = e->mlm_g;
+        la.beta = e->mlm_b;
+        BH_HIP_TRY(bh_launch_layernorm(la, st));
+        BH_HIP_TRY(hipMemsetAsync(e->SEG.p, 0, (size_t)batch * e->vpad * sizeof(unsigned), st));
+        BhGemmArgs g{};
+        g.A = e->mlm_wdec;
+        g.lda = d;
+        g.B = e->Y.p;
+        g.ldb = d;
+        g.C = e->H.p;  // never written
+        g.ldc = m_pad;
+        g.bias = e->mlm_bdec;
+        g.bias_mode = 2;
+        g.M = e->vpad;
+        g.N = m_pad;
+        g.K = d;
+        g.seg_grp = d_slot;
+        g.seg_out = e->SEG.p;
+        g.ld_seg = e->vpad;
+        BH_HIP_TRY(bh_launch_gemm_f16(g, 0, st));
+        BhSpladeFinishArgs fa{};
+        fa.seg = e->SEG.p;
+        fa.ld_seg = e->vpad;
+        fa.out = out_dev;
+        fa.batch = batch;
+        fa.vocab = c.vocab_size;
+        BH_HIP_TRY(bh_launch_splade_finish(fa, st));
+    } else if (pool == 2) {
         BhUnpackArgs ua{};
         ua.x = e->X.p;
         ua.out = out_dev;
@@ -453,6 +565,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     // algorithmic flops over REAL tokens: per layer 8 T d^2 + 4 T d dff (projections) + 4 sum(len^2) d (attention)
     k.flops = (double)c.n_layers *
               ((double)real_tokens * (8.0 * d * d + 4.0 * d * dff) + 4.0 * len_sq * d);
+    if (pool == 3) k.flops += (double)real_tokens * (2.0 * d * d + 2.0 * d * (double)c.vocab_size);
     return BH_OK;
 }
 

@@ -184,6 +184,24 @@ __global__ void __launch_bounds__(256) bh_unpack_kernel(BhUnpackArgs a) {
     }
 }
 
+// SPLADE pooling, second half: emb[b][v] = log(1 + max_t relu(logit[b][t][v]))  (reference models/retrievers/splade.py:42-43;
+// the max over tokens was taken by the decoder GEMM's epilogue)
+__global__ void __launch_bounds__(256) bh_splade_finish_kernel(BhSpladeFinishArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)a.batch * a.vocab;
+    if (i >= n) return;
+    const int b = (int)(i / a.vocab), v = (int)(i % a.vocab);
+    const float m = __uint_as_float(a.seg[(size_t)b * a.ld_seg + v]);
+    a.out[i] = (_Float16)log1pf(m);
+}
+
+hipError_t bh_launch_splade_finish(const BhSpladeFinishArgs& a, hipStream_t st) {
+    const long long n = (long long)a.batch * a.vocab;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_splade_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t bh_launch_embed_ln(const BhEmbedArgs& a, hipStream_t st) {
     if (a.n_rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(bh_embed_ln_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);

@@ -128,6 +128,11 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     if (a.bias && a.bias_mode == 2) epi |= BH_EPI_BIAS_ROW;
     if (a.residual) epi |= BH_EPI_RESIDUAL;
     if (a.gelu) epi |= BH_EPI_GELU;
+    if (a.seg_out) {  // SPLADE head: whole 256x256 tiles on the persistent kernel, bias per row (vocabulary term)
+        if (!a.seg_grp || a.M % 256 || a.N % 256 || a.residual || a.gelu || !(a.bias && a.bias_mode == 2) || g_swap_b != 0)
+            return hipErrorInvalidValue;
+        return bh_gemm_persist(a, BH_EPI_BIAS_ROW | BH_EPI_SEGMAX, 1, stream);
+    }
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);
     const bool auto_variant = variant == 0;

@@ -23,6 +23,9 @@ int n_cu() {
         case BH_EPI_BIAS_COL: return bh_gemm_launch_persist<BH_EPI_BIAS_COL, P>(a, n_cu(), s);                    \
         case BH_EPI_BIAS_ROW: return bh_gemm_launch_persist<BH_EPI_BIAS_ROW, P>(a, n_cu(), s);                    \
         case BH_EPI_BIAS_COL | BH_EPI_GELU: return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_GELU, P>(a, n_cu(), s); \
+        case BH_EPI_BIAS_ROW | BH_EPI_SEGMAX:                                                                     \
+            if (P == 1) return bh_gemm_launch_persist<BH_EPI_BIAS_ROW | BH_EPI_SEGMAX, 1>(a, n_cu(), s);          \
+            break;                                                                                                \
     }                                                                                                             \
     return hipErrorNotSupported;
 

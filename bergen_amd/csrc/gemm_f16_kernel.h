@@ -9,6 +9,7 @@
 #define BH_EPI_BIAS_ROW 2  // + bias[m]
 #define BH_EPI_RESIDUAL 4  // + residual[m][n]
 #define BH_EPI_GELU 8      // erf-GELU
+#define BH_EPI_SEGMAX 16   // persistent kernel only: no store; relu + per-sequence max into seg_out (SPLADE head)
 
 namespace bh_gemm {
 

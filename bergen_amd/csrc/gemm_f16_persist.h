@@ -289,14 +289,35 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         half8 o;
+                        float vv[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             float v = c[8 * u + e] + bias_row[tm];
                             if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)b8[u][e];
                             if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
                             o[e] = (_Float16)v;
+                            vv[e] = v;
                         }
-                        if constexpr ((PST & 4) != 0) {  // ablation: epilogue math without the stores
+                        (void)vv;
+                        if constexpr ((EPI & BH_EPI_SEGMAX) != 0) {
+                            // SPLADE head (C rows = vocabulary terms, C columns = packed tokens): the lane's 8 values
+                            // are 8 consecutive tokens of ONE sequence (sequences start at multiples of 8 rows), so
+                            // the max over tokens is taken in registers; seg_grp[token / 8] = sequence << 4 | valid
+                            // tokens in the group (0 = gap rows only).  max commutes with the monotone
+                            // log(1 + relu(.)), applied once per (sequence, term) by bh_splade_finish_kernel.
+                            const int g = a.seg_grp[(n0 + (wn * TN + tn) * 32 + u * 16 + 8 * h) >> 3];
+                            const int cnt = g & 15;
+                            float mx = 0.f;  // relu
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, e < cnt ? vv[e] : 0.f);
+                            if (cnt > 0 && mx > 0.f) {
+                                // non-negative floats order like their bit patterns; read first: once a few tokens of
+                                // the sequence have been seen almost nothing beats the running maximum
+                                unsigned* sp = a.seg_out + (size_t)(g >> 4) * a.ld_seg + m0 + (wm * TM + tm) * 32 + ql;
+                                const unsigned bits = __float_as_uint(mx);
+                                if (bits > __builtin_nontemporal_load(sp)) atomicMax(sp, bits);
+                            }
+                        } else if constexpr ((PST & 4) != 0) {  // ablation: epilogue math without the stores
                             asm volatile("" ::"v"(o));
                         } else if constexpr ((PST & 1) != 0) {  // burst: store at once, nothing stays live
                             half8* p = reinterpret_cast<half8*>(tile_ptr + tm * ldc32 + tn * 32 + u * 16);

@@ -52,6 +52,8 @@ class BertEncoder:
         self.device_index = device
         self.config = config
         self.hidden_size = int(get("hidden_size"))
+        self.vocab_size = int(get("vocab_size"))
+        self.has_mlm_head = False
         cfg = _lib.bh_encoder_config(
             n_layers=int(get("num_hidden_layers")), hidden=self.hidden_size, n_heads=int(get("num_attention_heads")),
             intermediate=int(get("intermediate_size")), vocab_size=int(get("vocab_size")),
@@ -68,7 +70,9 @@ class BertEncoder:
                     key = key[len(pre):]
             if key.startswith("pooler.") or key.endswith("position_ids") or key.endswith("token_type_ids"):
                 continue  # the reference uses outputs[0] only (dense.py:40-44): BertPooler is dead weight
-            if not (key.startswith("embeddings.") or key.startswith("encoder.layer.")):
+            if key.startswith("cls.predictions."):
+                self.has_mlm_head = True  # BertForMaskedLM checkpoint: SPLADE pooling available (encode_splade)
+            elif not (key.startswith("embeddings.") or key.startswith("encoder.layer.")):
                 continue
             a = t.detach().to("cpu")
             if a.dtype not in (torch.float16, torch.float32):
@@ -126,7 +130,7 @@ class BertEncoder:
 
         mask_p, type_p = host(attention_mask), host(token_type_ids)
         dev = torch.device("cuda", self.device_index)
-        shape = (B, T, self.hidden_size) if pool == 2 else (B, self.hidden_size)
+        shape = (B, T, self.hidden_size) if pool == 2 else (B, self.vocab_size) if pool == 3 else (B, self.hidden_size)
         out = torch.empty(shape, dtype=torch.float16, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # the library runs on its own stream
         _lib.init(self.device_index)
@@ -143,6 +147,13 @@ class BertEncoder:
         """Fused forward + pooling: [B, d] fp16 on the device (reference dense.py:40-46 in one call)."""
         return self._forward(kwargs["input_ids"], kwargs.get("attention_mask"), kwargs.get("token_type_ids"),
                              _pool_mode(pooler), l2_normalize)
+
+    def encode_splade(self, kwargs):
+        """Fused forward + masked-LM head + SPLADE pooling: [B, vocab] fp16 = max_t log(1 + relu(logits)) over the
+        attended tokens (reference models/retrievers/splade.py:36-43).  The [B, T, vocab] logits are never materialised."""
+        if not self.has_mlm_head:
+            raise RuntimeError("this encoder was built without cls.predictions.* weights (not a BertForMaskedLM checkpoint)")
+        return self._forward(kwargs["input_ids"], kwargs.get("attention_mask"), kwargs.get("token_type_ids"), 3)
 
     def counters(self):
         c = _lib.bh_encoder_counters()

@@ -10,12 +10,13 @@ Differences:
   * no torch.nn.DataParallel (splade.py:29-32): multi-GPU encoding range-partitions the dataset;
   * `sparse = True` tells `bergen_amd.Retrieve` to keep chunks sparse and search them with the CSR kernel
     (the reference decides by the substring 'splade' in the model name, modules/retrieve.py:138).
-The MLM forward pass itself still runs on the HF module (PyTorch-ROCm); the hand-written part of this path is the
-sparse search (bergen_amd.SparseIndex).
+On a gfx950 device a BERT-architecture checkpoint (naver/splade-*: BertForMaskedLM) is moved onto
+bergen_amd.BertEncoder: encoder layers, masked-LM head and the max-over-tokens pooling run as hand-written HIP
+(`encode_splade`; the [B, T, vocab] logits are never materialised).  Other architectures stay on the HF module.
 """
 import torch
 
-from .dense import Retriever
+from .dense import Retriever, _native_encoder
 
 
 class Splade(Retriever):
@@ -28,12 +29,12 @@ class Splade(Retriever):
             from transformers import AutoModelForMaskedLM, AutoTokenizer
         if model is None:
             model = AutoModelForMaskedLM.from_pretrained(self.model_name, low_cpu_mem_usage=True, torch_dtype=torch.float16)
-        self.model = model
+        self.model = _native_encoder(model)
         if query_encoder is not None:
-            self.query_encoder = query_encoder
+            self.query_encoder = _native_encoder(query_encoder)
         elif query_encoder_name:
-            self.query_encoder = AutoModelForMaskedLM.from_pretrained(query_encoder_name, torch_dtype=torch.float16,
-                                                                      low_cpu_mem_usage=True)
+            self.query_encoder = _native_encoder(AutoModelForMaskedLM.from_pretrained(
+                query_encoder_name, torch_dtype=torch.float16, low_cpu_mem_usage=True))
         else:
             self.query_encoder = self.model  # otherwise symmetric
         self.tokenizer = tokenizer if tokenizer is not None else AutoTokenizer.from_pretrained(self.model_name,
@@ -48,8 +49,10 @@ class Splade(Retriever):
 
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
-        kwargs = {key: value.to(self.device) for key, value in kwargs.items()}
         encoder = self.model if query_or_doc == "doc" else self.query_encoder
+        if getattr(encoder, "has_mlm_head", False):  # native: host BatchEncoding straight through the C ABI
+            return {"embedding": encoder.encode_splade(kwargs)}
+        kwargs = {key: value.to(self.device) for key, value in kwargs.items()}
         logits = encoder(**kwargs).logits
         # pooling over hidden representations: max_t log(1 + relu(logit)) * mask   (splade.py:42-43)
         emb, _ = torch.max(torch.log(1 + torch.relu(logits)) * kwargs["attention_mask"].unsqueeze(-1), dim=1)

@@ -37,6 +37,29 @@ def random_bert(cfg, seed, scale=None):
     return sd
 
 
+def random_mlm_head(cfg, seed, tied=False, sd=None, bias_mean=-1.5):
+    """Seeded random BertOnlyMLMHead weights (HF names under cls.predictions.).  tied=True leaves out the decoder
+    weight (HF ties it to the word embeddings).  The decoder bias is shifted negative so that, like a trained
+    SPLADE model, most (token, term) logits are negative and the pooled vectors are sparse-ish."""
+    rng = np.random.default_rng(seed)
+    d, V = cfg["hidden_size"], cfg["vocab_size"]
+    out = {}
+
+    def put(name, shape, std, mean=0.0):
+        out[name] = (rng.standard_normal(shape) * std + mean).astype(np.float16).astype(np.float32)
+
+    put("cls.predictions.transform.dense.weight", (d, d), 0.05)
+    put("cls.predictions.transform.dense.bias", (d,), 0.05)
+    put("cls.predictions.transform.LayerNorm.weight", (d,), 0.1, 1.0)
+    put("cls.predictions.transform.LayerNorm.bias", (d,), 0.1)
+    if not tied:
+        put("cls.predictions.decoder.weight", (V, d), 0.04)
+    put("cls.predictions.decoder.bias", (V,), 0.3, bias_mean)
+    if sd is not None:
+        sd.update(out)
+    return out
+
+
 def random_batch(cfg, batch, max_len, seed, min_len=1):
     """Right-padded [B, T] ids / mask / types like an HF tokenizer with padding="longest"."""
     rng = np.random.default_rng(seed)

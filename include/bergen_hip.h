@@ -151,7 +151,8 @@ typedef struct bh_encoder_counters {
     int64_t packed_rows;  /* rows the kernels ran over (real tokens + alignment padding) */
     double forward_ms;    /* embedding -> pooled output, HIP events on the encoder's stream */
     double flops;         /* ALGORITHMIC flops over real tokens:
-                             n_layers * (T*(8 d^2 + 4 d d_ff) + 4 d sum(len_s^2)) */
+                             n_layers * (T*(8 d^2 + 4 d d_ff) + 4 d sum(len_s^2))
+                             (+ T*(2 d^2 + 2 d vocab) for pool 3) */
 } bh_encoder_counters;
 
 /* Allocate an encoder (weights + workspace live in HBM, owned by the library).  Replaces
@@ -159,9 +160,15 @@ typedef struct bh_encoder_counters {
 int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg);
 /* Copy one weight tensor from HOST memory, addressed by its HF `BertModel.state_dict()` name
  * (e.g. "encoder.layer.3.attention.self.query.weight"); fp32 sources are rounded to fp16 like
- * `.half()`.  Shapes are HF's ([out, in] for Linear weights). */
+ * `.half()`.  Shapes are HF's ([out, in] for Linear weights).
+ * Optional masked-LM head (HF `BertForMaskedLM`, which the reference loads through
+ * AutoModelForMaskedLM for SPLADE, models/retrievers/splade.py:17): the six
+ * "cls.predictions.{transform.dense.{weight,bias}, transform.LayerNorm.{weight,bias},
+ * decoder.{weight,bias}}" tensors ("cls.predictions.bias" is accepted as the decoder bias).  A head
+ * without decoder.weight is tied to the word embeddings; a missing decoder bias is zero. */
 int bh_encoder_set_tensor(bh_encoder* enc, const char* name, const void* host, int32_t dtype, int64_t numel);
-/* Check that every tensor of the architecture has been set (BH_EINCOMPLETE otherwise). */
+/* Check that every tensor of the architecture has been set (BH_EINCOMPLETE otherwise; when any
+ * cls.predictions.* tensor was given, the head's transform weights must be complete too). */
 int bh_encoder_commit(bh_encoder* enc);
 /* name in {"gemm_variant" (0 = auto, 1..5 explicit tile configurations, 6 = generic bounds-checked kernel;
  * bench sweeps)}. */
@@ -171,7 +178,11 @@ int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
  * [batch, seq_len] int64; attention_mask / token_type_ids may be NULL = all ones / all zeros).
  * pool: 0 = ClsPooler (reference dense.py:71-75), 1 = MeanPooler (dense.py:64-69) -> out is
  * [batch, hidden] fp16; 2 = no pooling -> out is the padded last_hidden_state
- * [batch, seq_len, hidden] fp16 (zeros at padding).  l2_normalize applies to pooled outputs.
+ * [batch, seq_len, hidden] fp16 (zeros at padding); 3 = SPLADE: masked-LM head, then
+ * max over the attended tokens of log(1 + relu(logit)) -> out is [batch, vocab_size] fp16
+ * (replaces Splade.__call__, reference models/retrievers/splade.py:34-47; BH_EINCOMPLETE if the
+ * head was not set; the [batch, seq_len, vocab] logits are never materialised).
+ * l2_normalize applies to pooled outputs (pool 0 / 1).
  * out is a device pointer when out_on_device != 0 (e.g. the rows of a bh_index, or a torch
  * tensor), else a host pointer.  Replaces Dense.__call__, reference dense.py:37-47. */
 int bh_encoder_forward(bh_encoder* enc, const int64_t* input_ids, const int64_t* attention_mask,

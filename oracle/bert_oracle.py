@@ -101,6 +101,34 @@ def encode(sd, cfg, input_ids, attention_mask, token_type_ids=None, pooler="cls"
     return e
 
 
+def mlm_logits(sd, cfg, hidden, dtype=np.float64):
+    """BertOnlyMLMHead on [B, T, d] hidden states -> [B, T, vocab] logits (transformers modeling_bert.py:
+    BertPredictionHeadTransform :443-  dense -> gelu -> LayerNorm;  BertLMPredictionHead :462-  decoder(+bias);
+    reached from the reference through AutoModelForMaskedLM, models/retrievers/splade.py:17,36-40).
+    A state dict without cls.predictions.decoder.weight is a tied head: the word-embedding matrix."""
+    W = lambda k: np.asarray(sd[k], dtype)
+    eps = cfg.get("layer_norm_eps", 1e-12)
+    t = _gelu(hidden @ W("cls.predictions.transform.dense.weight").T + W("cls.predictions.transform.dense.bias"))
+    t = _ln(t, W("cls.predictions.transform.LayerNorm.weight"), W("cls.predictions.transform.LayerNorm.bias"), eps)
+    wdec = W("cls.predictions.decoder.weight") if "cls.predictions.decoder.weight" in sd \
+        else W("embeddings.word_embeddings.weight")
+    bdec = W("cls.predictions.decoder.bias") if "cls.predictions.decoder.bias" in sd else 0.0
+    return t @ wdec.T + bdec
+
+
+def splade_pool(logits, mask):
+    """SPLADE pooling, reference models/retrievers/splade.py:42-43:
+    max over tokens of log(1 + relu(logits)) * attention_mask  -> [B, vocab]."""
+    m = (np.asarray(mask) != 0)[..., None]
+    return (np.log1p(np.maximum(logits, 0.0)) * m).max(1)
+
+
+def encode_splade(sd, cfg, input_ids, attention_mask, token_type_ids=None):
+    """Splade.__call__ (reference splade.py:34-47) -> [B, vocab] float64."""
+    h = bert_forward(sd, cfg, input_ids, attention_mask, token_type_ids)
+    return splade_pool(mlm_logits(sd, cfg, h), attention_mask)
+
+
 # ---- op-level references for the kernel parity tests -------------------------------------------------------
 
 def gemm_ref(a, w, bias=None, bias_mode=1, residual=None, gelu=False):
@@ -140,4 +168,4 @@ def layernorm_ref(x, g, b, eps):
 
 
 # seeded synthetic weights / batches live in the product package's bench helpers (no arithmetic of the path)
-from bergen_amd.synth import random_batch, random_bert  # noqa: E402,F401
+from bergen_amd.synth import random_batch, random_bert, random_mlm_head  # noqa: E402,F401
