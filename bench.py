@@ -47,6 +47,8 @@ def parse_args():
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--k", type=int, default=50)
     p.add_argument("--query-tile", type=int, default=None, help="128 or 256 (library default if omitted)")
+    p.add_argument("--query-split", type=int, default=None, help="1 or 2 (paired workgroups share the corpus stream)")
+    p.add_argument("--pair-window", type=int, default=None, help="query_split 2: max tiles a workgroup runs ahead of its partner")
     p.add_argument("--share-threshold", type=int, default=None)
     p.add_argument("--nontemporal", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -196,6 +198,10 @@ def main():
     _lib.init(local_rank)
     if args.query_tile is not None:
         _lib.set_option("query_tile", args.query_tile)
+    if args.query_split is not None:
+        _lib.set_option("query_split", args.query_split)
+    if args.pair_window is not None:
+        _lib.set_option("pair_window", args.pair_window)
     if args.share_threshold is not None:
         _lib.set_option("share_threshold", args.share_threshold)
     if args.nontemporal is not None:
@@ -353,10 +359,10 @@ def sweep(ix, queries, k, args):
     """Kernel-variant timings for tuning (not part of the headline number)."""
     from bergen_amd import _lib
     res = []
-    for tile in (128, 256):
+    for split in (2, 1):
         for share in (1, 0):
             for nt in (1, 0):
-                _lib.set_option("query_tile", tile)
+                _lib.set_option("query_split", split)
                 _lib.set_option("share_threshold", share)
                 _lib.set_option("nontemporal", nt)
                 ix.search(queries, k)
@@ -367,9 +373,11 @@ def sweep(ix, queries, k, args):
                 dt = time.perf_counter() - t0
                 c = ix.counters()
                 per = c["algorithmic_bytes"] / c["n_passes"]
-                res.append({"query_tile": tile, "share": share, "nt": nt, "qps": queries.shape[0] / dt,
+                res.append({"query_split": split, "share": share, "nt": nt, "qps": queries.shape[0] / dt,
+                            "n_passes": c["n_passes"],
                             "scan_ms_per_pass": c["scan_ms"] / c["n_passes"], "merge_ms_per_pass": c["merge_ms"] / c["n_passes"],
                             "scan_GBps": per / (c["scan_ms"] / c["n_passes"] * 1e-3) / 1e9})
+    _lib.set_option("query_split", args.query_split if args.query_split is not None else 1)
     _lib.set_option("query_tile", 128)
     _lib.set_option("share_threshold", 1)
     _lib.set_option("nontemporal", 1)

@@ -9,14 +9,17 @@ struct BhScanArgs {
     const _Float16* corpus;  // [n_tiles*32][D] fp16, rows >= n_rows are zero padding
     long long n_rows;        // valid rows
     long long n_tiles;       // ceil(n_rows / 32)
-    const _Float16* qtile;   // [BQ][D] fp16 query tile (zero rows beyond the valid queries)
-    bh_u64* cand;            // [G][BQ][2*KP] candidate buffers (scratch)
-    bh_u64* partial;         // [G][BQ][KP]   out: per-workgroup sorted best-KP keys
-    unsigned* gthr;          // [BQ][64] threshold slot table (ordf), initialised to BH_ORD_NEG_INF
+    const _Float16* qtile;   // [qsplit*BQ][D] fp16 query tile (zero rows beyond the valid queries)
+    bh_u64* cand;            // [grid][BQ][2*KP] candidate buffers (scratch)
+    bh_u64* partial;         // [grid/qsplit][qsplit*BQ][KP]   out: per-workgroup sorted best-KP keys
+    unsigned* gthr;          // [qsplit*BQ][64] threshold slot table (ordf), initialised to BH_ORD_NEG_INF
     int share;               // share thresholds between workgroups
     int nontemporal;         // nt cache policy on the corpus stream
     int ablate;              // bench-only kernel ablation (0 = production kernel)
     int ring_variant;        // bench-only LDS ring geometry selector for d=768 (0 = default 6 lines x 6)
+    int qsplit;              // 1 | 2: workgroups sharing each row tile, each with its own BQ queries (see scan_topk.hip)
+    unsigned* progress;      // [grid] qsplit = 2: tiles started per workgroup (zeroed by the host), pacing hint only
+    int pair_window;         // qsplit = 2: a workgroup may run at most this many tiles ahead of its partner (0 = free-running)
 };
 
 // scan_topk.hip

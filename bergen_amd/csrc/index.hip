@@ -50,6 +50,8 @@ struct Options {
     int workgroups_per_cu = 1;
     int ablate = 0;
     int ring_variant = 0;
+    int query_split = 1;
+    int pair_window = 0;
 } g_opt;
 
 int pad_dim(int dim) {
@@ -199,6 +201,12 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "ablate") {
         if (value < 0 || value > 4) return fail(BH_EINVAL, "ablate must be 0..4");
         g_opt.ablate = (int)value;  // bench-only: results are NOT valid search results when != 0
+    } else if (s == "query_split") {
+        if (value != 1 && value != 2) return fail(BH_EINVAL, "query_split must be 1 or 2");
+        g_opt.query_split = (int)value;
+    } else if (s == "pair_window") {
+        if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
+        g_opt.pair_window = (int)value;
     } else if (s == "ring_variant") {
         if (value < 0 || value > 4) return fail(BH_EINVAL, "ring_variant must be 0..4");
         g_opt.ring_variant = (int)value;
@@ -337,15 +345,24 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     const int dp = ix->dim_padded;
     int qw = (g_opt.query_tile == 256 && bh_scan_supports(dp, kp, 2)) ? 2 : 1;
     const int bq = 128 * qw;
-    const int n_pass = (nq + bq - 1) / bq;
-    const int64_t nq_pad = (int64_t)n_pass * bq;
     const int grid = ix->n_cu * g_opt.workgroups_per_cu;
+    // passes: a launch scans for qs * bq queries (qs = 2: paired workgroups share the corpus stream through L2,
+    // scan_topk.hip); the last queries run unsplit when no more than bq are left
+    const int qs_max = (g_opt.query_split == 2 && grid % 16 == 0) ? 2 : 1;
+    std::vector<std::pair<int, int>> passes;  // (first query, qs)
+    for (int q0 = 0; q0 < nq;) {
+        const int qs = (qs_max == 2 && nq - q0 > bq) ? 2 : 1;
+        passes.push_back({q0, qs});
+        q0 += bq * qs;
+    }
+    const int n_pass = (int)passes.size();
+    const int64_t nq_pad = (int64_t)((nq + bq - 1) / bq) * bq;
 
     int rc;
     if ((rc = ix->qbuf.ensure((size_t)nq_pad * dp))) return rc;
     if ((rc = ix->cand.ensure((size_t)grid * bq * 2 * kp))) return rc;
     if ((rc = ix->partial.ensure((size_t)grid * bq * kp))) return rc;
-    if ((rc = ix->gthr.ensure((size_t)bq * 64))) return rc;
+    if ((rc = ix->gthr.ensure((size_t)bq * qs_max * 64 + grid))) return rc;
 
     hipStream_t st = ix->stream;
     // queries -> padded fp16 tile buffer (zero rows beyond nq)
@@ -359,10 +376,12 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         if (!ix->event(2 + 3 * p + 2)) return fail(BH_EHIP, "hipEventCreate failed");
 
     HIP_TRY(hipEventRecord(ev_begin, st));
+    double alg_bytes = 0;
     for (int p = 0; p < n_pass; ++p) {
-        const int q0 = p * bq;
-        const int nq_tile = std::min(bq, nq - q0);
-        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)bq * 64, 0x007fffffu, st));
+        const int q0 = passes[p].first, qs = passes[p].second;
+        const int tile = bq * qs;
+        const int nq_tile = std::min(tile, nq - q0);
+        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)tile * 64, 0x007fffffu, st));
         BhScanArgs sa;
         sa.corpus = ix->rows;
         sa.n_rows = ix->n_rows;
@@ -375,13 +394,17 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.nontemporal = g_opt.nontemporal;
         sa.ablate = g_opt.ablate;
         sa.ring_variant = g_opt.ring_variant;
+        sa.qsplit = qs;
+        sa.pair_window = g_opt.pair_window;
+        sa.progress = ix->gthr.p + (size_t)bq * qs_max * 64;  // [grid] words behind the slot table
+        if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p), st));
         HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 1), st));
         BhMergeArgs ma;
         ma.partial = ix->partial.p;
-        ma.n_lists = grid;
-        ma.bq = bq;
+        ma.n_lists = grid / qs;
+        ma.bq = tile;
         ma.corpus = ix->rows;
         ma.n_rows = ix->n_rows;
         ma.qtile = sa.qtile;
@@ -392,6 +415,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         ma.out_ids = reinterpret_cast<long long*>(out_ids_dev) + (size_t)q0 * k;
         HIP_TRY(bh_launch_merge_rescore(ma, kp, nq_tile, st));
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 2), st));
+        // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
+        alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + (double)tile * ix->dim * 2.0 + (double)tile * k * 12.0;
     }
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -400,7 +425,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     c.n_rows = ix->n_rows;
     c.dim = ix->dim;
     c.dim_padded = dp;
-    c.query_tile = bq;
+    c.query_tile = bq * qs_max;
     c.n_passes = n_pass;
     c.n_workgroups = grid;
     c.k_padded = kp;
@@ -416,9 +441,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     float tot = 0;
     HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
     c.total_ms = tot;
-    // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
-    c.algorithmic_bytes =
-        (double)n_pass * ((double)ix->n_rows * ix->dim * 2.0 + (double)bq * ix->dim * 2.0 + (double)bq * k * 12.0);
+    c.algorithmic_bytes = alg_bytes;
     return BH_OK;
 }
 

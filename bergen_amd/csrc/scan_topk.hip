@@ -88,12 +88,22 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = gridDim.x, b = blockIdx.x;
+    // Query split (a.qsplit = 2): workgroups xb and xb ^ 8 — dispatched to the SAME XCD (workgroup id mod 8) —
+    // walk the same row tiles b, b+G, ... in step, each against its own BQ queries, so one of them takes every
+    // corpus line from HBM and the other finds it in that XCD's L2: HBM traffic per query halves while the
+    // per-workgroup register budget (the query fragments) stays that of a BQ-query tile.
+    const int QS = a.qsplit;
+    const int xb = blockIdx.x;
+    const int G = QS == 1 ? (int)gridDim.x : (int)gridDim.x / QS;         // row-tile walkers
+    const int qh = QS == 1 ? 0 : (xb >> 3) % QS;                          // which BQ queries of the launch
+    const int b = QS == 1 ? xb : (((xb >> 3) / QS) << 3) | (xb & 7);      // row-tile walker id
     const int ql = lane & 31, h = lane >> 5;
 
     const long long my_tiles = (a.n_tiles > b) ? (a.n_tiles - b + G - 1) / G : 0;
-    u64* cand_wg = a.cand + (size_t)b * BQ * CAP;
-    u64* part_wg = a.partial + (size_t)b * BQ * KP;
+    u64* cand_wg = a.cand + (size_t)xb * BQ * CAP;
+    u64* part_wg = a.partial + ((size_t)b * QS + qh) * BQ * KP;
+    a.qtile += (size_t)qh * BQ * D;
+    a.gthr += (size_t)qh * BQ * 64;
 
     // ---- queries -> registers (B fragments).  Lane (ql, h) holds, for k-step s, the 8 halfs
     // at k = 16 s + 8 h of query  (wave*QW + w2)*32 + ql.  All loads first, then pin to AGPRs.
@@ -181,7 +191,29 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
         for (int p = 0; p < R - 1; ++p) issue_stage();
 
         int cslot = 0;  // ring slot of the stage being consumed
+        bool paced = QS > 1 && a.pair_window > 0;
         for (long long i = 0; i < my_tiles; ++i) {
+            // Pairing only pays while the partners stay within the L2 residency of a line (a few tiles): wave 0
+            // publishes the tile it starts and holds the workgroup (the others wait at the stage barrier) while
+            // it is more than pair_window tiles ahead of its partner.  The partner's counter is read with a
+            // SCALAR load (glc: from the XCD's L2, which both partners share) — a vector load would queue behind
+            // the ring's LDS-DMA requests, which return in order.  Pure pacing hint: a stale or missing value can
+            // only change timing; after one timeout the workgroup stops pacing for the rest of the launch.
+            if (paced && wave == 0) {
+                if (lane == 0) *(volatile unsigned*)(a.progress + xb) = (unsigned)i + 1u;
+                const unsigned* pp = a.progress + (xb ^ 8);
+                int spins = 0;
+                for (;;) {
+                    unsigned pv;
+                    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(pv) : "s"(pp) : "memory");
+                    if ((int)((unsigned)i + 1u - pv) <= a.pair_window) break;
+                    if (++spins > 2048) {
+                        paced = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
             floatx16 acc[QW];
 #pragma unroll
             for (int w2 = 0; w2 < QW; ++w2)

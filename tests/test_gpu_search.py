@@ -11,6 +11,8 @@ from tests.conftest import gap_tolerance
 
 pytestmark = pytest.mark.gpu
 
+SPLIT_DEFAULT = 1  # library default of "query_split" (restored after the option tests)
+
 
 @pytest.fixture(scope="module")
 def amd():
@@ -18,7 +20,7 @@ def amd():
     from bergen_amd import _lib
     _lib.init(0)
     yield bergen_amd
-    for name, val in (("query_tile", 128), ("share_threshold", 1), ("nontemporal", 1)):
+    for name, val in (("query_tile", 128), ("share_threshold", 1), ("nontemporal", 1), ("query_split", SPLIT_DEFAULT)):
         _lib.set_option(name, val)
 
 
@@ -130,21 +132,41 @@ def test_options_do_not_change_results(amd):
     ws, wi = c_oracle.canonical_search(q[:40], x, 50)
     base = None
     try:
-        for tile in (128, 256):
-            for share in (0, 1):
-                for nt in (0, 1):
-                    _lib.set_option("query_tile", tile)
-                    _lib.set_option("share_threshold", share)
-                    _lib.set_option("nontemporal", nt)
-                    s, i = _search(amd, x, q, 50)
-                    compare.assert_bit_exact(s[:40], i[:40], ws, wi, f"tile={tile} share={share} nt={nt}")
-                    if base is None:
-                        base = (s, i)
-                    compare.assert_bit_exact(s, i, base[0], base[1], f"variant tile={tile} share={share} nt={nt}")
+        for split in (1, 2):
+            for tile in (128, 256):
+                for share in (0, 1):
+                    for nt in (0, 1):
+                        _lib.set_option("query_split", split)
+                        _lib.set_option("query_tile", tile)
+                        _lib.set_option("share_threshold", share)
+                        _lib.set_option("nontemporal", nt)
+                        s, i = _search(amd, x, q, 50)
+                        what = f"split={split} tile={tile} share={share} nt={nt}"
+                        compare.assert_bit_exact(s[:40], i[:40], ws, wi, what)
+                        if base is None:
+                            base = (s, i)
+                        compare.assert_bit_exact(s, i, base[0], base[1], "variant " + what)
     finally:
         _lib.set_option("query_tile", 128)
         _lib.set_option("share_threshold", 1)
         _lib.set_option("nontemporal", 1)
+        _lib.set_option("query_split", SPLIT_DEFAULT)
+
+
+@pytest.mark.parametrize("nq", [129, 256, 257, 385, 512])
+def test_query_split_pass_boundaries(amd, nq):
+    """query_split = 2: launches of 256 queries by paired workgroups, the last <= 128 queries unsplit."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(nq)
+    x = rng.standard_normal((9001, 768)).astype(np.float16)
+    q = rng.standard_normal((nq, 768)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, 50)
+    try:
+        _lib.set_option("query_split", 2)
+        s, i = _search(amd, x, q, 50)
+        compare.assert_bit_exact(s, i, ws, wi, f"split nq={nq}")
+    finally:
+        _lib.set_option("query_split", SPLIT_DEFAULT)
 
 
 def test_shard_invariance_and_device_merge(amd):
