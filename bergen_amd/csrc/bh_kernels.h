@@ -25,6 +25,9 @@ struct BhScanArgs {
 // scan_topk.hip
 hipError_t bh_launch_scan(const BhScanArgs& a, int dim_padded, int kp, int qw, int grid, hipStream_t stream);
 bool bh_scan_supports(int dim_padded, int kp, int qw);
+// scan_topk8.hip (8 waves per CU, dimensions split between the two waves of a SIMD; 128-query tiles)
+hipError_t bh_launch_scan8(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
+bool bh_scan8_supports(int dim_padded);
 
 struct BhMergeArgs {
     const bh_u64* partial;   // [G][BQ][KP]

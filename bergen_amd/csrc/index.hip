@@ -52,6 +52,7 @@ struct Options {
     int ring_variant = 0;
     int query_split = 1;
     int pair_window = 0;
+    int scan_kernel = 0;  // 0 = scan_topk.hip (4 waves), 1 = scan_topk8.hip (8 waves, split dimensions)
 } g_opt;
 
 int pad_dim(int dim) {
@@ -204,6 +205,9 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "query_split") {
         if (value != 1 && value != 2) return fail(BH_EINVAL, "query_split must be 1 or 2");
         g_opt.query_split = (int)value;
+    } else if (s == "scan_kernel") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves) or 1 (8 waves)");
+        g_opt.scan_kernel = (int)value;
     } else if (s == "pair_window") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
         g_opt.pair_window = (int)value;
@@ -399,7 +403,10 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.progress = ix->gthr.p + (size_t)bq * qs_max * 64;  // [grid] words behind the slot table
         if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p), st));
-        HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
+        if (g_opt.scan_kernel == 1 && qw == 1 && bh_scan8_supports(dp))
+            HIP_TRY(bh_launch_scan8(sa, dp, kp, grid, st));
+        else
+            HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
         HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 1), st));
         BhMergeArgs ma;
         ma.partial = ix->partial.p;

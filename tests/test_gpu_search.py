@@ -12,6 +12,7 @@ from tests.conftest import gap_tolerance
 pytestmark = pytest.mark.gpu
 
 SPLIT_DEFAULT = 1  # library default of "query_split" (restored after the option tests)
+KERNEL_DEFAULT = 0  # library default of "scan_kernel"
 
 
 @pytest.fixture(scope="module")
@@ -20,7 +21,8 @@ def amd():
     from bergen_amd import _lib
     _lib.init(0)
     yield bergen_amd
-    for name, val in (("query_tile", 128), ("share_threshold", 1), ("nontemporal", 1), ("query_split", SPLIT_DEFAULT)):
+    for name, val in (("query_tile", 128), ("share_threshold", 1), ("nontemporal", 1), ("query_split", SPLIT_DEFAULT),
+                      ("scan_kernel", KERNEL_DEFAULT)):
         _lib.set_option(name, val)
 
 
@@ -326,3 +328,45 @@ def test_full_size_properties(amd):
     compare.assert_bit_exact(ms.cpu().numpy(), mi.cpu().numpy(), s_np, i_np, "2 shards at full size")
     for h in (ix, half_lo, half_hi):
         h.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [
+    (33, 100, 129, 50), (1000, 128, 7, 56), (4097, 256, 130, 57), (3000, 384, 40, 120), (2500, 512, 33, 121),
+    (7777, 768, 300, 50), (20000, 768, 64, 50), (9000, 768, 200, 200), (1, 768, 1, 1), (31, 700, 5, 31),
+])
+@pytest.mark.parametrize("split", [1, 2])
+def test_eight_wave_kernel_matches_oracle(amd, n, d, nq, k, split):
+    """scan_kernel = 1 (scan_topk8.hip: dimensions split between the two waves of a SIMD): same bit-exact results."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(n * 31 + d + 5)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    try:
+        _lib.set_option("scan_kernel", 1)
+        _lib.set_option("query_split", split)
+        s, i = _search(amd, x, q, k)
+        compare.assert_bit_exact(s, i, ws, wi, f"8-wave n={n} d={d} nq={nq} k={k} split={split}")
+    finally:
+        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
+        _lib.set_option("query_split", SPLIT_DEFAULT)
+
+
+def test_eight_wave_kernel_ties_and_options(amd):
+    from bergen_amd import _lib
+    rng = np.random.default_rng(77)
+    x = rng.integers(-2, 3, size=(5000, 768)).astype(np.float16)  # heavy exact ties
+    q = rng.integers(-2, 3, size=(70, 768)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, 50)
+    try:
+        _lib.set_option("scan_kernel", 1)
+        for share in (0, 1):
+            for nt in (0, 1):
+                _lib.set_option("share_threshold", share)
+                _lib.set_option("nontemporal", nt)
+                s, i = _search(amd, x, q, 50)
+                compare.assert_bit_exact(s, i, ws, wi, f"8-wave ties share={share} nt={nt}")
+    finally:
+        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
+        _lib.set_option("share_threshold", 1)
+        _lib.set_option("nontemporal", 1)
