@@ -22,6 +22,7 @@ from .config import instantiate  # noqa: F401
 from .dense import ClsPooler, CosineSim, Dense, DotProduct, MeanPooler, Retriever  # noqa: F401
 from .encoder import BertEncoder  # noqa: F401
 from .index import FlatIndex, merge_topk  # noqa: F401
+from .rerank import CrossEncoder, Rerank, Reranker  # noqa: F401
 from .retrieve import Retrieve  # noqa: F401
 from .sharded import ShardedSearcher, shard_range  # noqa: F401
 from .sparse import SparseIndex  # noqa: F401

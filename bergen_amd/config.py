@@ -19,6 +19,8 @@ TARGET_ALIASES = {
     "models.retrievers.dense.CosineSim": "bergen_amd.dense.CosineSim",
     "models.retrievers.splade.Splade": "bergen_amd.splade.Splade",
     "modules.retrieve.Retrieve": "bergen_amd.retrieve.Retrieve",
+    "models.rerankers.crossencoder.CrossEncoder": "bergen_amd.rerank.CrossEncoder",
+    "modules.rerank.Rerank": "bergen_amd.rerank.Rerank",
 }
 
 

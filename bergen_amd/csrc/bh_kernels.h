@@ -208,3 +208,15 @@ struct BhSpladeFinishArgs {
     int batch, vocab;
 };
 hipError_t bh_launch_splade_finish(const BhSpladeFinishArgs& a, hipStream_t stream);
+
+struct BhClsHeadArgs {
+    const _Float16* x;         // packed hidden states [rows][d]
+    const long long* seq_off;  // [batch] first packed row of each sequence (= its [CLS] token)
+    const _Float16* wp;        // [d][d]  BertPooler.dense.weight
+    const _Float16* bp;        // [d]
+    const _Float16* wc;        // [n_labels][d]  classifier.weight
+    const _Float16* bc;        // [n_labels]
+    float* out;                // [batch][n_labels] logits, fp32
+    int batch, d, n_labels;
+};
+hipError_t bh_launch_cls_head(const BhClsHeadArgs& a, hipStream_t stream);

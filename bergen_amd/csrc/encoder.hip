@@ -66,6 +66,11 @@ struct bh_encoder {
     std::map<std::string, std::pair<_Float16*, int64_t>> mlm_slots;
     std::map<std::string, bool> mlm_have;
     bool has_mlm = false;
+    // optional sequence-classification head (BertPooler + classifier of BertForSequenceClassification; pool 4)
+    _Float16* cls_arena = nullptr;
+    _Float16 *cls_wp = nullptr, *cls_bp = nullptr, *cls_wc = nullptr, *cls_bc = nullptr;
+    int n_labels = 0;
+    std::map<std::string, bool> cls_have;
     BhDevBuf<int> ibuf;          // tok | pos | typ | seq_len | slot
     BhDevBuf<long long> seq_off;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -173,6 +178,22 @@ int build_mlm_slots(bh_encoder* e) {
     return BH_OK;
 }
 
+constexpr int kMaxLabels = 16;
+
+int build_cls_slots(bh_encoder* e) {
+    if (e->cls_arena) return BH_OK;
+    const size_t d = e->cfg.hidden;
+    const size_t total = d * d + d + kMaxLabels * d + kMaxLabels + 64;
+    BH_HIP_TRY(hipSetDevice(e->device));
+    BH_HIP_TRY(hipMalloc((void**)&e->cls_arena, total * sizeof(_Float16)));
+    BH_HIP_TRY(hipMemset(e->cls_arena, 0, total * sizeof(_Float16)));
+    e->cls_wp = e->cls_arena;
+    e->cls_bp = e->cls_wp + d * d;
+    e->cls_wc = e->cls_bp + d;
+    e->cls_bc = e->cls_wc + kMaxLabels * d;
+    return BH_OK;
+}
+
 int gemm(bh_encoder* e, const _Float16* A, long long lda, const _Float16* B, long long ldb, _Float16* C, long long ldc,
          int M, int N, int K, const _Float16* bias, int bias_mode, const _Float16* residual, long long ldr, int gelu,
          long long c_block_rows = 0) {
@@ -253,6 +274,7 @@ void bh_encoder_destroy(bh_encoder* e) {
     e->SEG.release();
     if (e->arena) (void)hipFree(e->arena);
     if (e->mlm_arena) (void)hipFree(e->mlm_arena);
+    if (e->cls_arena) (void)hipFree(e->cls_arena);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -265,6 +287,34 @@ int bh_encoder_set_tensor(bh_encoder* e, const char* name, const void* host, int
     std::string key(name);
     for (const char* pre : {"bert.", "model."})  // tolerate task-model prefixes
         if (key.rfind(pre, 0) == 0 && !e->slots.count(key)) key = key.substr(strlen(pre));
+    if (key.rfind("pooler.dense.", 0) == 0 || key.rfind("classifier.", 0) == 0) {
+        // sequence-classification head: shapes depend on num_labels, handled apart from the fixed slot table
+        if (dtype != BH_F16 && dtype != BH_F32) return bh_fail(BH_EINVAL, "bad dtype %d", dtype);
+        int rc = build_cls_slots(e);
+        if (rc) return rc;
+        const int64_t d = e->cfg.hidden;
+        _Float16* dst = nullptr;
+        if (key == "pooler.dense.weight" && numel == d * d) dst = e->cls_wp;
+        else if (key == "pooler.dense.bias" && numel == d) dst = e->cls_bp;
+        else if (key == "classifier.weight" && numel % d == 0 && numel / d >= 1 && numel / d <= kMaxLabels) {
+            dst = e->cls_wc;
+            e->n_labels = (int)(numel / d);
+        } else if (key == "classifier.bias" && numel >= 1 && numel <= kMaxLabels) dst = e->cls_bc;
+        else return bh_fail(BH_EINVAL, "tensor '%s': unexpected name or size %lld (hidden %lld, at most %d labels)", name,
+                            (long long)numel, (long long)d, kMaxLabels);
+        BH_HIP_TRY(hipSetDevice(e->device));
+        if (dtype == BH_F16) {
+            BH_HIP_TRY(hipMemcpy(dst, host, (size_t)numel * 2, hipMemcpyHostToDevice));
+        } else {
+            std::vector<_Float16> tmp((size_t)numel);
+            const float* src = static_cast<const float*>(host);
+            for (int64_t i = 0; i < numel; ++i) tmp[(size_t)i] = (_Float16)src[i];
+            BH_HIP_TRY(hipMemcpy(dst, tmp.data(), (size_t)numel * 2, hipMemcpyHostToDevice));
+        }
+        e->cls_have[key] = true;
+        e->committed = false;
+        return BH_OK;
+    }
     auto it = e->slots.find(key);
     bool is_mlm = false;
     if (it == e->slots.end() && key.rfind("cls.predictions.", 0) == 0) {
@@ -298,6 +348,9 @@ int bh_encoder_commit(bh_encoder* e) {
     if (!e) return bh_fail(BH_EINVAL, "null encoder");
     for (auto& kv : e->slots)
         if (!e->have.count(kv.first)) return bh_fail(BH_EINCOMPLETE, "encoder weight '%s' was never set", kv.first.c_str());
+    if (e->cls_arena)
+        for (const char* k : {"pooler.dense.weight", "pooler.dense.bias", "classifier.weight", "classifier.bias"})
+            if (!e->cls_have.count(k)) return bh_fail(BH_EINCOMPLETE, "classification head weight '%s' was never set", k);
     e->has_mlm = false;
     if (e->mlm_arena) {
         for (const char* k : {"cls.predictions.transform.dense.weight", "cls.predictions.transform.dense.bias",
@@ -330,7 +383,10 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if (!e) return bh_fail(BH_EINVAL, "null encoder");
     if (!e->committed) return bh_fail(BH_EINCOMPLETE, "encoder weights not committed (bh_encoder_commit)");
     if (batch < 0 || seq_len <= 0) return bh_fail(BH_EINVAL, "batch=%d seq_len=%d", batch, seq_len);
-    if (pool < 0 || pool > 3) return bh_fail(BH_EINVAL, "pool must be 0 (cls), 1 (mean), 2 (hidden states) or 3 (splade)");
+    if (pool < 0 || pool > 4)
+        return bh_fail(BH_EINVAL, "pool must be 0 (cls), 1 (mean), 2 (hidden states), 3 (splade) or 4 (classification head)");
+    if (pool == 4 && !(e->cls_arena && e->n_labels > 0))
+        return bh_fail(BH_EINCOMPLETE, "pool 4 (classification head) needs the pooler.dense.* and classifier.* weights");
     if (pool == 3 && !e->has_mlm) return bh_fail(BH_EINCOMPLETE, "pool 3 (splade) needs the cls.predictions.* weights");
     if (batch == 0) return BH_OK;
     if (!input_ids || !out) return bh_fail(BH_EINVAL, "null buffer");
@@ -350,7 +406,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         int n = 0;
         for (int t = 0; t < seq_len; ++t) n += attention_mask ? (attention_mask[(size_t)b * seq_len + t] != 0) : 1;
         if (n == 0) return bh_fail(BH_EINVAL, "sequence %d has an all-zero attention mask", b);
-        if (pool == 0 && attention_mask && attention_mask[(size_t)b * seq_len] == 0)
+        if ((pool == 0 || pool == 4) && attention_mask && attention_mask[(size_t)b * seq_len] == 0)
             return bh_fail(BH_EINVAL, "CLS pooling needs attention_mask[%d][0] != 0", b);
         off[b] = cursor;
         len[b] = n;
@@ -417,7 +473,8 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if ((rc = e->H.ensure(M * dff))) return rc;
     if ((rc = e->ibuf.ensure(ib.size()))) return rc;
     if ((rc = e->seq_off.ensure(batch))) return rc;
-    const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size : (size_t)batch * d;
+    const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size
+                             : pool == 4 ? (size_t)batch * e->n_labels * 2 /* fp32 logits, counted in halves */ : (size_t)batch * d;
     if (pool == 3 && (rc = e->SEG.ensure((size_t)batch * e->vpad))) return rc;
     _Float16* out_dev = static_cast<_Float16*>(out);
     if (!out_on_device) {
@@ -489,7 +546,20 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         la.beta = L.ln2b;
         BH_HIP_TRY(bh_launch_layernorm(la, st));
     }
-    if (pool == 3) {
+    if (pool == 4) {
+        BhClsHeadArgs ca{};
+        ca.x = e->X.p;
+        ca.seq_off = e->seq_off.p;
+        ca.wp = e->cls_wp;
+        ca.bp = e->cls_bp;
+        ca.wc = e->cls_wc;
+        ca.bc = e->cls_bc;
+        ca.out = reinterpret_cast<float*>(out_dev);
+        ca.batch = batch;
+        ca.d = d;
+        ca.n_labels = e->n_labels;
+        BH_HIP_TRY(bh_launch_cls_head(ca, st));
+    } else if (pool == 3) {
         // masked-LM head (BertOnlyMLMHead) + SPLADE pooling, reference models/retrievers/splade.py:36-43:
         //   T = LayerNorm(GELU(X Wt^T + bt));  logit = T Wdec^T + bdec;  emb[b][v] = max_t log(1 + relu(logit[b][t][v]))
         // The [tokens][vocab] logits are never written: the decoder GEMM (terms as rows, tokens as columns) keeps a

@@ -195,6 +195,53 @@ __global__ void __launch_bounds__(256) bh_splade_finish_kernel(BhSpladeFinishArg
     a.out[i] = (_Float16)log1pf(m);
 }
 
+// Sequence-classification head of HF BertForSequenceClassification (the reference's cross-encoder reranker,
+// models/rerankers/crossencoder.py:18,34-38 -> .logits): pooled = tanh(Wp h_cls + bp) (BertPooler), logits = Wc pooled + bc.
+// One workgroup per sequence; a wave per output row, lanes striding over d with 16-byte loads; fp32 throughout.
+__global__ void __launch_bounds__(256) bh_cls_head_kernel(BhClsHeadArgs a) {
+    __shared__ float hs[2048];
+    __shared__ float ps[2048];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = a.d, nchunk = d >> 3;
+    const _Float16* h = a.x + (size_t)a.seq_off[b] * d;
+    for (int c = tid; c < nchunk; c += 256) {
+        const half8 v = *reinterpret_cast<const half8*>(h + (size_t)c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hs[c * 8 + e] = (float)v[e];
+    }
+    __syncthreads();
+    for (int j = wave; j < d; j += 4) {
+        const _Float16* w = a.wp + (size_t)j * d;
+        float s = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            const half8 v = *reinterpret_cast<const half8*>(w + (size_t)c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[e] * hs[c * 8 + e];
+        }
+        s = wave_sum(s);
+        if (lane == 0) ps[j] = tanhf(s + (float)a.bp[j]);
+    }
+    __syncthreads();
+    for (int l = wave; l < a.n_labels; l += 4) {
+        const _Float16* w = a.wc + (size_t)l * d;
+        float s = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            const half8 v = *reinterpret_cast<const half8*>(w + (size_t)c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[e] * ps[c * 8 + e];
+        }
+        s = wave_sum(s);
+        if (lane == 0) a.out[(size_t)b * a.n_labels + l] = s + (float)a.bc[l];
+    }
+}
+
+hipError_t bh_launch_cls_head(const BhClsHeadArgs& a, hipStream_t st) {
+    if (a.batch <= 0) return hipSuccess;
+    if (a.d > 2048 || (a.d & 7)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bh_cls_head_kernel, dim3((unsigned)a.batch), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t bh_launch_splade_finish(const BhSpladeFinishArgs& a, hipStream_t st) {
     const long long n = (long long)a.batch * a.vocab;
     if (n <= 0) return hipSuccess;

@@ -63,13 +63,20 @@ class BertEncoder:
         _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))
         self._h = h
         n_set = 0
+        classifier = {}
         for name, t in state_dict.items():
             key = name
             for pre in ("bert.", "model."):
                 if key.startswith(pre):
                     key = key[len(pre):]
-            if key.startswith("pooler.") or key.endswith("position_ids") or key.endswith("token_type_ids"):
-                continue  # the reference uses outputs[0] only (dense.py:40-44): BertPooler is dead weight
+            if key.endswith("position_ids") or key.endswith("token_type_ids"):
+                continue
+            if key.startswith("classifier."):
+                classifier[key] = t
+                continue
+            if key.startswith("pooler."):
+                classifier[key] = t  # BertPooler only matters under a classifier (the dense path reads outputs[0], dense.py:40-44)
+                continue
             if key.startswith("cls.predictions."):
                 self.has_mlm_head = True  # BertForMaskedLM checkpoint: SPLADE pooling available (encode_splade)
             elif not (key.startswith("embeddings.") or key.startswith("encoder.layer.")):
@@ -82,6 +89,18 @@ class BertEncoder:
             _lib.check(_lib.lib().bh_encoder_set_tensor(self._h, key.encode(), ctypes.c_void_p(a.data_ptr()), code,
                                                         a.numel()))
             n_set += 1
+        self.num_labels = 0
+        if "classifier.weight" in classifier:  # BertForSequenceClassification checkpoint: classify() available
+            for key, t in classifier.items():
+                a = t.detach().to("cpu")
+                if a.dtype not in (torch.float16, torch.float32):
+                    a = a.float()
+                a = a.contiguous()
+                code = _lib.BH_F16 if a.dtype == torch.float16 else _lib.BH_F32
+                _lib.check(_lib.lib().bh_encoder_set_tensor(self._h, key.encode(), ctypes.c_void_p(a.data_ptr()), code,
+                                                            a.numel()))
+                n_set += 1
+            self.num_labels = int(classifier["classifier.weight"].shape[0])
         _lib.check(_lib.lib().bh_encoder_commit(self._h))
         self.n_tensors = n_set
 
@@ -130,8 +149,9 @@ class BertEncoder:
 
         mask_p, type_p = host(attention_mask), host(token_type_ids)
         dev = torch.device("cuda", self.device_index)
-        shape = (B, T, self.hidden_size) if pool == 2 else (B, self.vocab_size) if pool == 3 else (B, self.hidden_size)
-        out = torch.empty(shape, dtype=torch.float16, device=dev)
+        shape = (B, T, self.hidden_size) if pool == 2 else (B, self.vocab_size) if pool == 3 else \
+            (B, self.num_labels) if pool == 4 else (B, self.hidden_size)
+        out = torch.empty(shape, dtype=torch.float32 if pool == 4 else torch.float16, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # the library runs on its own stream
         _lib.init(self.device_index)
         _lib.check(_lib.lib().bh_encoder_forward(self._h, ctypes.c_void_p(ids.data_ptr()), mask_p, type_p, B, T, pool,
@@ -154,6 +174,13 @@ class BertEncoder:
         if not self.has_mlm_head:
             raise RuntimeError("this encoder was built without cls.predictions.* weights (not a BertForMaskedLM checkpoint)")
         return self._forward(kwargs["input_ids"], kwargs.get("attention_mask"), kwargs.get("token_type_ids"), 3)
+
+    def classify(self, kwargs):
+        """Forward + BertPooler + classifier: [B, num_labels] fp32 logits on the device (the `.logits` of HF
+        BertForSequenceClassification; reference models/rerankers/crossencoder.py:34-38)."""
+        if not self.num_labels:
+            raise RuntimeError("this encoder was built without classifier.* weights (not a sequence-classification checkpoint)")
+        return self._forward(kwargs["input_ids"], kwargs.get("attention_mask"), kwargs.get("token_type_ids"), 4)
 
     def counters(self):
         c = _lib.bh_encoder_counters()

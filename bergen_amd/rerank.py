@@ -1,0 +1,118 @@
+"""
+Rerank stage + cross-encoder plug-in (the consumer of the retrieval stage's top-k list) — same
+constructor kwargs, methods and return dict as the reference, so `modules/rag.py` can drive it unchanged.
+
+Reference -> here
+  Rerank.__init__/eval/sort_by_score_indexes/get_clean_model_name   modules/rerank.py:16-68
+  Reranker (ABC)                                                    models/rerankers/reranker.py:9-19
+  CrossEncoder.__init__/collate_fn/__call__                         models/rerankers/crossencoder.py:13-39
+On a gfx950 device a BERT-architecture sequence-classification checkpoint (BAAI/bge-large-en, ...) runs on
+bergen_amd.BertEncoder: the hand-written encoder forward pass plus the BertPooler / classifier head kernel
+(`classify`, fp32 logits).  The reference pads every (query, passage) pair to max_len (padding="max_length",
+crossencoder.py:30) and runs the padding through the model; the native path packs the attended tokens only.
+Other architectures (DeBERTa-v3, XLM-RoBERTa) stay on their HF module.
+Differences: no torch.nn.DataParallel (crossencoder.py:20-21); scores are fp32 (the reference's
+are the fp16 logits of an fp16 model); `sort_by_score_indexes` keeps Python's stable sort, i.e. ties stay in
+retrieval order, as in the reference.
+"""
+from abc import ABC, abstractmethod
+from collections import defaultdict
+
+import torch
+from torch.utils.data import DataLoader
+from tqdm import tqdm
+
+from . import config as _config
+from .dense import _native_encoder
+
+
+class Reranker(ABC):
+    def __init__(self, model_name=None):
+        self.model_name = model_name
+
+    @abstractmethod
+    def __call__(self, kwargs):
+        pass
+
+    @abstractmethod
+    def collate_fn(self, batch, query_or_doc=None):
+        pass
+
+
+class CrossEncoder(Reranker):
+    def __init__(self, model_name=None, max_len=512, model=None, tokenizer=None):
+        self.model_name = model_name
+        self.max_len = max_len
+        if model is None or tokenizer is None:
+            from transformers import AutoModelForSequenceClassification, AutoTokenizer
+        if model is None:
+            model = AutoModelForSequenceClassification.from_pretrained(self.model_name, low_cpu_mem_usage=True,
+                                                                       torch_dtype=torch.float16)
+        self.model = _native_encoder(model)
+        self.tokenizer = tokenizer if tokenizer is not None else AutoTokenizer.from_pretrained(self.model_name,
+                                                                                               max_length=self.max_len)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if hasattr(self.model, "eval"):
+            self.model.eval()
+
+    def collate_fn(self, examples, query_or_doc=None):
+        question = [e['query'] for e in examples]
+        doc = [e['doc'] for e in examples]
+        q_id = [e['q_id'] for e in examples]
+        d_id = [e['d_id'] for e in examples]
+        inp_dict = self.tokenizer(question, doc, padding="max_length", truncation='only_second', max_length=self.max_len,
+                                  return_tensors='pt')
+        inp_dict['q_id'] = q_id
+        inp_dict['d_id'] = d_id
+        return inp_dict
+
+    @torch.no_grad()
+    def __call__(self, kwargs):
+        if getattr(self.model, "num_labels", 0) and hasattr(self.model, "classify"):
+            return {"score": self.model.classify(kwargs)}  # host BatchEncoding straight through the C ABI
+        kwargs = {k: v.to(self.device) for k, v in kwargs.items()}
+        return {"score": self.model(**kwargs).logits}
+
+
+class Rerank:
+    def __init__(self, init_args=None, batch_size=1):
+        self.batch_size = batch_size
+        self.init_args = init_args
+        self.model = _config.instantiate(self.init_args)  # yaml dict with _target_, or an already built reranker
+        self.model_name = self.model.model_name.replace('/', '_')
+
+    @torch.no_grad()
+    def eval(self, dataset):
+        dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+        self.model.model = self.model.model.to(dev)
+        dataloader = DataLoader(dataset, batch_size=self.batch_size, collate_fn=self.model.collate_fn)
+        q_ids, d_ids, scores = list(), list(), list()
+        for batch in tqdm(dataloader, desc=f'Reranking: {self.model.model_name}'):
+            q_ids += batch.pop('q_id')
+            d_ids += batch.pop('d_id')
+            outputs = self.model(batch)
+            scores.append(outputs['score'].detach().cpu())
+        scores = torch.cat(scores).ravel()
+        q_ids_sorted, d_ids_sorted, scores_sorted = self.sort_by_score_indexes(scores, q_ids, d_ids)
+        self.model.model.to('cpu')
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        return {"score": scores_sorted, "doc_id": d_ids_sorted, "q_id": q_ids_sorted}
+
+    def sort_by_score_indexes(self, scores, q_ids, d_ids):
+        """Per query (first-appearance order), documents by descending score; the score lists stay ragged
+        (modules/rerank.py:50-65)."""
+        ranking = defaultdict(list)
+        q_ids_sorted, doc_ids_sorted, scores_sorted = list(), list(), list()
+        for i, (q_id, d_id) in enumerate(zip(q_ids, d_ids)):
+            ranking[q_id].append((scores[i], d_id))
+        for q_id in ranking:
+            sorted_list = sorted(ranking[q_id], key=lambda x: x[0], reverse=True)
+            score_sorted, d_id_sorted = zip(*sorted_list)
+            scores_sorted.append(torch.stack(score_sorted))
+            doc_ids_sorted.append(list(d_id_sorted))
+            q_ids_sorted.append(q_id)
+        return q_ids_sorted, doc_ids_sorted, scores_sorted
+
+    def get_clean_model_name(self):
+        return self.model_name

@@ -60,6 +60,25 @@ def random_mlm_head(cfg, seed, tied=False, sd=None, bias_mean=-1.5):
     return out
 
 
+def random_cls_head(cfg, seed, num_labels=1, sd=None):
+    """Seeded random BertPooler + classifier weights (HF BertForSequenceClassification names, `bert.` prefix
+    stripped like the rest of this module's state dicts)."""
+    rng = np.random.default_rng(seed)
+    d = cfg["hidden_size"]
+    out = {}
+
+    def put(name, shape, std, mean=0.0):
+        out[name] = (rng.standard_normal(shape) * std + mean).astype(np.float16).astype(np.float32)
+
+    put("pooler.dense.weight", (d, d), 0.08)
+    put("pooler.dense.bias", (d,), 0.05)
+    put("classifier.weight", (num_labels, d), 0.1)
+    put("classifier.bias", (num_labels,), 0.1)
+    if sd is not None:
+        sd.update(out)
+    return out
+
+
 def random_batch(cfg, batch, max_len, seed, min_len=1):
     """Right-padded [B, T] ids / mask / types like an HF tokenizer with padding="longest"."""
     rng = np.random.default_rng(seed)

@@ -165,7 +165,11 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg);
  * AutoModelForMaskedLM for SPLADE, models/retrievers/splade.py:17): the six
  * "cls.predictions.{transform.dense.{weight,bias}, transform.LayerNorm.{weight,bias},
  * decoder.{weight,bias}}" tensors ("cls.predictions.bias" is accepted as the decoder bias).  A head
- * without decoder.weight is tied to the word embeddings; a missing decoder bias is zero. */
+ * without decoder.weight is tied to the word embeddings; a missing decoder bias is zero.
+ * Optional sequence-classification head (HF `BertForSequenceClassification`, which the reference
+ * loads through AutoModelForSequenceClassification for its cross-encoder reranker,
+ * models/rerankers/crossencoder.py:18): "pooler.dense.{weight,bias}" and
+ * "classifier.{weight,bias}" ([num_labels, hidden], num_labels <= 16). */
 int bh_encoder_set_tensor(bh_encoder* enc, const char* name, const void* host, int32_t dtype, int64_t numel);
 /* Check that every tensor of the architecture has been set (BH_EINCOMPLETE otherwise; when any
  * cls.predictions.* tensor was given, the head's transform weights must be complete too). */
@@ -182,6 +186,9 @@ int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
  * max over the attended tokens of log(1 + relu(logit)) -> out is [batch, vocab_size] fp16
  * (replaces Splade.__call__, reference models/retrievers/splade.py:34-47; BH_EINCOMPLETE if the
  * head was not set; the [batch, seq_len, vocab] logits are never materialised).
+ * 4 = sequence classification: tanh(BertPooler) on the first token, then the classifier ->
+ * out is [batch, num_labels] FP32 logits (replaces CrossEncoder.__call__'s
+ * `self.model(**kwargs).logits`, reference models/rerankers/crossencoder.py:34-38).
  * l2_normalize applies to pooled outputs (pool 0 / 1).
  * out is a device pointer when out_on_device != 0 (e.g. the rows of a bh_index, or a torch
  * tensor), else a host pointer.  Replaces Dense.__call__, reference dense.py:37-47. */

@@ -129,6 +129,21 @@ def encode_splade(sd, cfg, input_ids, attention_mask, token_type_ids=None):
     return splade_pool(mlm_logits(sd, cfg, h), attention_mask)
 
 
+def seqcls_logits(sd, cfg, hidden, dtype=np.float64):
+    """BertForSequenceClassification head on [B, T, d] hidden states -> [B, num_labels] (transformers
+    modeling_bert.py: BertPooler :425-  tanh(dense(hidden[:, 0]));  classifier = Linear(d, num_labels); dropout is
+    inactive in eval mode; reached from the reference through AutoModelForSequenceClassification,
+    models/rerankers/crossencoder.py:18,34-38)."""
+    W = lambda k: np.asarray(sd[k], dtype)
+    pooled = np.tanh(hidden[:, 0] @ W("pooler.dense.weight").T + W("pooler.dense.bias"))
+    return pooled @ W("classifier.weight").T + W("classifier.bias")
+
+
+def cross_encode(sd, cfg, input_ids, attention_mask, token_type_ids=None):
+    """CrossEncoder.__call__ (reference crossencoder.py:34-38) -> [B, num_labels] float64 logits."""
+    return seqcls_logits(sd, cfg, bert_forward(sd, cfg, input_ids, attention_mask, token_type_ids))
+
+
 # ---- op-level references for the kernel parity tests -------------------------------------------------------
 
 def gemm_ref(a, w, bias=None, bias_mode=1, residual=None, gelu=False):
@@ -168,4 +183,4 @@ def layernorm_ref(x, g, b, eps):
 
 
 # seeded synthetic weights / batches live in the product package's bench helpers (no arithmetic of the path)
-from bergen_amd.synth import random_batch, random_bert, random_mlm_head  # noqa: E402,F401
+from bergen_amd.synth import random_batch, random_bert, random_cls_head, random_mlm_head  # noqa: E402,F401

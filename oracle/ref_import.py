@@ -71,8 +71,10 @@ def load():
     ref_retrieve = importlib.import_module("modules.retrieve")
     ref_dense = importlib.import_module("models.retrievers.dense")
     ref_splade = importlib.import_module("models.retrievers.splade")
+    ref_rerank = importlib.import_module("modules.rerank")
+    ref_crossencoder = importlib.import_module("models.rerankers.crossencoder")
     _loaded = types.SimpleNamespace(utils=ref_utils, retrieve=ref_retrieve, dense=ref_dense, splade=ref_splade,
-                                    Retrieve=ref_retrieve.Retrieve)
+                                    rerank=ref_rerank, crossencoder=ref_crossencoder, Retrieve=ref_retrieve.Retrieve)
     return _loaded
 
 

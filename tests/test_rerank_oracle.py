@@ -1,0 +1,84 @@
+"""CPU: the rerank stage's host logic and the numpy sequence-classification oracle against HF
+BertForSequenceClassification + the reference's CrossEncoder.__call__ / Rerank.sort_by_score_indexes
+(tests/golden/rerank_tiny.npz, made by oracle/make_golden_rerank.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert_oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rerank_tiny.npz")
+
+
+def load(labels):
+    z = np.load(GOLD)
+    cfg = {k: (float(v) if "." in v or "e-" in v else int(v)) if v.replace(".", "").replace("e-", "").isdigit() else v
+           for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    sd = {k[3:]: z[k].astype(np.float32) for k in z.files if k.startswith("w::")}
+    sd.update({k.split("::", 1)[1]: z[k].astype(np.float32) for k in z.files if k.startswith(f"w_{labels}::")})
+    return z, cfg, sd
+
+
+@pytest.mark.parametrize("labels", [1, 3])
+def test_oracle_matches_hf_through_the_reference_call(labels):
+    z, cfg, sd = load(labels)
+    got = bert_oracle.cross_encode(sd, cfg, z["input_ids"], z["attention_mask"], z["token_type_ids"])
+    assert got.shape == (12, labels)
+    np.testing.assert_allclose(got, z[f"ref_score_{labels}"], rtol=0, atol=2e-5)
+
+
+def test_sort_by_score_indexes_matches_reference():
+    import bergen_amd
+    z, _, _ = load(1)
+    rr = object.__new__(bergen_amd.Rerank)
+    q_ids = [f"q{i // 4}" for i in range(12)]
+    d_ids = [f"d{i}" for i in range(12)]
+    qs, ds, ss = rr.sort_by_score_indexes(torch.from_numpy(z["sort_scores_in"]), q_ids, d_ids)
+    assert qs == list(z["sort_q"])
+    assert ds == [list(r) for r in z["sort_d"]]  # includes a tie: stable, retrieval order kept
+    assert np.array_equal(np.stack([s.numpy() for s in ss]), z["sort_s"])
+
+
+def test_rerank_stage_with_a_stub_model_and_config_aliases():
+    import bergen_amd
+    from bergen_amd import config
+
+    class Stub(bergen_amd.Reranker):
+        def __init__(self):
+            super().__init__("org/stub-reranker")
+            self.model = torch.nn.Identity()
+
+        def collate_fn(self, examples, query_or_doc=None):
+            return {"x": torch.tensor([[float(len(e["doc"]))] for e in examples]),
+                    "q_id": [e["q_id"] for e in examples], "d_id": [e["d_id"] for e in examples]}
+
+        def __call__(self, kwargs):
+            return {"score": kwargs["x"]}
+
+    data = [{"query": "q", "doc": "x" * n, "q_id": f"q{i % 2}", "d_id": f"d{i}"} for i, n in enumerate([3, 9, 5, 1, 7, 2])]
+    r = bergen_amd.Rerank(init_args=Stub(), batch_size=4)
+    out = r.eval(data)
+    assert out["q_id"] == ["q0", "q1"]
+    assert out["doc_id"] == [["d4", "d2", "d0"], ["d1", "d5", "d3"]]
+    assert [s.tolist() for s in out["score"]] == [[7.0, 5.0, 3.0], [9.0, 2.0, 1.0]]
+    assert r.get_clean_model_name() == "org_stub-reranker"
+    assert config._locate("models.rerankers.crossencoder.CrossEncoder") is bergen_amd.CrossEncoder
+    assert config._locate("modules.rerank.Rerank") is bergen_amd.Rerank
+
+
+def test_cross_encoder_collate_matches_reference_contract():
+    """padding='max_length', truncation='only_second', q_id / d_id carried beside the tensors (crossencoder.py:24-33)."""
+    import bergen_amd
+    seen = {}
+
+    class Tok:
+        def __call__(self, a, b, **kw):
+            seen.update(kw, a=a, b=b)
+            return {"input_ids": torch.zeros(len(a), kw["max_length"], dtype=torch.long)}
+
+    ce = bergen_amd.CrossEncoder("org/m", max_len=32, model=torch.nn.Identity(), tokenizer=Tok())
+    out = ce.collate_fn([{"query": "a", "doc": "b", "q_id": "q", "d_id": "d"}])
+    assert seen["padding"] == "max_length" and seen["truncation"] == "only_second" and seen["max_length"] == 32
+    assert seen["a"] == ["a"] and seen["b"] == ["b"] and out["q_id"] == ["q"] and out["d_id"] == ["d"]
