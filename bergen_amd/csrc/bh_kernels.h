@@ -181,6 +181,7 @@ struct BhCsrMergeArgs {
 };
 hipError_t bh_launch_csr_merge_rescore(const BhCsrMergeArgs& a, int kp, int nq_tile, hipStream_t stream);
 
+#define BH_CSR_MFMA_WAVE_LDS 13312  /* per wave: D tile 4 KiB + S tile 8 KiB + hit queue 1 KiB */
 struct BhCsrMfmaArgs {
     const unsigned* entries;
     const long long* row_ptr;
@@ -194,7 +195,9 @@ struct BhCsrMfmaArgs {
     int off_prefix, off_sinfo, off_pairs, off_thr, off_tiles;  // byte offsets of the LDS images
     bh_u64* cand;                  // [grid * 8][64][2 * KP]
     bh_u64* partial;               // [grid][64][KP]
-    unsigned* gthr;                // [64]
+    unsigned* gthr;                // [64 queries][64 slots] threshold slot table (ordf), initialised to BH_ORD_NEG_INF
+    int skip_final;                // pre-pass launch: fill the slot table only, leave no candidate lists
+    unsigned* stats;               // optional diagnostics (BH_SPARSE_STATS): [0] groups with hits [1] appended [2] compactions [3] polls
     int ablate;                    // bench-only: 1 = no scatter, 2 = no candidate handling (results invalid)
 };
 hipError_t bh_launch_csr_scan_mfma(const BhCsrMfmaArgs& a, int kp, int grid, size_t smem, hipStream_t stream);

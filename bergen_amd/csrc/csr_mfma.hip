@@ -49,14 +49,15 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     const int ql = lane & 31, h = lane >> 5;
     const long long gw = (long long)blockIdx.x * NWV + wave, TW = (long long)gridDim.x * NWV;
 
-    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile)
+    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (1 KiB)
     unsigned* bitmap = reinterpret_cast<unsigned*>(smem);
     unsigned short* prefix = reinterpret_cast<unsigned short*>(smem + a.off_prefix);
     unsigned* sinfo = reinterpret_cast<unsigned*>(smem + a.off_sinfo);
     unsigned* pairs = reinterpret_cast<unsigned*>(smem + a.off_pairs);
     unsigned* thr_lds = reinterpret_cast<unsigned*>(smem + a.off_thr);
-    unsigned char* Dt = smem + a.off_tiles + wave * 12288;
+    unsigned char* Dt = smem + a.off_tiles + wave * BH_CSR_MFMA_WAVE_LDS;
     float* St = reinterpret_cast<float*>(Dt + 4096);
+    uint2* Qt = reinterpret_cast<uint2*>(Dt + 12288);  // ring of 128 pending hits: (slot info, fp16 weight | document << 16)
     for (int i = tid; i < a.n_words; i += 512) {
         bitmap[i] = a.bitmap[i];
         prefix[i] = a.prefix[i];
@@ -82,12 +83,19 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         for (int s = 0; s < 4; ++s) d_off[s] = (unsigned)((ql >> 3) * 1024 + (ql & 7) * 128 + (((2 * s + h) ^ g) << 4));
     }
 
+    constexpr int RB = KP / 64;  // a wave publishes its RB-th best appended score (see the exchange below)
     float thr[2];
     unsigned cnt[2];
+    float best[2][RB];  // this half-lane's RB best appended scores, descending
+    float pub[2];
+    long long next_poll = 0;
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2) {
         thr[w2] = -__builtin_inff();
         cnt[w2] = 0;
+        pub[w2] = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < RB; ++r) best[w2][r] = -__builtin_inff();
     }
     u64* cand_w = a.cand + (size_t)gw * 64 * CAP;
 
@@ -107,7 +115,6 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             // KP-th best loses on row index, so the exclusive compare against the wave's own bound is exact
             const float nt = bh_key_score(kth);
             if (ql == qq) thr[w2] = fmaxf(thr[w2], nt);
-            if (lane == qq) atomicMax(&thr_lds[qi], bh_ordf(nt));
         }
     };
 
@@ -140,6 +147,46 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             buf[c] = idx < total ? eb[idx] : 0u;
         }
     };
+    // pending hits of the current group (wave-uniform ring indices)
+    unsigned q_head = 0, q_tail = 0;
+    // resolve n <= 64 queued hits, lane = hit: a head term is ONE fp16 store into the dense tile D, a tail term walks its
+    // short (query, weight) pair list (all lanes busy: the walk costs the longest list among 64 hits, once)
+    auto drain = [&](unsigned n, unsigned rel) {
+        const uint2 it = Qt[(q_head + lane) & 127u];
+        q_head += n;
+        const unsigned p = it.x, ent = it.y;
+        // document of the hit = number of row pointers rel[1..32] (lane l holds rel[l]) that are <= p: a 6-step binary
+        // search with ds_bpermute, all 64 hits at once
+        int dd = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int mid = dd + step;
+            const unsigned bv = (unsigned)__shfl((int)rel, mid < 33 ? mid : 32, 64);
+            if (mid <= 32 && bv <= p) dd = mid;
+        }
+        if (dd > 31) dd = 31;
+        if ((a.ablate & 16) == 0 && (unsigned)lane < n) {  // (16, bench-only: queue without resolving)
+            const unsigned term = ent & 0xffffu;
+            const unsigned word = bitmap[term >> 5];
+            const int slot = (int)prefix[term >> 5] + __builtin_popcount(word & ((1u << (term & 31)) - 1u));
+            const unsigned info = sinfo[slot];
+            if (info & 0x80000000u) {
+                const unsigned hx = info & 63u;
+                const int g = ((dd >> 1) & 1) | ((dd >> 3) << 1);
+                *reinterpret_cast<unsigned short*>(Dt + (dd >> 3) * 1024 + (dd & 7) * 128 + (((hx >> 3) ^ g) << 4) +
+                                                   (hx & 7) * 2) = (unsigned short)(ent >> 16);
+            } else {
+                const float val = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent >> 16));
+                const unsigned off = info >> 8, np = info & 0xffu;
+                float* srow = St + dd * 64;
+                for (unsigned pp = 0; pp < np; ++pp) {
+                    const unsigned pr = pairs[off + pp];
+                    const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+                    atomicAdd(&srow[pr & 63u], val * w);
+                }
+            }
+        }
+    };
     // scatter one super-chunk of the current group into the D / S tiles
     auto process_sc = [&](const unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc) {
 #pragma unroll
@@ -158,36 +205,20 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             const unsigned bit = 1u << (term & 31);
             const bool hit = valid && (word & bit);
             if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;  // wave-uniform
-            // document of the entry = number of row pointers rel[1..32] that are <= p.  The chunk's first entry sits in
-            // document fd (one ballot + popcount over the row pointers held one per lane); a 64-entry chunk rarely
-            // contains more than one or two document boundaries, which are walked with wave-uniform v_readlane.
-            int fd = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane >= 1 && lane <= 32 && rel <= c0));
-            int dd = fd;
-            for (int nb = fd + 1; nb <= 32; ++nb) {
-                const unsigned bpos = __builtin_amdgcn_readlane(rel, nb);
-                if (bpos > c0 + 63u) break;
-                dd += p >= bpos ? 1 : 0;
+            if (a.ablate & 4) {  // bench-only: term-set lookup only
+                asm volatile("" ::"v"(word));
+                continue;
             }
-            if (dd > 31) dd = 31;  // (only lanes past the group's end, which are not hits)
+            // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them here would run
+            // the document search and the divergent slot lookup / pair walk once per chunk.  They are queued instead
+            // (position in the group + entry, compacted by the ballot's prefix count) and resolved 64 at a time by drain().
+            const u64 hm = __builtin_amdgcn_ballot_w64(hit);
             if (hit) {
-                const int slot = (int)prefix[term >> 5] + __builtin_popcount(word & (bit - 1u));
-                const unsigned info = sinfo[slot];
-                if (info & 0x80000000u) {  // head term: one fp16 store into the dense tile
-                    const unsigned hx = info & 63u;
-                    const int g = ((dd >> 1) & 1) | ((dd >> 3) << 1);
-                    *reinterpret_cast<unsigned short*>(Dt + (dd >> 3) * 1024 + (dd & 7) * 128 + (((hx >> 3) ^ g) << 4) +
-                                                       (hx & 7) * 2) = (unsigned short)(ent >> 16);
-                } else {  // tail term: walk its (query, weight) pairs
-                    const float val = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent >> 16));
-                    const unsigned off = info >> 8, n = info & 0xffu;
-                    float* srow = St + dd * 64;
-                    for (unsigned pp = 0; pp < n; ++pp) {
-                        const unsigned pr = pairs[off + pp];
-                        const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
-                        atomicAdd(&srow[pr & 63u], val * w);
-                    }
-                }
+                const unsigned pos = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                Qt[pos & 127u] = make_uint2(p, ent);
             }
+            q_tail += (unsigned)__builtin_popcountll(hm);
+            if (q_tail - q_head >= 64u) drain(64u, rel);
         }
     };
 
@@ -198,6 +229,54 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     unsigned bufA[SC], bufB[SC];
     issue_sc(bufA, a.entries + base, __builtin_amdgcn_readlane(rel, 32), 0u);
     for (long long grp = grp_lo; grp < grp_hi; ++grp, ++n_groups_seen) {
+        // ---- threshold exchange (filter hint only).  A wave sees only a few thousand documents, far too few for its own
+        // KP-th best to become selective, so bounds are shared chip-wide through the dense scan's slot table
+        // (scan_topk.hip): a workgroup atomicMax-es the RB-th best appended score of its best wave into slot blockIdx % 64 of each query; the
+        // minimum over a query's 64 slots is reached by at least 64 * RB = KP distinct documents, hence a valid lower
+        // bound of the final KP-th best.  Geometric schedule of the group ordinal (0, 1, 2, 4, 7, 11, ...), BEFORE the group is
+        // scanned: the very first poll picks up the bounds left by the pre-pass launch (sparse.hip), so that no wave starts
+        // with an open threshold (an open start appends 32 x 64 candidates per group and wave: 8 M per pass).
+        if (!(a.ablate & (2 | 32)) && n_groups_seen >= next_poll) {  // (32, bench-only: no exchange)
+            next_poll = n_groups_seen + 1 + (n_groups_seen >> 1);
+            if (a.stats && lane == 0) atomicAdd(a.stats + 3, 1u);
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                // publish through the workgroup: an LDS atomicMax per query first, and only the wave that RAISES the
+                // workgroup's value goes to the global slot (blockIdx % 64) — 2048 waves hammering 4096 global words with
+                // atomics at every poll stalled the entry stream behind them (stores, atomics and loads retire in order)
+                float mine = best[w2][RB - 1];
+                mine = fmaxf(mine, __shfl_xor(mine, 32, 64));  // either half-lane's RB-th best is reached by RB documents
+                if (h == 0 && mine > pub[w2]) {
+                    pub[w2] = mine;
+                    const unsigned mo = bh_ordf(mine);
+                    const unsigned old = atomicMax(&thr_lds[w2 * 32 + ql], mo);
+                    if (mo > old)
+                        __hip_atomic_fetch_max(a.gthr + (size_t)(w2 * 32 + ql) * 64 + (blockIdx.x & 63), mo, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                uint4 sl[8];  // 16 lanes x 4 slots cover one query; 4 queries per 16-byte load instruction
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int q = w2 * 32 + it * 4 + (lane >> 4);
+                    // (nt: served by L2, not by this CU's L1; a stale value would only mean less filtering)
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gthr + (size_t)q * 64 + (lane & 15) * 4));
+                    sl[it] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    unsigned mn = min(min(sl[it].x, sl[it].y), min(sl[it].z, sl[it].w));
+#pragma unroll
+                    for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
+                    const unsigned got = (unsigned)__shfl((int)mn, (ql & 3) * 16, 64);
+                    // a document that TIES the bound may still win on row index: inclusive compare
+                    if ((ql >> 2) == it && got > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(got - 1u));
+                }
+            }
+        }
         const long long g0 = grp * 32;
         const unsigned total = __builtin_amdgcn_readlane(rel, 32);
         const unsigned nsc = (total + SC * 64 - 1) / (SC * 64);
@@ -221,6 +300,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                 issue_sc(bufA, a.entries + nbase, __builtin_amdgcn_readlane(nrel, 32), 0u);
             process_sc(bufB, rel, total, sc + 1);
         }
+        if (q_tail != q_head) drain(q_tail - q_head, rel);  // (< 64 left)
         // ---- scores = S + D . WhT^T
         floatx16 acc[2];
 #pragma unroll
@@ -245,8 +325,12 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             float m = acc[w2][0];
 #pragma unroll
             for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[w2][v]);
-            if (__builtin_amdgcn_ballot_w64(m > thr[w2]) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64(m > thr[w2]) != 0ull && !(a.ablate & 64)) {  // (64, bench-only: filter, never append)
                 u64 need = __builtin_amdgcn_ballot_w64(cnt[w2] > (unsigned)(CAP - 32)) & 0xffffffffull;
+                if (a.stats && lane == 0) {
+                    atomicAdd(a.stats + 0, 1u);
+                    atomicAdd(a.stats + 2, (unsigned)__builtin_popcountll(need));
+                }
                 while (need) {
                     const int qq = __builtin_ctzll(need);
                     need &= need - 1;
@@ -261,58 +345,83 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                     if (hm != 0ull) {
                         const unsigned hl = ((unsigned)hm >> ql) & 1u;
                         const unsigned hh = ((unsigned)(hm >> 32) >> ql) & 1u;
-                        if (hit) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
-                        cnt[w2] += hl + hh;
+                        if (a.stats && lane == 0) atomicAdd(a.stats + 1, (unsigned)__builtin_popcountll(hm));
+                        if (hit) {
+                            if (!(a.ablate & 256)) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
+                            float x = acc[w2][v];
+#pragma unroll
+                            for (int r = 0; r < RB; ++r) {
+                                const float hi = fmaxf(best[w2][r], x);
+                                x = fminf(best[w2][r], x);
+                                best[w2][r] = hi;
+                            }
+                        }
+                        if (!(a.ablate & 512)) cnt[w2] += hl + hh;  // (512, bench-only: lists stay empty)
                     }
                 }
-            }
-        }
-        // ---- pick up bounds published by other waves (workgroup: LDS, chip: global), now and then
-        if ((n_groups_seen & 3) == 3) {
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                unsigned b = thr_lds[w2 * 32 + ql];
-                if ((n_groups_seen & 15) == 15) {
-                    const unsigned gl = __hip_atomic_load(a.gthr + w2 * 32 + ql, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (b > gl && h == 0)
-                        __hip_atomic_fetch_max(a.gthr + w2 * 32 + ql, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    b = b > gl ? b : gl;
-                }
-                // a document that TIES another wave's bound may still win on row index: inclusive compare
-                if (b > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(b - 1u));
             }
         }
         base = nbase;
         rel = nrel;
     }
 
-    // ---- final: every wave sorts its buffers, then the workgroup folds its 8 lists per query
-#pragma unroll
-    for (int w2 = 0; w2 < 2; ++w2)
-        for (int qq = 0; qq < 32; ++qq) {
-            const unsigned n = __builtin_amdgcn_readlane(cnt[w2], qq);
-            u64* buf = cand_w + (size_t)(w2 * 32 + qq) * CAP;
-            u64 e[EPLC];
-            load_keys_m<EPLC>(e, buf, n, lane);
-            bh_wave_sort_desc<EPLC>(e, lane);
-#pragma unroll
-            for (int r = 0; r < EPLK; ++r) buf[r * 64 + lane] = e[r];
-        }
+    // ---- final: the workgroup folds its 8 waves' candidate buffers per query.  With working thresholds a buffer holds
+    // a handful of keys, so the usual case is ONE sort of the concatenated buffers (<= CAP keys); only a query whose
+    // waves hold more than that falls back to sorting each buffer and merging.
+    if (a.skip_final || (a.ablate & 128)) return;  // (pre-pass launch: only the slot table is wanted; 128: bench-only)
+    unsigned* cnt_out = reinterpret_cast<unsigned*>(St);  // this wave's 64 counts, in its (now idle) S tile
+    if (h == 0) {
+        cnt_out[ql] = cnt[0];
+        cnt_out[32 + ql] = cnt[1];
+    }
     __syncthreads();
     for (int qi = wave; qi < 64; qi += NWV) {
-        u64 best[EPLK];
+        unsigned c[NWV], tot = 0;
 #pragma unroll
-        for (int r = 0; r < EPLK; ++r) best[r] = 0ull;
-        for (int w2 = 0; w2 < NWV; ++w2) {
-            const u64* lst = a.cand + ((size_t)((long long)blockIdx.x * NWV + w2) * 64 + qi) * CAP;
-            u64 bb[EPLK];
-#pragma unroll
-            for (int r = 0; r < EPLK; ++r) bb[r] = lst[r * 64 + lane];
-            bh_wave_merge_top<EPLK>(best, bb, lane);
+        for (int w = 0; w < NWV; ++w) {
+            c[w] = *reinterpret_cast<const unsigned*>(smem + a.off_tiles + w * BH_CSR_MFMA_WAVE_LDS + 4096 + qi * 4);
+            c[w] = __builtin_amdgcn_readfirstlane(c[w]);
+            tot += c[w];
         }
+        const u64* lists = a.cand + ((size_t)((long long)blockIdx.x * NWV) * 64 + qi) * CAP;  // + w * 64 * CAP
         u64* out = a.partial + ((size_t)blockIdx.x * 64 + qi) * KP;
+        if (tot <= (unsigned)CAP) {
+            u64 e[EPLC];
 #pragma unroll
-        for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = best[r];
+            for (int r = 0; r < EPLC; ++r) {
+                unsigned idx = r * 64 + lane;
+                u64 key = 0ull;
+                if (idx < tot) {
+                    int w = 0;
+#pragma unroll
+                    for (int ww = 0; ww < NWV - 1; ++ww)
+                        if (w == ww && idx >= c[ww]) {
+                            idx -= c[ww];
+                            w = ww + 1;
+                        }
+                    key = lists[(size_t)w * 64 * CAP + idx];
+                }
+                e[r] = key;
+            }
+            bh_wave_sort_desc<EPLC>(e, lane);
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = e[r];
+        } else {
+            u64 best[EPLK];
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) best[r] = 0ull;
+            for (int w = 0; w < NWV; ++w) {
+                u64 e[EPLC];
+                load_keys_m<EPLC>(e, lists + (size_t)w * 64 * CAP, c[w], lane);
+                bh_wave_sort_desc<EPLC>(e, lane);
+                u64 bb[EPLK];
+#pragma unroll
+                for (int r = 0; r < EPLK; ++r) bb[r] = e[r];
+                bh_wave_merge_top<EPLK>(best, bb, lane);
+            }
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = best[r];
+        }
     }
 }
 

@@ -218,7 +218,7 @@ int bh_set_option(const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_kernel must be 0 (broadcast) or 1 (mfma)");
         bh_sparse_set_kernel((int)value);
     } else if (s == "sparse_ablate") {
-        if (value < 0 || value > 3) return fail(BH_EINVAL, "sparse_ablate must be 0..3");
+        if (value < 0 || value > 1023) return fail(BH_EINVAL, "sparse_ablate must be 0..1023");
         bh_sparse_set_ablate((int)value);
     } else if (s == "gemm_stagger_phases") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");

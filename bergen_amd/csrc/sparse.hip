@@ -11,6 +11,9 @@
 // There is no CPU fallback: every entry point that computes needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -238,7 +241,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const int grid = ix->n_cu;
     int rc;
     if ((rc = ix->partial.ensure((size_t)grid * 64 * kp))) return rc;
-    if ((rc = ix->gthr.ensure(64))) return rc;
+    if ((rc = ix->gthr.ensure(64 * 64 + 8))) return rc;  // [64 queries][64 slots] (csr_mfma.hip); csr_topk.hip uses the first 64 words
     if ((rc = ix->bitmap.ensure((size_t)n_words))) return rc;
     if ((rc = ix->prefix.ensure((size_t)n_words))) return rc;
     if ((rc = ix->W.ensure((size_t)(max_slots + 1) * 64))) return rc;
@@ -266,7 +269,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const int waves_per_wg = mfma ? 8 : 16;
     if ((rc = ix->cand.ensure((size_t)grid * waves_per_wg * 64 * 2 * kp))) return rc;
     // LDS budget of the MFMA kernel: tables + 8 waves x (4 KiB D tile + 8 KiB S tile)
-    const int mfma_fixed = n_words * 6 + 16 + 256 + 8 * 12288;
+    const int mfma_fixed = n_words * 6 + 16 + 256 + 8 * BH_CSR_MFMA_WAVE_LDS;
     const int mfma_table_bytes = kLdsBytes - mfma_fixed;  // for sinfo (4 B per slot) + pairs (4 B per pair)
     if (mfma && mfma_table_bytes < 4096) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile tables", V);
 
@@ -274,7 +277,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     std::vector<unsigned short> pf((size_t)n_words);
     std::vector<unsigned short> Wh((size_t)(max_slots + 1) * 64);
     std::vector<unsigned short> qd((size_t)kTileQ * V);
-    std::vector<unsigned> gt(64, 0x007fffffu);
+    std::vector<unsigned> gt(64 * 64, 0x007fffffu);
     std::vector<int> term_cnt((size_t)V, 0);
     std::vector<unsigned> sinfo_h, pairs_h;
     std::vector<unsigned short> WhT_h((size_t)64 * 64);
@@ -323,7 +326,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         BH_HIP_TRY(hipMemcpyAsync(ix->bitmap.p, bm.data(), (size_t)n_words * 4, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->prefix.p, pf.data(), (size_t)n_words * 2, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->qdense.p, qd.data(), (size_t)nt * V * 2, hipMemcpyHostToDevice, st));
-        BH_HIP_TRY(hipMemcpyAsync(ix->gthr.p, gt.data(), 64 * 4, hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(hipMemcpyAsync(ix->gthr.p, gt.data(), 64 * 64 * 4, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
         if (!mfma) {
             std::fill(Wh.begin(), Wh.begin() + (size_t)(n_slots + 1) * 64, (unsigned short)0);
@@ -414,9 +417,21 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             ma2.partial = ix->partial.p;
             ma2.gthr = ix->gthr.p;
             ma2.ablate = g_sparse_ablate;
-            const size_t smem2 = (size_t)ma2.off_tiles + 8 * 12288;
+            static const bool want_stats = getenv("BH_SPARSE_STATS") != nullptr;  // diagnostics: candidate-path event counts
+            ma2.stats = want_stats ? ix->gthr.p + 64 * 64 : nullptr;
+            if (want_stats) BH_HIP_TRY(hipMemsetAsync(ma2.stats, 0, 8 * sizeof(unsigned), st));
+            const size_t smem2 = (size_t)ma2.off_tiles + 8 * BH_CSR_MFMA_WAVE_LDS;
             if (smem2 > (size_t)kLdsBytes) return bh_fail(BH_EHIP, "internal: sparse tile exceeds LDS (%zu bytes)", smem2);
             BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+            // Pre-pass: the same kernel over a short prefix of the corpus with a small grid, only to fill the threshold
+            // slot table (its candidate lists are overwritten by the main launch, which scans the prefix again).
+            const long long pre_rows = 16LL * 8 * 4 * 32;  // 16 workgroups x 8 waves x 4 groups
+            if (ix->n_rows > 4 * pre_rows && grid >= 16) {
+                BhCsrMfmaArgs pre = ma2;
+                pre.n_rows = pre_rows;
+                pre.skip_final = 1;
+                BH_HIP_TRY(bh_launch_csr_scan_mfma(pre, kp, 16, smem2, st));
+            }
             BH_HIP_TRY(bh_launch_csr_scan_mfma(ma2, kp, grid, smem2, st));
         }
         BH_HIP_TRY(hipEventRecord(ix->ev[2], st));
@@ -435,6 +450,11 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         BH_HIP_TRY(bh_launch_csr_merge_rescore(ma, kp, nt, st));
         BH_HIP_TRY(hipEventRecord(ix->ev[3], st));
         BH_HIP_TRY(hipStreamSynchronize(st));  // the host tables are rebuilt for the next tile
+        if (mfma && getenv("BH_SPARSE_STATS")) {
+            unsigned stv[8];
+            BH_HIP_TRY(hipMemcpy(stv, ix->gthr.p + 64 * 64, sizeof(stv), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bh sparse stats] groups_with_hits=%u appended=%u compactions=%u polls=%u\n", stv[0], stv[1], stv[2], stv[3]);
+        }
         float ms = 0;
         BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]));
         scan_ms += ms;

@@ -59,7 +59,12 @@ def main():
     dt, c = best
     abl = {}
     if args.ablate:
-        for bits, what in ((1, "no scatter (stream + MFMA + candidates)"), (2, "no candidate handling"), (3, "stream + MFMA only")):
+        for bits, what in ((1, "no scatter (stream + MFMA + candidates)"), (2, "no candidate handling"), (3, "stream + MFMA only"),
+                           (6, "stream + term-set lookup + MFMA"), (18, "+ hit queue + document search, unresolved"),
+                           (32, "everything, no threshold exchange"), (64, "everything, filter never appends"),
+                           (128, "everything, no final sort / fold"), (64 + 128, "filter never appends, no final phase"),
+                           (2 + 128, "no candidate handling, no final phase"), (256, "everything, appends without the store"),
+                           (512, "everything, appends not counted"), (256 + 512, "appends: no store, not counted")):
             _lib.set_option("sparse_ablate", bits)
             ix.search(q, args.k)
             ca = ix.counters()
