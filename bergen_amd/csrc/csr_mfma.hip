@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     const int ql = lane & 31, h = lane >> 5;
     const long long gw = (long long)blockIdx.x * NWV + wave, TW = (long long)gridDim.x * NWV;
 
-    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (1 KiB)
+    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | WhT (64 x 144 B) | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (1 KiB)
     unsigned* bitmap = reinterpret_cast<unsigned*>(smem);
     unsigned short* prefix = reinterpret_cast<unsigned short*>(smem + a.off_prefix);
     unsigned* sinfo = reinterpret_cast<unsigned*>(smem + a.off_sinfo);
@@ -67,14 +67,15 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     if (tid < 64) thr_lds[tid] = BH_ORD_NEG_INF;
     __syncthreads();
 
-    // ---- B fragments of the head-term weights, resident in registers: lane (query ql [+32 w2], k-group h),
-    // k-step s covers head terms 16 s + 8 h .. + 8
-    half8 wf[2][4];
-#pragma unroll
-    for (int w2 = 0; w2 < 2; ++w2)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            wf[w2][s] = *reinterpret_cast<const half8*>(a.WhT + (size_t)(w2 * 32 + ql) * 64 + 16 * s + 8 * h);
+    // ---- head-term weights WhT[query][head] (MFMA operand B) live in LDS, rows padded to 144 bytes so that the
+    // per-group fragment reads (lane = query) are conflict-free; keeping the 8 fragments in registers for the whole
+    // launch cost 32 VGPRs the kernel does not have
+    unsigned char* whl = smem + a.off_thr + 256;
+    {
+        const int row = tid >> 3, ch = tid & 7;  // 64 rows x 8 chunks of 16 bytes
+        *reinterpret_cast<uint4*>(whl + row * 144 + ch * 16) = *reinterpret_cast<const uint4*>(a.WhT + (size_t)row * 64 + ch * 8);
+    }
+    __syncthreads();
     // A-fragment read offsets in the D tile (same XOR-permuted 128-byte-row image as the GEMM: conflict-free)
     unsigned d_off[4];
     {
@@ -257,23 +258,29 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             }
 #pragma unroll
             for (int w2 = 0; w2 < 2; ++w2) {
-                uint4 sl[8];  // 16 lanes x 4 slots cover one query; 4 queries per 16-byte load instruction
+                // 16 lanes x 4 slots cover one query, 4 queries per 16-byte load instruction; two batches of four loads
+                // (eight in flight cost 16 more registers than the kernel has)
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int q = w2 * 32 + it * 4 + (lane >> 4);
-                    // (nt: served by L2, not by this CU's L1; a stale value would only mean less filtering)
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gthr + (size_t)q * 64 + (lane & 15) * 4));
-                    sl[it] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                }
+                for (int hb = 0; hb < 2; ++hb) {
+                    uint4 sl[4];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    unsigned mn = min(min(sl[it].x, sl[it].y), min(sl[it].z, sl[it].w));
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const int q = w2 * 32 + (hb * 4 + i4) * 4 + (lane >> 4);
+                        // (nt: served by L2, not by this CU's L1; a stale value would only mean less filtering)
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gthr + (size_t)q * 64 + (lane & 15) * 4));
+                        sl[i4] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                    }
 #pragma unroll
-                    for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
-                    const unsigned got = (unsigned)__shfl((int)mn, (ql & 3) * 16, 64);
-                    // a document that TIES the bound may still win on row index: inclusive compare
-                    if ((ql >> 2) == it && got > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(got - 1u));
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const int it = hb * 4 + i4;
+                        unsigned mn = min(min(sl[i4].x, sl[i4].y), min(sl[i4].z, sl[i4].w));
+#pragma unroll
+                        for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
+                        const unsigned got = (unsigned)__shfl((int)mn, (ql & 3) * 16, 64);
+                        // a document that TIES the bound may still win on row index: inclusive compare
+                        if ((ql >> 2) == it && got > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(got - 1u));
+                    }
                 }
             }
         }
@@ -307,9 +314,14 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[w2][v] = St[((v & 3) + 8 * (v >> 2) + 4 * h) * 64 + w2 * 32 + ql];
-        half8 df[4];
+        half8 df[4], wf[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) df[s] = *reinterpret_cast<const half8*>(Dt + d_off[s]);
+        // lane (query ql [+32 w2], k-group h), k-step s covers head terms 16 s + 8 h .. + 8
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wf[w2][s] = *reinterpret_cast<const half8*>(whl + (w2 * 32 + ql) * 144 + (2 * s + h) * 16);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll

@@ -269,7 +269,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const int waves_per_wg = mfma ? 8 : 16;
     if ((rc = ix->cand.ensure((size_t)grid * waves_per_wg * 64 * 2 * kp))) return rc;
     // LDS budget of the MFMA kernel: tables + 8 waves x (4 KiB D tile + 8 KiB S tile)
-    const int mfma_fixed = n_words * 6 + 16 + 256 + 8 * BH_CSR_MFMA_WAVE_LDS;
+    const int mfma_fixed = n_words * 6 + 16 + 256 + 64 * 144 + 32 + 8 * BH_CSR_MFMA_WAVE_LDS;
     const int mfma_table_bytes = kLdsBytes - mfma_fixed;  // for sinfo (4 B per slot) + pairs (4 B per pair)
     if (mfma && mfma_table_bytes < 4096) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile tables", V);
 
@@ -411,8 +411,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             ma2.off_prefix = n_words * 4;
             ma2.off_sinfo = (ma2.off_prefix + n_words * 2 + 15) / 16 * 16;
             ma2.off_pairs = ma2.off_sinfo + n_slots * 4;
-            ma2.off_thr = ma2.off_pairs + n_pairs * 4;
-            ma2.off_tiles = (ma2.off_thr + 256 + 15) / 16 * 16;
+            ma2.off_thr = (ma2.off_pairs + n_pairs * 4 + 15) / 16 * 16;
+            ma2.off_tiles = (ma2.off_thr + 256 + 64 * 144 + 15) / 16 * 16;  // thr[64] | WhT image | per-wave tiles
             ma2.cand = ix->cand.p;
             ma2.partial = ix->partial.p;
             ma2.gthr = ix->gthr.p;
