@@ -181,7 +181,8 @@ struct BhCsrMergeArgs {
 };
 hipError_t bh_launch_csr_merge_rescore(const BhCsrMergeArgs& a, int kp, int nq_tile, hipStream_t stream);
 
-#define BH_CSR_MFMA_WAVE_LDS 13312  /* per wave: D tile 4 KiB + S tile 8 KiB + hit queue 1 KiB */
+#define BH_CSR_MFMA_QUEUE 512       /* pending-hit ring entries per wave (8 bytes each) */
+#define BH_CSR_MFMA_WAVE_LDS 16384  /* per wave: D tile 4 KiB + S tile 8 KiB + hit queue 4 KiB */
 struct BhCsrMfmaArgs {
     const unsigned* entries;
     const long long* row_ptr;

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     const int ql = lane & 31, h = lane >> 5;
     const long long gw = (long long)blockIdx.x * NWV + wave, TW = (long long)gridDim.x * NWV;
 
-    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | WhT (64 x 144 B) | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (1 KiB)
+    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | WhT (64 x 144 B) | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (4 KiB)
     unsigned* bitmap = reinterpret_cast<unsigned*>(smem);
     unsigned short* prefix = reinterpret_cast<unsigned short*>(smem + a.off_prefix);
     unsigned* sinfo = reinterpret_cast<unsigned*>(smem + a.off_sinfo);
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     unsigned* thr_lds = reinterpret_cast<unsigned*>(smem + a.off_thr);
     unsigned char* Dt = smem + a.off_tiles + wave * BH_CSR_MFMA_WAVE_LDS;
     float* St = reinterpret_cast<float*>(Dt + 4096);
-    uint2* Qt = reinterpret_cast<uint2*>(Dt + 12288);  // ring of 128 pending hits: (slot info, fp16 weight | document << 16)
+    uint2* Qt = reinterpret_cast<uint2*>(Dt + 12288);  // ring of BH_CSR_MFMA_QUEUE pending hits: (position in the group, entry)
     for (int i = tid; i < a.n_words; i += 512) {
         bitmap[i] = a.bitmap[i];
         prefix[i] = a.prefix[i];
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     // resolve n <= 64 queued hits, lane = hit: a head term is ONE fp16 store into the dense tile D, a tail term walks its
     // short (query, weight) pair list (all lanes busy: the walk costs the longest list among 64 hits, once)
     auto drain = [&](unsigned n, unsigned rel) {
-        const uint2 it = Qt[(q_head + lane) & 127u];
+        const uint2 it = Qt[(q_head + lane) & (BH_CSR_MFMA_QUEUE - 1)];
         q_head += n;
         const unsigned p = it.x, ent = it.y;
         // document of the hit = number of row pointers rel[1..32] (lane l holds rel[l]) that are <= p: a 6-step binary
@@ -188,41 +188,64 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             }
         }
     };
-    // scatter one super-chunk of the current group into the D / S tiles
-    auto process_sc = [&](const unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc) {
+    // scatter one super-chunk of the current group into the D / S tiles.  CODE SIZE matters here: fully unrolled over
+    // the SC register-resident chunks (with the drain inlined per chunk) this kernel was 95 KiB of instructions, more
+    // than the 64 KiB instruction cache two CUs share, and every group streamed most of it.  The chunks are therefore
+    // processed four at a time in a ROLLED loop; the register array is shifted down by four after each step (60 v_mov
+    // per 1536 entries) so that the body always addresses buf[0..3].
+    auto process_sc = [&](unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc) {
+#pragma unroll 1
+        for (int step = 0; step < SC / 4; ++step) {
+            const unsigned cbase = (sc * SC + step * 4) * 64;
+            if (cbase >= total) break;  // wave-uniform
+            if (a.ablate & 1) {         // bench-only: stream the entries, no scatter
+                asm volatile("" ::"v"(buf[0]), "v"(buf[1]), "v"(buf[2]), "v"(buf[3]));
+            } else {
 #pragma unroll
-        for (int c = 0; c < SC; ++c) {
-            const unsigned c0 = (sc * SC + c) * 64;
-            if (c0 >= total) break;  // wave-uniform
-            if (a.ablate & 1) {      // bench-only: stream the entries, no scatter
-                asm volatile("" ::"v"(buf[c]));
-                continue;
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned p = cbase + c * 64 + lane;
+                    const unsigned ent = buf[c];
+                    const unsigned term = ent & 0xffffu;
+                    const unsigned word = bitmap[term >> 5];
+                    const bool hit = p < total && (word & (1u << (term & 31)));
+                    // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them here
+                    // would run the document search and the divergent slot lookup / pair walk once per chunk.  They
+                    // are queued instead (position in the group + entry, compacted by the ballot's prefix count) and
+                    // resolved 64 at a time by drain().
+                    const u64 hm = __builtin_amdgcn_ballot_w64(hit);
+                    if (hm != 0ull && !(a.ablate & 4)) {  // (4, bench-only: term-set lookup only)
+                        if (hit) {
+                            const unsigned pos = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                            Qt[pos & (BH_CSR_MFMA_QUEUE - 1)] = make_uint2(p, ent);
+                        }
+                        q_tail += (unsigned)__builtin_popcountll(hm);
+                    }
+                }
+                while (q_tail - q_head >= 64u) drain(64u, rel);
             }
-            const unsigned p = c0 + lane;
-            const bool valid = p < total;
-            const unsigned ent = buf[c];
-            const unsigned term = ent & 0xffffu;
-            const unsigned word = bitmap[term >> 5];
-            const unsigned bit = 1u << (term & 31);
-            const bool hit = valid && (word & bit);
-            if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;  // wave-uniform
-            if (a.ablate & 4) {  // bench-only: term-set lookup only
-                asm volatile("" ::"v"(word));
-                continue;
-            }
-            // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them here would run
-            // the document search and the divergent slot lookup / pair walk once per chunk.  They are queued instead
-            // (position in the group + entry, compacted by the ballot's prefix count) and resolved 64 at a time by drain().
-            const u64 hm = __builtin_amdgcn_ballot_w64(hit);
-            if (hit) {
-                const unsigned pos = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                Qt[pos & 127u] = make_uint2(p, ent);
-            }
-            q_tail += (unsigned)__builtin_popcountll(hm);
-            if (q_tail - q_head >= 64u) drain(64u, rel);
+#pragma unroll
+            for (int j = 0; j + 4 < SC; ++j) buf[j] = buf[j + 4];
         }
     };
 
+    auto publish = [&]() {
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            // publish through the workgroup: an LDS atomicMax per query first, and only the wave that RAISES the
+            // workgroup's value goes to the global slot (blockIdx % 64) — 2048 waves hammering 4096 global words with
+            // atomics at every poll stalled the entry stream behind them (stores, atomics and loads retire in order)
+            float mine = best[w2][RB - 1];
+            mine = fmaxf(mine, __shfl_xor(mine, 32, 64));  // either half-lane's RB-th best is reached by RB documents
+            if (h == 0 && mine > pub[w2]) {
+                pub[w2] = mine;
+                const unsigned mo = bh_ordf(mine);
+                const unsigned old = atomicMax(&thr_lds[w2 * 32 + ql], mo);
+                if (mo > old)
+                    __hip_atomic_fetch_max(a.gthr + (size_t)(w2 * 32 + ql) * 64 + (blockIdx.x & 63), mo, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     long long n_groups_seen = 0;
     long long base, nbase;
     unsigned rel, nrel;
@@ -240,22 +263,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         if (!(a.ablate & (2 | 32)) && n_groups_seen >= next_poll) {  // (32, bench-only: no exchange)
             next_poll = n_groups_seen + 1 + (n_groups_seen >> 1);
             if (a.stats && lane == 0) atomicAdd(a.stats + 3, 1u);
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                // publish through the workgroup: an LDS atomicMax per query first, and only the wave that RAISES the
-                // workgroup's value goes to the global slot (blockIdx % 64) — 2048 waves hammering 4096 global words with
-                // atomics at every poll stalled the entry stream behind them (stores, atomics and loads retire in order)
-                float mine = best[w2][RB - 1];
-                mine = fmaxf(mine, __shfl_xor(mine, 32, 64));  // either half-lane's RB-th best is reached by RB documents
-                if (h == 0 && mine > pub[w2]) {
-                    pub[w2] = mine;
-                    const unsigned mo = bh_ordf(mine);
-                    const unsigned old = atomicMax(&thr_lds[w2 * 32 + ql], mo);
-                    if (mo > old)
-                        __hip_atomic_fetch_max(a.gthr + (size_t)(w2 * 32 + ql) * 64 + (blockIdx.x & 63), mo, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            publish();
 #pragma unroll
             for (int w2 = 0; w2 < 2; ++w2) {
                 // 16 lanes x 4 slots cover one query, 4 queries per 16-byte load instruction; two batches of four loads
@@ -349,18 +357,24 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                     compact(w2, qq);
                 }
                 u64* buf = cand_w + (size_t)(w2 * 32 + ql) * CAP;
-#pragma unroll
+                // rolled (the score registers are shifted down once per step): this path is entered a few dozen times per
+                // wave, each time from a cold instruction cache, so its cost is its code size
+                floatx16 sc16 = acc[w2];
+#pragma unroll 1
                 for (int v = 0; v < 16; ++v) {
                     const long long row = g0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    const bool hit = (acc[w2][v] > thr[w2]) && (row < a.n_rows);
+                    const float sv = sc16[0];
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) sc16[j] = sc16[j + 1];
+                    const bool hit = (sv > thr[w2]) && (row < a.n_rows);
                     const u64 hm = __builtin_amdgcn_ballot_w64(hit);
                     if (hm != 0ull) {
                         const unsigned hl = ((unsigned)hm >> ql) & 1u;
                         const unsigned hh = ((unsigned)(hm >> 32) >> ql) & 1u;
                         if (a.stats && lane == 0) atomicAdd(a.stats + 1, (unsigned)__builtin_popcountll(hm));
                         if (hit) {
-                            if (!(a.ablate & 256)) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(acc[w2][v], (unsigned)row);
-                            float x = acc[w2][v];
+                            if (!(a.ablate & 256)) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(sv, (unsigned)row);
+                            float x = sv;
 #pragma unroll
                             for (int r = 0; r < RB; ++r) {
                                 const float hi = fmaxf(best[w2][r], x);
@@ -376,6 +390,8 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         base = nbase;
         rel = nrel;
     }
+
+    if (!(a.ablate & (2 | 32))) publish();  // what the wave learnt in its last groups (the pre-pass relies on this)
 
     // ---- final: the workgroup folds its 8 waves' candidate buffers per query.  With working thresholds a buffer holds
     // a handful of keys, so the usual case is ONE sort of the concatenated buffers (<= CAP keys); only a query whose

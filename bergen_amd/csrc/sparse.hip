@@ -425,12 +425,13 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
             // Pre-pass: the same kernel over a short prefix of the corpus with a small grid, only to fill the threshold
             // slot table (its candidate lists are overwritten by the main launch, which scans the prefix again).
-            const long long pre_rows = 16LL * 8 * 4 * 32;  // 16 workgroups x 8 waves x 4 groups
-            if (ix->n_rows > 4 * pre_rows && grid >= 16) {
+            // 64 workgroups: one per slot of the table (a slot nobody wrote leaves the bound open)
+            const long long pre_rows = 64LL * 8 * 2 * 32;  // 64 workgroups x 8 waves x 2 groups
+            if (ix->n_rows > 4 * pre_rows && grid >= 64) {
                 BhCsrMfmaArgs pre = ma2;
                 pre.n_rows = pre_rows;
                 pre.skip_final = 1;
-                BH_HIP_TRY(bh_launch_csr_scan_mfma(pre, kp, 16, smem2, st));
+                BH_HIP_TRY(bh_launch_csr_scan_mfma(pre, kp, 64, smem2, st));
             }
             BH_HIP_TRY(bh_launch_csr_scan_mfma(ma2, kp, grid, smem2, st));
         }
