@@ -57,6 +57,8 @@ def parse_args():
     p.add_argument("--no-encoder", action="store_true", help="skip the passages-encoded/s leg")
     p.add_argument("--enc-batch", type=int, default=512, help="sequences per encoder step (retromae.yaml batch_size)")
     p.add_argument("--enc-steps", type=int, default=3)
+    p.add_argument("--no-splade", action="store_true", help="skip the SPLADE legs (configs[3]: MLM-head encode, sparse search)")
+    p.add_argument("--splade-docs", type=int, default=4_000_000, help="documents of the synthetic SPLADE corpus (S4)")
     p.add_argument("--sweep", action="store_true", help="also time kernel variants (written to gpurun_out/sweep.json)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                    help="optional PMC-derived HBM bytes per scan launch (written by profiles/collect_pmc.py)")
@@ -177,6 +179,84 @@ def encoder_leg(args, device_index):
                              "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
                              "algorithmic_flops_per_step": c["flops"]},
     }
+
+
+def splade_legs(args, device_index):
+    """BASELINE configs[3] (SPLADE), both halves, as secondary figures beside the headline (N = 1 only):
+    * encode: BERT-base + tied masked-LM head over 30 522 terms + max-over-tokens pooling on the encoder leg's batch
+      (`BertEncoder.encode_splade`; the [B, T, vocab] logits are never materialised);
+    * search: SURVEY §8d S4 — synthetic CSR corpus (V = 30 522, ~110 terms per document kept, Zipf term ids), 64-query
+      tiles, top-k; roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per tile pass.
+    A 200 k-document slice is checked bit-exactly against the oracle's canonical sparse search."""
+    from bergen_amd import BertEncoder, SparseIndex, synth
+    out = {}
+    cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = synth.random_bert(cfg, seed=31)
+    synth.random_mlm_head(cfg, seed=32, tied=True, sd=sd, bias_mean=-3.0)
+    enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=device_index)
+    rng = np.random.default_rng(6)
+    lens = np.clip(np.rint(rng.normal(130, 30, size=args.enc_batch)), 16, 256).astype(np.int64)
+    T = int(lens.max())
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    ids = rng.integers(1, cfg["vocab_size"], size=(args.enc_batch, T)).astype(np.int64) * mask
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    enc.encode_splade(kw)
+    torch.cuda.synchronize()
+    ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.enc_steps):
+        emb = enc.encode_splade(kw)
+        ms += enc.counters()["forward_ms"]
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    c = enc.counters()
+    out["splade_encode"] = {
+        "passages_per_s": args.enc_batch * args.enc_steps / wall, "ms_per_step_kernels": ms / args.enc_steps,
+        "tflops": c["flops"] / (ms / args.enc_steps * 1e-3) / 1e12,
+        "workload": f"BERT-base + tied MLM head (30522 terms) + SPLADE pooling, {args.enc_batch} synthetic passages/step, "
+                    f"{int(c['real_tokens'])} real tokens, random-init weights",
+        "finite_and_shaped": bool(torch.isfinite(emb.float()).all()) and tuple(emb.shape) == (args.enc_batch, 30522)}
+    del emb
+    enc.close()
+    V, block = 30522, 1_000_000
+    blk = synth.random_sparse_corpus_fast(min(block, args.splade_docs), V, seed=4)
+    ix = SparseIndex(args.splade_docs, V, device=device_index)
+    done = 0
+    while done < args.splade_docs:  # the corpus is the block repeated (timing depends on sizes only)
+        m = min(len(blk[0]) - 1, args.splade_docs - done)
+        ix.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
+        done += m
+    ix.finalize()
+    qp, qt, qw = synth.random_sparse_corpus_fast(256, V, seed=5, mean_nnz=24, lo=4, hi=64)
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    ix.search(q[:64], args.k)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ix.search(q, args.k)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, ix.counters())
+    dt, c = best
+    gbps = c["algorithmic_bytes"] / (c["scan_ms"] * 1e-3) / 1e9
+    from oracle import c_oracle  # checker only
+    m = min(len(blk[0]) - 1, 200_000)
+    sub = SparseIndex(m, V, device=device_index)
+    sub.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
+    sub.finalize()
+    s2, i2 = sub.search(q[:8], args.k)
+    ws, wi = c_oracle.sparse_canonical_search(blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]], V, q[:8], args.k)
+    ok = bool(np.array_equal(i2, wi) and np.array_equal(s2.view(np.uint32), ws.view(np.uint32)))
+    out["splade_search"] = {
+        "queries_per_s": 256 / dt, "docs": args.splade_docs, "nnz": int(ix.nnz), "scan_ms_per_pass": c["scan_ms"] / c["n_passes"],
+        "roofline": {"bound": "hbm", "kernel": "bh_csr_scan_mfma_kernel", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": c["algorithmic_bytes"] / c["n_passes"]},
+        "parity_check": "pass" if ok else "FAIL"}
+    sub.close()
+    ix.close()
+    return out
 
 
 def main():
@@ -319,6 +399,8 @@ def main():
         if not args.no_encoder and world == 1:
             ix.close()  # the search index is no longer needed: give the HBM back before the encoder leg
             out.update(encoder_leg(args, local_rank))
+            if not args.no_splade:
+                out.update(splade_legs(args, local_rank))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, dim, k)
         print(json.dumps(out), flush=True)
