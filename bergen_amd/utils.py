@@ -110,3 +110,123 @@ def merge_indexes(in_paths, out_path):
             made.append((link, os.path.join(in_path, chunk)))
         current_global_index = newidx + 1
     return made
+
+
+# ---- doc-id mapping + context fetch ----------------------------------------------------------
+class IdIndex:
+    """Compact id -> row table for a corpus' string ids.
+
+    The reference keeps ``dataset.id2index`` as a pickled Python dict (modules/dataset_processor.py:88-100): 24.85 M
+    str keys for KILT-100w, several GB of objects, and `retrieve.py:58` additionally materialises the id column as a
+    Python list.  Here the ids live in ONE fixed-width numpy bytes array, sorted once; lookups are vectorised binary
+    searches.  Dict-like enough (`in`, `[]`, `keys()`, `len`) to be dropped in as ``dataset.id2index``."""
+
+    def __init__(self, ids):
+        import numpy as np
+        arr = np.asarray([i.encode() if isinstance(i, str) else i for i in ids], dtype=np.bytes_)
+        self._order = np.argsort(arr, kind="stable")
+        self._sorted = arr[self._order]
+        if len(arr) > 1 and bool((self._sorted[1:] == self._sorted[:-1]).any()):
+            # a dict keeps the LAST row of a duplicated id (dataset_processor.get_index_to_id)
+            keep = np.ones(len(arr), bool)
+            keep[:-1] = self._sorted[1:] != self._sorted[:-1]
+            self._sorted, self._order = self._sorted[keep], self._order[keep]
+        self._np = np
+
+    @classmethod
+    def from_ids(cls, ids):
+        return cls(ids)
+
+    def __len__(self):
+        return len(self._sorted)
+
+    def get_many(self, ids):
+        """-> (rows int64 [len(ids)], found bool [len(ids)]); rows of missing ids are -1."""
+        np = self._np
+        if len(ids) == 0 or len(self._sorted) == 0:
+            return np.full(len(ids), -1, np.int64), np.zeros(len(ids), bool)
+        q = np.asarray([i.encode() if isinstance(i, str) else i for i in ids], dtype=np.bytes_)
+        pos = np.searchsorted(self._sorted, q)
+        pos_c = np.minimum(pos, len(self._sorted) - 1)
+        found = self._sorted[pos_c] == q
+        rows = np.where(found, self._order[pos_c], -1).astype(np.int64)
+        return rows, found
+
+    def __contains__(self, id_):
+        return bool(self.get_many([id_])[1][0])
+
+    def __getitem__(self, id_):
+        rows, found = self.get_many([id_])
+        if not found[0]:
+            raise KeyError(id_)
+        return int(rows[0])
+
+    def keys(self):
+        return (k.decode() for k in self._sorted)
+
+
+def get_by_id(dataset, ids, field=None):
+    """Reference utils.py:37-45: rows (or a field of the rows) of the ids that exist, in the order given.
+    `dataset.id2index` may be the reference's dict or an IdIndex."""
+    if not isinstance(ids, list):
+        ids = [ids]
+    table = dataset.id2index
+    if isinstance(table, IdIndex):
+        rows, found = table.get_many(ids)
+        idxs = [int(r) for r in rows[found]]
+    else:
+        idxs = [table[id_] for id_ in ids if id_ in table]
+    if field is not None:
+        sel = dataset[idxs]
+        return sel[field] if field in sel else []
+    return idxs
+
+
+def prepare_dataset_from_ids(dataset, q_ids, d_ids, multi_doc=False, query_field="content", oracle_provenance=False):
+    """Reference utils.py:116-178: join the (query id, ranked doc ids) lists back to text — the dataset the rerank and
+    generation stages consume.  Same rows, same keys (including the reference's `ranking_labels` spelling in the
+    per-row dicts), same str-id assertions; returns a `datasets.Dataset`."""
+    import datasets
+    if q_ids is None and d_ids is None:
+        dataset_dict = {'query': dataset['query'][query_field], 'q_id': dataset['query']['id']}
+        if 'label' in dataset['query'].features:
+            dataset_dict['label'] = dataset['query']['label']
+        if 'ranking_label' in dataset['query'].features:
+            dataset_dict['ranking_label'] = dataset['query']['ranking_label']
+        return datasets.Dataset.from_dict(dataset_dict)
+    use_oracle = oracle_provenance and "doc" in dataset['query'].features
+    if not use_oracle:
+        assert isinstance(d_ids[0][0], str), f"{d_ids[0]}"
+        assert isinstance(next(iter(dataset['doc'].id2index.keys())), str), \
+            "Dataset id type is not string, real index retrieval will fail and retrieve nothing. Please convert to string in dataset_processor!"
+    labels = get_by_id(dataset['query'], q_ids, 'label')
+    ranking_labels = get_by_id(dataset['query'], q_ids, 'ranking_label')
+    queries = get_by_id(dataset['query'], q_ids, query_field)
+
+    def mygen():
+        for i, q_id in enumerate(q_ids):
+            if use_oracle:
+                docs = get_by_id(dataset['query'], q_id, 'doc')[0]
+                d_ids_ = get_by_id(dataset['query'], q_id, 'doc_id')[0]
+                doc_idxs = [None for _ in d_ids_]
+            else:
+                docs = get_by_id(dataset['doc'], d_ids[i], 'content')
+                d_ids_ = d_ids[i]
+                doc_idxs = get_by_id(dataset['doc'], d_ids[i])
+            if multi_doc:
+                x = {'doc': docs, 'query': queries[i], 'q_id': q_id, 'd_id': d_ids_, 'd_idx': doc_idxs}
+                if len(labels) > 0:
+                    x['label'] = labels[i]
+                if len(ranking_labels) > 0:
+                    x['ranking_labels'] = ranking_labels[i]
+                yield x
+            else:
+                for d_id, doc, d_idx in zip(d_ids_, docs, doc_idxs):
+                    x = {'d_id': d_id, 'd_idx': d_idx, 'doc': doc, 'query': queries[i], 'q_id': q_id}
+                    if len(labels) > 0:
+                        x['label'] = labels[i]
+                    if len(ranking_labels) > 0:
+                        x['ranking_labels'] = ranking_labels[i]
+                    yield x
+
+    return datasets.Dataset.from_generator(mygen)

@@ -109,3 +109,57 @@ def test_merge_indexes_matches_the_reference_script(tmp_path):
     ours = tmp_path / "ours"
     bergen_amd.utils.merge_indexes([str(idx / "wiki_en_doc_m"), str(idx / "wiki_fr_doc_m")], str(ours))
     assert sorted(os.listdir(ours)) == want
+
+
+# ---- doc-id mapping + context fetch -------------------------------------------------------------
+def _toy_rag_dataset(id_table):
+    import datasets
+    docs = datasets.Dataset.from_dict({"id": [f"d{i}" for i in range(50)], "content": [f"passage number {i}" for i in range(50)]})
+    queries = datasets.Dataset.from_dict({"id": [f"q{i}" for i in range(6)], "content": [f"question {i}?" for i in range(6)],
+                                         "label": [[f"answer {i}"] for i in range(6)],
+                                         "ranking_label": [[f"d{i}", f"d{i + 1}"] for i in range(6)]})
+    docs.id2index = id_table({f"d{i}": i for i in range(50)})
+    queries.id2index = id_table({f"q{i}": i for i in range(6)})
+    return {"doc": docs, "query": queries}
+
+
+def test_id_index_behaves_like_the_reference_dict():
+    from bergen_amd.utils import IdIndex
+    ids = [f"doc-{i * 7 % 1000}" for i in range(1000)] + ["doc-3"]  # shuffled, with one duplicate
+    ref = {}
+    for row, k in enumerate(ids):
+        ref[k] = row  # dict semantics: the last row wins
+    t = IdIndex(ids)
+    assert len(t) == len(ref)
+    ask = ["doc-0", "doc-3", "nope", "doc-999", "", "doc-3"]
+    rows, found = t.get_many(ask)
+    assert [int(r) if f else None for r, f in zip(rows, found)] == [ref.get(k) for k in ask]
+    assert "doc-5" in t and "missing" not in t and t["doc-5"] == ref["doc-5"]
+    with pytest.raises(KeyError):
+        t["missing"]
+    assert sorted(t.keys()) == sorted(ref.keys())
+
+
+@pytest.mark.parametrize("multi_doc", [False, True])
+def test_prepare_dataset_from_ids_matches_reference(multi_doc):
+    """Same rows as the reference's utils.prepare_dataset_from_ids / get_by_id on a toy RAG dataset, with the reference's
+    dict id2index and with the compact IdIndex (missing doc ids are silently dropped by both)."""
+    from oracle import ref_import
+    from bergen_amd import utils as U
+    q_ids = ["q2", "q0", "q5"]
+    d_ids = [["d3", "d10", "d49"], ["d0", "d7", "d8"], ["d1", "d2", "d44"]]
+    ours_dict = U.prepare_dataset_from_ids(_toy_rag_dataset(dict), q_ids, d_ids, multi_doc=multi_doc)
+    ours_tab = U.prepare_dataset_from_ids(_toy_rag_dataset(lambda d: U.IdIndex(list(d.keys()))), q_ids, d_ids, multi_doc=multi_doc)
+    assert ours_dict.to_dict() == ours_tab.to_dict()
+    assert len(ours_dict) == (3 if multi_doc else 9)
+    assert set(ours_dict.column_names) == {"doc", "query", "q_id", "d_id", "d_idx", "label", "ranking_labels"}
+    base = U.prepare_dataset_from_ids(_toy_rag_dataset(dict), None, None)
+    assert base["q_id"] == [f"q{i}" for i in range(6)] and "ranking_label" in base.column_names
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref = ref_import.load()
+    want = ref.utils.prepare_dataset_from_ids(_toy_rag_dataset(dict), q_ids, d_ids, multi_doc=multi_doc)
+    assert want.to_dict() == ours_dict.to_dict()
+    assert ref.utils.get_by_id(_toy_rag_dataset(dict)["doc"], ["d4", "zz", "d9"], "content") == \
+        U.get_by_id(_toy_rag_dataset(lambda d: U.IdIndex(list(d.keys())))["doc"], ["d4", "zz", "d9"], "content")
+    assert want.to_dict() == ref.utils.prepare_dataset_from_ids(_toy_rag_dataset(dict), q_ids, d_ids, multi_doc=multi_doc).to_dict()
