@@ -19,6 +19,7 @@ struct BhScanArgs {
     int ring_variant;        // bench-only LDS ring geometry selector for d=768 (0 = default 6 lines x 6)
     int qsplit;              // 1 | 2: workgroups sharing each row tile, each with its own BQ queries (see scan_topk.hip)
     unsigned* progress;      // [grid] qsplit = 2: tiles started per workgroup (zeroed by the host), pacing hint only
+    int dma_interleave;      // 1: LDS-DMA refills issued one per line between the MFMAs instead of all after the barrier
     int pair_window;         // qsplit = 2: a workgroup may run at most this many tiles ahead of its partner (0 = free-running)
 };
 

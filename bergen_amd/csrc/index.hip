@@ -52,6 +52,7 @@ struct Options {
     int ring_variant = 0;
     int query_split = 1;
     int pair_window = 0;
+    int dma_interleave = 1;
     int scan_kernel = 0;  // 0 = scan_topk.hip (4 waves), 1 = scan_topk8.hip (8 waves, split dimensions)
 } g_opt;
 
@@ -205,6 +206,9 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "query_split") {
         if (value != 1 && value != 2) return fail(BH_EINVAL, "query_split must be 1 or 2");
         g_opt.query_split = (int)value;
+    } else if (s == "dma_interleave") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "dma_interleave must be 0 or 1");
+        g_opt.dma_interleave = (int)value;
     } else if (s == "scan_kernel") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves) or 1 (8 waves)");
         g_opt.scan_kernel = (int)value;
@@ -399,6 +403,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.ablate = g_opt.ablate;
         sa.ring_variant = g_opt.ring_variant;
         sa.qsplit = qs;
+        sa.dma_interleave = g_opt.dma_interleave;
         sa.pair_window = g_opt.pair_window;
         sa.progress = ix->gthr.p + (size_t)bq * qs_max * 64;  // [grid] words behind the slot table
         if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));

@@ -71,7 +71,7 @@ __device__ __forceinline__ void sort_candidates(u64 (&e)[2 * KP / 64], const u64
 // NT = non-temporal cache policy on the corpus stream.
 // ABL (ablation, bench-only, 0 in production): 1 = no threshold epilogue, 2 = stream only (no LDS
 // reads, no MFMA), 3 = LDS reads without MFMA, 4 = MFMA without LDS reads.
-template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0>
+template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0, bool IL = true>
 __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NK * 16;
@@ -174,18 +174,24 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
         long long it = 0;
         int ip = 0;
         int islot = 0;
-        auto issue_stage = [&]() {
+        // one LDS-DMA instruction: line j of the stage at the issue cursor
+        auto issue_line = [&](int j) {
             const long long itc = it < my_tiles ? it : my_tiles - 1;  // past the end: harmless re-fetch,
             const long long tile = b + itc * G;                       // keeps the vmcnt arithmetic uniform
             const unsigned char* src = corpus + (size_t)tile * 32 * ROW_BYTES + (size_t)ip * LS * 128 + ld_off;
             unsigned char* dst = smem + islot * STAGE_BYTES + wave * 1024;
-#pragma unroll
-            for (int j = 0; j < LS; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 128),
-                                                 (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0,
-                                                 NT ? 2 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 128),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0,
+                                             NT ? 2 : 0);
+        };
+        auto advance_cursor = [&]() {
             if (++ip == S) { ip = 0; ++it; }
             if (++islot == R) islot = 0;
+        };
+        auto issue_stage = [&]() {
+#pragma unroll
+            for (int j = 0; j < LS; ++j) issue_line(j);
+            advance_cursor();
         };
 #pragma unroll
         for (int p = 0; p < R - 1; ++p) issue_stage();
@@ -226,7 +232,10 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                 // rendezvous: everybody's pieces landed AND everybody is done reading the slot
                 // that the next issue overwrites.
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * LS) : "memory");
-                issue_stage();
+                // The refill of the slot everybody just left: either all LS instructions here (the matrix pipe is idle
+                // while they issue, ~100 cycles each under load), or one after every line's MFMAs (dma_interleave).
+                constexpr bool spread = ABL == 0 && IL;
+                if (!spread) issue_stage();
                 const unsigned char* st = smem + cslot * STAGE_BYTES;
                 // fragment reads run one 128-byte line (4 k-steps) ahead of the MFMAs
                 half8 af[2][4];
@@ -272,13 +281,20 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                             for (int f = 0; f < 4 * GL; ++f) asm volatile("" ::"v"(ag[g & 1][f]));
                         } else {
 #pragma unroll
-                            for (int f = 0; f < 4 * GL; ++f)
+                            for (int f = 0; f < 4 * GL; ++f) {
 #pragma unroll
                                 for (int w2 = 0; w2 < QW; ++w2)
                                     acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                         ag[g & 1][f], qf[w2][(part * LS + g * GL) * 4 + f], acc[w2], 0, 0, 0);
+                                if ((f & 3) == 3) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (spread) issue_line(g * GL + (f >> 2));
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
                         }
                     }
+                    if (spread) advance_cursor();
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (++cslot == R) cslot = 0;
@@ -393,11 +409,11 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 
-template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0>
+template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0, bool IL = true>
 static hipError_t launch_one(const BhScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t smem = (size_t)R * 32 * LS * 128;
     static bool attr_done = false;
-    auto kern = bh_scan_topk_kernel<NK, KP, LS, R, QW, NT, ABL>;
+    auto kern = bh_scan_topk_kernel<NK, KP, LS, R, QW, NT, ABL, IL>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -420,6 +436,12 @@ static hipError_t launch_kp(const BhScanArgs& a, int kp, int grid, hipStream_t s
                 case 4: return launch_one<NK, 64, LS, R, QW, true, 4>(a, grid, stream);
             }
         }
+    }
+    if constexpr (NK == 48 && QW == 1 && LS == 6 && R == 6) {
+        // (bench option "dma_interleave" 0: the refill issued in one block after the barrier, d = 768 / top-50 only)
+        if (a.dma_interleave == 0 && kp == 64)
+            return nt ? launch_one<NK, 64, LS, R, QW, true, 0, false>(a, grid, stream)
+                      : launch_one<NK, 64, LS, R, QW, false, 0, false>(a, grid, stream);
     }
     switch (kp) {
         case 64:

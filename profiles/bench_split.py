@@ -28,11 +28,11 @@ def main():
     base = None
     ablate = int(os.environ.get("ABLATE", "0"))  # 2 = stream only, 3 = + LDS reads, 4 = MFMA only (timings only)
     _lib.set_option("ablate", ablate)
-    configs = [(kern, split, 0, nt) for kern in (0, 1) for split in (1, 2) for nt in (1, 0)]
-    for kern, split, window, nt in configs:
+    configs = [(0, split, il, nt) for il in (0, 1) for split in (1, 2) for nt in (1, 0)]
+    for kern, split, window, nt in configs:  # (window slot reused: dma_interleave)
         _lib.set_option("scan_kernel", kern)
+        _lib.set_option("dma_interleave", window)
         _lib.set_option("query_split", split)
-        _lib.set_option("pair_window", window)
         _lib.set_option("nontemporal", nt)
         s, i = ix.search(q, k)
         torch.cuda.synchronize()
@@ -45,11 +45,12 @@ def main():
         if base is None:
             base = (s.clone(), i.clone())
         same = bool(torch.equal(s, base[0]) and torch.equal(i, base[1]))
-        res.append({"scan_kernel": kern, "query_split": split, "pair_window": window, "nt": nt, "qps": nq / dt, "passes": c["n_passes"],
+        res.append({"scan_kernel": kern, "query_split": split, "dma_interleave": window, "nt": nt, "qps": nq / dt, "passes": c["n_passes"],
                     "scan_ms_per_pass": c["scan_ms"] / c["n_passes"], "same_results_as_unsplit": same, "ablate": ablate})
         print(res[-1], file=sys.stderr, flush=True)
     _lib.set_option("ablate", 0)
     _lib.set_option("scan_kernel", 0)
+    _lib.set_option("dma_interleave", 0)
     _lib.set_option("query_split", 1)
     _lib.set_option("nontemporal", 1)
     print(json.dumps(res, indent=1))
