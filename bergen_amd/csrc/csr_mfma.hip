@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             rel = 0u;
         }
     };
-    // one super-chunk = SC chunks of 64 entries; all SC loads are issued back to back (6 KiB in flight per wave)
+    // one super-chunk = SC chunks of 64 entries (6 KiB in flight per wave); the very first one is loaded in a block
     constexpr int SC = 24;
     auto issue_sc = [&](unsigned (&buf)[SC], const unsigned* eb, unsigned total, unsigned sc) {
 #pragma unroll
@@ -188,43 +188,49 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             }
         }
     };
-    // scatter one super-chunk of the current group into the D / S tiles.  CODE SIZE matters here: fully unrolled over
-    // the SC register-resident chunks (with the drain inlined per chunk) this kernel was 95 KiB of instructions, more
-    // than the 64 KiB instruction cache two CUs share, and every group streamed most of it.  The chunks are therefore
-    // processed four at a time in a ROLLED loop; the register array is shifted down by four after each step (60 v_mov
-    // per 1536 entries) so that the body always addresses buf[0..3].
-    auto process_sc = [&](unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc) {
-#pragma unroll 1
+    // scatter one super-chunk of the current group into the D / S tiles and refill the buffer with the NEXT super-chunk
+    // (of this group, or the first one of the wave's next group).  ONE register buffer: the four registers of a step
+    // are re-loaded as soon as their entries have been tested, so SC loads stay in flight and their issue (each one
+    // blocks the wave for ~100 cycles while the memory pipeline is saturated) is spread between the steps instead of
+    // coming in blocks of 24.  CODE SIZE matters here: with the hit resolution inlined per CHUNK (and two buffers) this
+    // kernel was 95 KiB of instructions, more than the 64 KiB instruction cache two CUs share; it is inlined per step.
+    auto process_and_refill = [&](unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc, const unsigned* nb,
+                                  unsigned ntot, unsigned nsc_i) {
+#pragma unroll
         for (int step = 0; step < SC / 4; ++step) {
             const unsigned cbase = (sc * SC + step * 4) * 64;
-            if (cbase >= total) break;  // wave-uniform
-            if (a.ablate & 1) {         // bench-only: stream the entries, no scatter
-                asm volatile("" ::"v"(buf[0]), "v"(buf[1]), "v"(buf[2]), "v"(buf[3]));
-            } else {
+            if (cbase < total) {        // wave-uniform
+                if (a.ablate & 1) {     // bench-only: stream the entries, no scatter
+                    asm volatile("" ::"v"(buf[step * 4]), "v"(buf[step * 4 + 1]), "v"(buf[step * 4 + 2]), "v"(buf[step * 4 + 3]));
+                } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned p = cbase + c * 64 + lane;
-                    const unsigned ent = buf[c];
-                    const unsigned term = ent & 0xffffu;
-                    const unsigned word = bitmap[term >> 5];
-                    const bool hit = p < total && (word & (1u << (term & 31)));
-                    // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them here
-                    // would run the document search and the divergent slot lookup / pair walk once per chunk.  They
-                    // are queued instead (position in the group + entry, compacted by the ballot's prefix count) and
-                    // resolved 64 at a time by drain().
-                    const u64 hm = __builtin_amdgcn_ballot_w64(hit);
-                    if (hm != 0ull && !(a.ablate & 4)) {  // (4, bench-only: term-set lookup only)
-                        if (hit) {
-                            const unsigned pos = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
-                            Qt[pos & (BH_CSR_MFMA_QUEUE - 1)] = make_uint2(p, ent);
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned p = cbase + c * 64 + lane;
+                        const unsigned ent = buf[step * 4 + c];
+                        const unsigned term = ent & 0xffffu;
+                        const unsigned word = bitmap[term >> 5];
+                        const bool hit = p < total && (word & (1u << (term & 31)));
+                        // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them
+                        // here would run the document search and the divergent slot lookup / pair walk once per chunk.
+                        // They are queued instead (position in the group + entry, compacted by the ballot's prefix
+                        // count) and resolved 64 at a time by drain().
+                        const u64 hm = __builtin_amdgcn_ballot_w64(hit);
+                        if (hm != 0ull && !(a.ablate & 4)) {  // (4, bench-only: term-set lookup only)
+                            if (hit) {
+                                const unsigned pos = q_tail + __builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));
+                                Qt[pos & (BH_CSR_MFMA_QUEUE - 1)] = make_uint2(p, ent);
+                            }
+                            q_tail += (unsigned)__builtin_popcountll(hm);
                         }
-                        q_tail += (unsigned)__builtin_popcountll(hm);
                     }
+                    while (q_tail - q_head >= 64u) drain(64u, rel);
                 }
-                while (q_tail - q_head >= 64u) drain(64u, rel);
             }
 #pragma unroll
-            for (int j = 0; j + 4 < SC; ++j) buf[j] = buf[j + 4];
+            for (int c = 0; c < 4; ++c) {
+                const unsigned idx = (nsc_i * SC + step * 4 + c) * 64 + lane;
+                buf[step * 4 + c] = idx < ntot ? nb[idx] : 0u;
+            }
         }
     };
 
@@ -250,8 +256,8 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     long long base, nbase;
     unsigned rel, nrel;
     load_group(grp_lo, base, rel);
-    unsigned bufA[SC], bufB[SC];
-    issue_sc(bufA, a.entries + base, __builtin_amdgcn_readlane(rel, 32), 0u);
+    unsigned buf[SC];
+    issue_sc(buf, a.entries + base, __builtin_amdgcn_readlane(rel, 32), 0u);
     for (long long grp = grp_lo; grp < grp_hi; ++grp, ++n_groups_seen) {
         // ---- threshold exchange (filter hint only).  A wave sees only a few thousand documents, far too few for its own
         // KP-th best to become selective, so bounds are shared chip-wide through the dense scan's slot table
@@ -294,9 +300,8 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         }
         const long long g0 = grp * 32;
         const unsigned total = __builtin_amdgcn_readlane(rel, 32);
-        const unsigned nsc = (total + SC * 64 - 1) / (SC * 64);
-        const unsigned nsc_eff = nsc < 2 ? 2u : ((nsc + 1) & ~1u);  // processed in pairs: A -> B -> A
-        load_group(grp + 1, nbase, nrel);  // (used by the last prefetch of this group)
+        const unsigned nsc = total == 0 ? 1u : (total + SC * 64 - 1) / (SC * 64);
+        load_group(grp + 1, nbase, nrel);  // (used by the last refill of this group)
         // ---- clear the tiles
         {
             const uint4 z = {0u, 0u, 0u, 0u};
@@ -304,16 +309,11 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             for (int i = 0; i < 12; ++i) *reinterpret_cast<uint4*>(Dt + i * 1024 + lane * 16) = z;
         }
         const unsigned* ent_base = a.entries + base;
-        // ---- scatter phase, software-pipelined over super-chunks: while one buffer is scattered the next
-        // super-chunk (of this group, or the first one of the wave's next group) is in flight
-        for (unsigned sc = 0; sc < nsc_eff; sc += 2) {
-            issue_sc(bufB, ent_base, total, sc + 1);  // (all-invalid past the group's end: no memory traffic)
-            process_sc(bufA, rel, total, sc);
-            if (sc + 2 < nsc_eff)
-                issue_sc(bufA, ent_base, total, sc + 2);
-            else
-                issue_sc(bufA, a.entries + nbase, __builtin_amdgcn_readlane(nrel, 32), 0u);
-            process_sc(bufB, rel, total, sc + 1);
+        // ---- scatter phase: every super-chunk is scattered while the next one is being loaded into the same registers
+        for (unsigned sc = 0; sc < nsc; ++sc) {
+            const bool last = sc + 1 == nsc;
+            process_and_refill(buf, rel, total, sc, last ? a.entries + nbase : ent_base,
+                               last ? __builtin_amdgcn_readlane(nrel, 32) : total, last ? 0u : sc + 1);
         }
         if (q_tail != q_head) drain(q_tail - q_head, rel);  // (< 64 left)
         // ---- scores = S + D . WhT^T
