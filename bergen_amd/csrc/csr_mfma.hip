@@ -9,7 +9,7 @@
 //     weights (MFMA operand B, loaded once into registers); every other term of the tile is a "tail" term with a
 //     short list of (query, weight) pairs.
 //   * a wave (8 per workgroup) owns a contiguous range of 32-document groups, i.e. one contiguous stream of entries,
-//     read in super-chunks of 24 x 64 entries (24 loads in flight per wave, double-buffered across groups);
+//     read in super-chunks of 32 x 64 entries (32 loads in flight per wave, one rotating register buffer);
 //     every entry (lane = entry) is looked up in the tile's term set (bitmap + rank in LDS, then one info word
 //     per slot), its document found from the group's row pointers (one ballot for the chunk + a walk over the few
 //     document boundaries inside it);
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         }
     };
     // one super-chunk = SC chunks of 64 entries (6 KiB in flight per wave); the very first one is loaded in a block
-    constexpr int SC = 24;
+    constexpr int SC = 32;
     auto issue_sc = [&](unsigned (&buf)[SC], const unsigned* eb, unsigned total, unsigned sc) {
 #pragma unroll
         for (int c = 0; c < SC; ++c) {
