@@ -179,6 +179,7 @@ struct BhCsrMergeArgs {
     long long id_offset;
     float* out_scores;    // already offset to the tile's first query
     long long* out_ids;
+    int floor_zero;                // fill lists shorter than k with the lowest absent rows at score 0 (non-negative data)
 };
 hipError_t bh_launch_csr_merge_rescore(const BhCsrMergeArgs& a, int kp, int nq_tile, hipStream_t stream);
 
@@ -198,7 +199,9 @@ struct BhCsrMfmaArgs {
     bh_u64* cand;                  // [grid * 8][64][2 * KP]
     bh_u64* partial;               // [grid][64][KP]
     unsigned* gthr;                // [64 queries][64 slots] threshold slot table (ordf), initialised to BH_ORD_NEG_INF
+    int floor_zero;                // non-negative data: candidates need score > 0 (zero-score rows are filled in by the merge)
     int skip_final;                // pre-pass launch: fill the slot table only, leave no candidate lists
+    int stats_mode;                // BH_SPARSE_STATS: 1 = count events (global atomics: distorts timing), 2 = phase timers of sampled waves
     unsigned* stats;               // optional diagnostics (BH_SPARSE_STATS): [0] groups with hits [1] appended [2] compactions [3] polls
     int ablate;                    // bench-only: 1 = no scatter, 2 = no candidate handling (results invalid)
 };

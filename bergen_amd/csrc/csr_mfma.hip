@@ -49,12 +49,13 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     const int ql = lane & 31, h = lane >> 5;
     const long long gw = (long long)blockIdx.x * NWV + wave, TW = (long long)gridDim.x * NWV;
 
-    // ---- LDS: bitmap | prefix | sinfo | pairs | thr[64] | WhT (64 x 144 B) | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (4 KiB)
+    // ---- LDS: bitmap | prefix | sinfo | pairs | published[64] bound[64] | WhT (64 x 144 B) | per wave: D (4 KiB fp16 tile) + S (8 KiB fp32 tile) + hit queue (4 KiB)
     unsigned* bitmap = reinterpret_cast<unsigned*>(smem);
     unsigned short* prefix = reinterpret_cast<unsigned short*>(smem + a.off_prefix);
     unsigned* sinfo = reinterpret_cast<unsigned*>(smem + a.off_sinfo);
     unsigned* pairs = reinterpret_cast<unsigned*>(smem + a.off_pairs);
-    unsigned* thr_lds = reinterpret_cast<unsigned*>(smem + a.off_thr);
+    unsigned* thr_lds = reinterpret_cast<unsigned*>(smem + a.off_thr);  // [64] best score the workgroup has published
+    unsigned* bound_lds = thr_lds + 64;                                 // [64] chip-wide bound the workgroup has seen
     unsigned char* Dt = smem + a.off_tiles + wave * BH_CSR_MFMA_WAVE_LDS;
     float* St = reinterpret_cast<float*>(Dt + 4096);
     uint2* Qt = reinterpret_cast<uint2*>(Dt + 12288);  // ring of BH_CSR_MFMA_QUEUE pending hits: (position in the group, entry)
@@ -64,13 +65,13 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     }
     for (int i = tid; i < a.n_slots; i += 512) sinfo[i] = a.sinfo[i];
     for (int i = tid; i < a.n_pairs; i += 512) pairs[i] = a.pairs[i];
-    if (tid < 64) thr_lds[tid] = BH_ORD_NEG_INF;
+    if (tid < 128) thr_lds[tid] = BH_ORD_NEG_INF;
     __syncthreads();
 
     // ---- head-term weights WhT[query][head] (MFMA operand B) live in LDS, rows padded to 144 bytes so that the
     // per-group fragment reads (lane = query) are conflict-free; keeping the 8 fragments in registers for the whole
     // launch cost 32 VGPRs the kernel does not have
-    unsigned char* whl = smem + a.off_thr + 256;
+    unsigned char* whl = smem + a.off_thr + 512;
     {
         const int row = tid >> 3, ch = tid & 7;  // 64 rows x 8 chunks of 16 bytes
         *reinterpret_cast<uint4*>(whl + row * 144 + ch * 16) = *reinterpret_cast<const uint4*>(a.WhT + (size_t)row * 64 + ch * 8);
@@ -90,9 +91,10 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     float best[2][RB];  // this half-lane's RB best appended scores, descending
     float pub[2];
     long long next_poll = 0;
+    int n_polls = 0;
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2) {
-        thr[w2] = -__builtin_inff();
+        thr[w2] = a.floor_zero ? 0.f : -__builtin_inff();  // candidate iff score > thr
         cnt[w2] = 0;
         pub[w2] = -__builtin_inff();
 #pragma unroll
@@ -148,11 +150,16 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             buf[c] = idx < total ? eb[idx] : 0u;
         }
     };
+    // diagnostics (BH_SPARSE_STATS): cycle counts of the phases of a few sampled waves (s_memtime; perturbs little)
+    const bool timed = a.stats_mode == 2 && (gw & 255) == 0;
+    long long t_kernel = timed ? (long long)__builtin_amdgcn_s_memtime() : 0, t_hit = 0, t_poll = 0, t_drain = 0, t_mfma = 0, t_need = 0;
+    unsigned n_entries = 0, n_appends = 0, n_app_early = 0, n_app_mid = 0;
     // pending hits of the current group (wave-uniform ring indices)
     unsigned q_head = 0, q_tail = 0;
     // resolve n <= 64 queued hits, lane = hit: a head term is ONE fp16 store into the dense tile D, a tail term walks its
     // short (query, weight) pair list (all lanes busy: the walk costs the longest list among 64 hits, once)
     auto drain = [&](unsigned n, unsigned rel) {
+        const long long td0 = timed ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const uint2 it = Qt[(q_head + lane) & (BH_CSR_MFMA_QUEUE - 1)];
         q_head += n;
         const unsigned p = it.x, ent = it.y;
@@ -187,6 +194,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                 }
             }
         }
+        if (timed) t_drain += (long long)__builtin_amdgcn_s_memtime() - td0;
     };
     // scatter one super-chunk of the current group into the D / S tiles and refill the buffer with the NEXT super-chunk
     // (of this group, or the first one of the wave's next group).  ONE register buffer: the four registers of a step
@@ -266,36 +274,53 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         // bound of the final KP-th best.  Geometric schedule of the group ordinal (0, 1, 2, 4, 7, 11, ...), BEFORE the group is
         // scanned: the very first poll picks up the bounds left by the pre-pass launch (sparse.hip), so that no wave starts
         // with an open threshold (an open start appends 32 x 64 candidates per group and wave: 8 M per pass).
-        if (!(a.ablate & (2 | 32)) && n_groups_seen >= next_poll) {  // (32, bench-only: no exchange)
-            next_poll = n_groups_seen + 1 + (n_groups_seen >> 1);
-            if (a.stats && lane == 0) atomicAdd(a.stats + 3, 1u);
-            publish();
+        if (!(a.ablate & (2 | 32))) {  // (32, bench-only: no exchange)
+            if (n_groups_seen >= next_poll) {
+                const long long tp0 = timed ? (long long)__builtin_amdgcn_s_memtime() : 0;
+                next_poll = n_groups_seen + 1 + (n_groups_seen >> 1);
+                if (a.stats_mode == 1 && lane == 0) atomicAdd(a.stats + 3, 1u);
+                publish();
+                // The table is read on behalf of the WORKGROUP: the waves take turns (poll ordinal mod 8), the reader
+                // leaves the minima in LDS.  Every wave reading all 16 KiB itself, with agent-scope loads that bypass
+                // the non-coherent L2, cost 0.25 ms per pass and stalled the entry stream behind them.
+                if ((n_polls & 7) == wave) {
 #pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                // 16 lanes x 4 slots cover one query, 4 queries per 16-byte load instruction; two batches of four loads
-                // (eight in flight cost 16 more registers than the kernel has)
+                    for (int w2 = 0; w2 < 2; ++w2) {
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    uint4 sl[4];
+                        for (int hb = 0; hb < 2; ++hb) {
+                            uint4 sl[4];
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        const int q = w2 * 32 + (hb * 4 + i4) * 4 + (lane >> 4);
-                        // (nt: served by L2, not by this CU's L1; a stale value would only mean less filtering)
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.gthr + (size_t)q * 64 + (lane & 15) * 4));
-                        sl[i4] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                    }
+                            for (int i4 = 0; i4 < 4; ++i4) {
+                                const int q = w2 * 32 + (hb * 4 + i4) * 4 + (lane >> 4);
+                                // agent-scope loads (sc1): the table is written by atomics from all eight XCDs, whose L2s are
+                                // not coherent with each other — a plain or nt load can be served a stale line by this XCD's
+                                // L2 forever, which silently disables the filter
+                                const unsigned* src = a.gthr + (size_t)q * 64 + (lane & 15) * 4;
+                                sl[i4].x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                sl[i4].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                sl[i4].z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                sl[i4].w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        const int it = hb * 4 + i4;
-                        unsigned mn = min(min(sl[i4].x, sl[i4].y), min(sl[i4].z, sl[i4].w));
+                            for (int i4 = 0; i4 < 4; ++i4) {
+                                unsigned mn = min(min(sl[i4].x, sl[i4].y), min(sl[i4].z, sl[i4].w));
 #pragma unroll
-                        for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
-                        const unsigned got = (unsigned)__shfl((int)mn, (ql & 3) * 16, 64);
-                        // a document that TIES the bound may still win on row index: inclusive compare
-                        if ((ql >> 2) == it && got > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(got - 1u));
+                                for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
+                                // lanes 16 g .. 16 g + 15 hold the minimum of query (hb * 4 + i4) * 4 + g of this block
+                                if ((lane & 15) == 0 && mn > BH_ORD_NEG_INF)
+                                    atomicMax(&bound_lds[w2 * 32 + (hb * 4 + i4) * 4 + (lane >> 4)], mn);
+                            }
+                        }
                     }
                 }
+                ++n_polls;
+                if (timed) t_poll += (long long)__builtin_amdgcn_s_memtime() - tp0;
+            }
+            // every group: the bound the workgroup knows (a document that TIES it may still win on row index: inclusive)
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                const unsigned bnd = bound_lds[w2 * 32 + ql];
+                if (bnd > BH_ORD_NEG_INF) thr[w2] = fmaxf(thr[w2], bh_unordf(bnd - 1u));
             }
         }
         const long long g0 = grp * 32;
@@ -316,6 +341,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                                last ? __builtin_amdgcn_readlane(nrel, 32) : total, last ? 0u : sc + 1);
         }
         if (q_tail != q_head) drain(q_tail - q_head, rel);  // (< 64 left)
+        const long long tm0 = timed ? (long long)__builtin_amdgcn_s_memtime() : 0;
         // ---- scores = S + D . WhT^T
         floatx16 acc[2];
 #pragma unroll
@@ -346,8 +372,9 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
 #pragma unroll
             for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[w2][v]);
             if (__builtin_amdgcn_ballot_w64(m > thr[w2]) != 0ull && !(a.ablate & 64)) {  // (64, bench-only: filter, never append)
+                const long long th0 = timed ? (long long)__builtin_amdgcn_s_memtime() : 0;
                 u64 need = __builtin_amdgcn_ballot_w64(cnt[w2] > (unsigned)(CAP - 32)) & 0xffffffffull;
-                if (a.stats && lane == 0) {
+                if (a.stats_mode == 1 && lane == 0) {
                     atomicAdd(a.stats + 0, 1u);
                     atomicAdd(a.stats + 2, (unsigned)__builtin_popcountll(need));
                 }
@@ -355,6 +382,10 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                     const int qq = __builtin_ctzll(need);
                     need &= need - 1;
                     compact(w2, qq);
+                }
+                if (timed) {
+                    t_need += (long long)__builtin_amdgcn_s_memtime() - th0;
+                    ++n_entries;
                 }
                 u64* buf = cand_w + (size_t)(w2 * 32 + ql) * CAP;
                 // rolled (the score registers are shifted down once per step): this path is entered a few dozen times per
@@ -371,7 +402,13 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                     if (hm != 0ull) {
                         const unsigned hl = ((unsigned)hm >> ql) & 1u;
                         const unsigned hh = ((unsigned)(hm >> 32) >> ql) & 1u;
-                        if (a.stats && lane == 0) atomicAdd(a.stats + 1, (unsigned)__builtin_popcountll(hm));
+                        if (a.stats_mode == 1 && lane == 0) atomicAdd(a.stats + 1, (unsigned)__builtin_popcountll(hm));
+                        if (timed) {
+                            const unsigned na = (unsigned)__builtin_popcountll(hm);
+                            n_appends += na;
+                            if (n_groups_seen < 4) n_app_early += na;
+                            else if (n_groups_seen < 16) n_app_mid += na;
+                        }
                         if (hit) {
                             if (!(a.ablate & 256)) buf[cnt[w2] + (h ? hl : 0u)] = bh_make_key(sv, (unsigned)row);
                             float x = sv;
@@ -385,13 +422,16 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                         if (!(a.ablate & 512)) cnt[w2] += hl + hh;  // (512, bench-only: lists stay empty)
                     }
                 }
+                if (timed) t_hit += (long long)__builtin_amdgcn_s_memtime() - th0;
             }
         }
+        if (timed) t_mfma += (long long)__builtin_amdgcn_s_memtime() - tm0;
         base = nbase;
         rel = nrel;
     }
 
     if (!(a.ablate & (2 | 32))) publish();  // what the wave learnt in its last groups (the pre-pass relies on this)
+    const long long t_loop_end = timed ? (long long)__builtin_amdgcn_s_memtime() : 0;
 
     // ---- final: the workgroup folds its 8 waves' candidate buffers per query.  With working thresholds a buffer holds
     // a handful of keys, so the usual case is ONE sort of the concatenated buffers (<= CAP keys); only a query whose
@@ -450,6 +490,23 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
 #pragma unroll
             for (int r = 0; r < EPLK; ++r) out[r * 64 + lane] = best[r];
         }
+    }
+    if (timed && lane == 0 && !a.skip_final) {
+        const long long t_end = (long long)__builtin_amdgcn_s_memtime();
+        unsigned* o = a.stats + 8 + (gw >> 8) * 8;
+        o[0] = (unsigned)((t_end - t_kernel));
+        o[1] = (unsigned)((t_loop_end - t_kernel));
+        o[2] = (unsigned)(t_mfma);
+        o[3] = (unsigned)(t_hit);
+        o[4] = (unsigned)(t_poll);
+        o[5] = (unsigned)(t_drain);
+        o[6] = n_entries;
+        o[7] = n_appends;
+        o[1] = (unsigned)(t_need);
+        o[4] = n_app_early;
+        o[5] = n_app_mid;
+        o[2] = __float_as_uint(__shfl(thr[0], 0, 64));
+        o[3] = __float_as_uint(__shfl(thr[0], 5, 64));
     }
 }
 

@@ -284,6 +284,9 @@ __global__ void __launch_bounds__(256) bh_csr_merge_rescore_kernel(BhCsrMergeArg
 #pragma unroll
         for (int r = 0; r < EPL; ++r) e[r] = lds_keys[KP + r * 64 + lane];
         bh_wave_sort_desc<EPL>(e, lane);
+        unsigned n_valid = 0;
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) n_valid += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e[r] != 0ull));
 #pragma unroll
         for (int r = 0; r < EPL; ++r) {
             const int i = r * 64 + lane;
@@ -291,6 +294,28 @@ __global__ void __launch_bounds__(256) bh_csr_merge_rescore_kernel(BhCsrMergeArg
                 const bool valid = e[r] != 0ull;
                 a.out_scores[(size_t)q * a.k + i] = valid ? bh_key_score(e[r]) : -__builtin_inff();
                 a.out_ids[(size_t)q * a.k + i] = valid ? a.id_offset + (long long)bh_key_row(e[r]) : -1ll;
+            }
+        }
+        // Non-negative data (floor_zero): the scan collected positive-score documents only.  A list shorter than k then
+        // holds EVERY positive document of the corpus, and the canonical order continues with the zero-score documents
+        // by ascending row: the lowest rows that are not in the list.  At most n_valid of the rows [0, k) are in it, so
+        // the k - n_valid fill rows are all found below k.
+        if (a.floor_zero && n_valid < (unsigned)a.k) {
+#pragma unroll
+            for (int r = 0; r < EPL; ++r) lds_keys[r * 64 + lane] = e[r];  // (same wave wrote and reads: no barrier needed)
+            unsigned filled = n_valid;
+            for (int rb = 0; rb < a.k && filled < (unsigned)a.k; rb += 64) {
+                const long long row = rb + lane;
+                bool absent = row < a.k && row < a.n_rows;
+                for (unsigned c = 0; c < n_valid && absent; ++c)
+                    if ((long long)bh_key_row(lds_keys[c]) == row) absent = false;
+                const u64 am = __builtin_amdgcn_ballot_w64(absent);
+                const unsigned pos = filled + __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                if (absent && pos < (unsigned)a.k) {
+                    a.out_scores[(size_t)q * a.k + pos] = 0.f;
+                    a.out_ids[(size_t)q * a.k + pos] = a.id_offset + row;
+                }
+                filled += (unsigned)__builtin_popcountll(am);
             }
         }
     }

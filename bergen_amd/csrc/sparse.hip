@@ -34,6 +34,7 @@ struct bh_sparse_index {
     BhDevBuf<long long> row_ptr;
     BhDevBuf<bh_u64> cand, partial;
     BhDevBuf<unsigned> gthr, bitmap;
+    bool nonneg_docs = true;  // no stored document weight is negative (SPLADE vectors are log(1 + relu(.)) >= 0)
     BhDevBuf<unsigned short> prefix;
     BhDevBuf<_Float16> W, qdense, WhT;
     BhDevBuf<unsigned> sinfo, pairs;
@@ -185,6 +186,7 @@ int bh_sparse_upload_csr(bh_sparse_index* ix, int64_t row0, int64_t n, const int
             if (t < 0 || t >= ix->vocab) return bh_fail(BH_EINVAL, "term id %d out of range at row %lld", t, (long long)(row0 + r));
             const unsigned short hb = val_dtype == BH_F16 ? v16[i] : f32_to_f16_bits(v32[i]);
             if ((hb & 0x7fffu) == 0) continue;  // +-0
+            if (hb & 0x8000u) ix->nonneg_docs = false;
             packed.push_back((unsigned)t | ((unsigned)hb << 16));
         }
         std::sort(packed.begin() + start, packed.end(), [](unsigned x, unsigned y) { return (x & 0xffffu) < (y & 0xffffu); });
@@ -241,7 +243,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const int grid = ix->n_cu;
     int rc;
     if ((rc = ix->partial.ensure((size_t)grid * 64 * kp))) return rc;
-    if ((rc = ix->gthr.ensure(64 * 64 + 8))) return rc;  // [64 queries][64 slots] (csr_mfma.hip); csr_topk.hip uses the first 64 words
+    if ((rc = ix->gthr.ensure(64 * 64 + 8 + 64))) return rc;  // [64 queries][64 slots] (csr_mfma.hip); csr_topk.hip uses the first 64 words
     if ((rc = ix->bitmap.ensure((size_t)n_words))) return rc;
     if ((rc = ix->prefix.ensure((size_t)n_words))) return rc;
     if ((rc = ix->W.ensure((size_t)(max_slots + 1) * 64))) return rc;
@@ -269,7 +271,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const int waves_per_wg = mfma ? 8 : 16;
     if ((rc = ix->cand.ensure((size_t)grid * waves_per_wg * 64 * 2 * kp))) return rc;
     // LDS budget of the MFMA kernel: tables + 8 waves x (4 KiB D tile + 8 KiB S tile)
-    const int mfma_fixed = n_words * 6 + 16 + 256 + 64 * 144 + 32 + 8 * BH_CSR_MFMA_WAVE_LDS;
+    const int mfma_fixed = n_words * 6 + 16 + 512 + 64 * 144 + 32 + 8 * BH_CSR_MFMA_WAVE_LDS;
     const int mfma_table_bytes = kLdsBytes - mfma_fixed;  // for sinfo (4 B per slot) + pairs (4 B per pair)
     if (mfma && mfma_table_bytes < 4096) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile tables", V);
 
@@ -328,6 +330,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         BH_HIP_TRY(hipMemcpyAsync(ix->qdense.p, qd.data(), (size_t)nt * V * 2, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->gthr.p, gt.data(), 64 * 64 * 4, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+        bool floor_zero = false;
         if (!mfma) {
             std::fill(Wh.begin(), Wh.begin() + (size_t)(n_slots + 1) * 64, (unsigned short)0);
             for (int j = 0; j < nt; ++j)
@@ -412,14 +415,28 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             ma2.off_sinfo = (ma2.off_prefix + n_words * 2 + 15) / 16 * 16;
             ma2.off_pairs = ma2.off_sinfo + n_slots * 4;
             ma2.off_thr = (ma2.off_pairs + n_pairs * 4 + 15) / 16 * 16;
-            ma2.off_tiles = (ma2.off_thr + 256 + 64 * 144 + 15) / 16 * 16;  // thr[64] | WhT image | per-wave tiles
+            ma2.off_tiles = (ma2.off_thr + 512 + 64 * 144 + 15) / 16 * 16;  // published[64] bound[64] | WhT image | per-wave tiles
             ma2.cand = ix->cand.p;
             ma2.partial = ix->partial.p;
             ma2.gthr = ix->gthr.p;
             ma2.ablate = g_sparse_ablate;
-            static const bool want_stats = getenv("BH_SPARSE_STATS") != nullptr;  // diagnostics: candidate-path event counts
+            // Non-negative corpus and tile: scores are >= 0, a zero-score document can only enter a top-k that has fewer
+            // than k positive documents, and then it is simply one of the lowest row ids.  The scan then never collects
+            // zero-score documents (threshold floor 0, exclusive) and the merge fills short lists with the lowest absent rows.
+            bool nonneg_q = true;
+            for (int j = 0; j < nt && nonneg_q; ++j)
+                for (auto& tv : qnz[(size_t)(q0 + j)])
+                    if (tv.second & 0x8000u) {
+                        nonneg_q = false;
+                        break;
+                    }
+            floor_zero = ix->nonneg_docs && nonneg_q && !getenv("BH_SPARSE_NO_FLOOR");
+            ma2.floor_zero = floor_zero ? 1 : 0;
+            static const int stats_mode = getenv("BH_SPARSE_STATS") ? atoi(getenv("BH_SPARSE_STATS")) : 0;  // diagnostics
+            const bool want_stats = stats_mode != 0;
+            ma2.stats_mode = stats_mode;
             ma2.stats = want_stats ? ix->gthr.p + 64 * 64 : nullptr;
-            if (want_stats) BH_HIP_TRY(hipMemsetAsync(ma2.stats, 0, 8 * sizeof(unsigned), st));
+            if (want_stats) BH_HIP_TRY(hipMemsetAsync(ma2.stats, 0, 72 * sizeof(unsigned), st));
             const size_t smem2 = (size_t)ma2.off_tiles + 8 * BH_CSR_MFMA_WAVE_LDS;
             if (smem2 > (size_t)kLdsBytes) return bh_fail(BH_EHIP, "internal: sparse tile exceeds LDS (%zu bytes)", smem2);
             BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
@@ -437,6 +454,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         }
         BH_HIP_TRY(hipEventRecord(ix->ev[2], st));
         BhCsrMergeArgs ma{};
+        ma.floor_zero = floor_zero ? 1 : 0;
         ma.partial = ix->partial.p;
         ma.n_lists = grid;
         ma.entries = ix->entries.p;
@@ -452,9 +470,15 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         BH_HIP_TRY(hipEventRecord(ix->ev[3], st));
         BH_HIP_TRY(hipStreamSynchronize(st));  // the host tables are rebuilt for the next tile
         if (mfma && getenv("BH_SPARSE_STATS")) {
-            unsigned stv[8];
+            unsigned stv[72];
             BH_HIP_TRY(hipMemcpy(stv, ix->gthr.p + 64 * 64, sizeof(stv), hipMemcpyDeviceToHost));
             fprintf(stderr, "[bh sparse stats] groups_with_hits=%u appended=%u compactions=%u polls=%u\n", stv[0], stv[1], stv[2], stv[3]);
+            for (int w = 0; w < 8; ++w) {  // sampled waves: s_memtime ticks
+                const unsigned* o = stv + 8 + w * 8;
+                if (o[0])
+                    fprintf(stderr, "[bh sparse wave %d] total=%u entries=%u appends=%u (groups 0-3: %u, 4-15: %u) final thr q0=%g q5=%g\n",
+                            w * 256, o[0], o[6], o[7], o[4], o[5], *reinterpret_cast<const float*>(&o[2]), *reinterpret_cast<const float*>(&o[3]));
+            }
         }
         float ms = 0;
         BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]));

@@ -161,3 +161,41 @@ def test_retrieve_stage_on_sparse_chunks(amd, tmp_path):
     assert out["doc_id"] == [[f"d{j}" for j in row] for row in want_i]
     assert out["q_id"] == [f"q{i}" for i in range(Q)]
     r.close()
+
+
+def test_negative_weights_take_the_general_path_and_few_positives_fill_with_low_rows(amd):
+    """The non-negative fast path (no zero-score candidates; short lists filled with the lowest absent rows) must agree
+    with the oracle, and signed weights must fall back to the general path: negative scores rank BELOW the zeros."""
+    V = 1200
+    rng = np.random.default_rng(17)
+    dp, dt, dw = synth.random_sparse_corpus(3000, V, seed=18, mean_nnz=20, lo=0, hi=50)
+    dense = synth.csr_to_dense(dp, dt, dw, V)
+    q = np.zeros((5, V), np.float16)
+    rare = int(np.argmin((dense != 0).sum(0) + 10_000 * ((dense != 0).sum(0) == 0)))  # a term present in few documents
+    q[0, rare] = 1.5                      # fewer positive documents than k: fill with rows 0, 1, 2, ... not in the list
+    q[1, dt[dp[3]:dp[4]][:4]] = 0.75
+    q[2, :] = 0
+    q[3, rng.integers(0, V, 30)] = 1.0
+    q[4, rng.integers(0, V, 3)] = 0.5
+    for signed in (False, True):
+        d = dense.copy()
+        qq = q.copy()
+        if signed:
+            d[5:400:7] *= -1               # documents with negative weights
+            qq[4] *= -1                    # and a query with negative weights
+        p2 = np.zeros(len(d) + 1, np.int64)
+        nz = d != 0
+        np.cumsum(nz.sum(1), out=p2[1:])
+        r, c = np.nonzero(nz)
+        vals = d[r, c].astype(np.float16)
+        ix = amd.SparseIndex(len(d), V, device=0)
+        ix.upload((p2, c.astype(np.int32), vals))
+        ix.finalize()
+        s, i = ix.search(qq, 60)
+        want_s, want_i = c_oracle.sparse_canonical_search(p2, c.astype(np.int32), vals, V, qq, 60)
+        assert_bit_exact(s, i, want_s, want_i, f"few positives, signed={signed}")
+        if not signed:
+            n_pos = int((want_s[0] > 0).sum())
+            assert 0 < n_pos < 60 and np.all(want_s[0][n_pos:] == 0)
+            assert np.array_equal(i[2], np.arange(60))
+        ix.close()
