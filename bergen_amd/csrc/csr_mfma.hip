@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     float pub[2];
     long long next_poll = 0;
     int n_polls = 0;
+    const __amdgpu_buffer_rsrc_t gthr_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gthr, 0, 64 * 64 * 4, 0x00020000);
 #pragma unroll
     for (int w2 = 0; w2 < 2; ++w2) {
         thr[w2] = a.floor_zero ? 0.f : -__builtin_inff();  // candidate iff score > thr
@@ -151,7 +152,11 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         }
     };
     // diagnostics (BH_SPARSE_STATS): cycle counts of the phases of a few sampled waves (s_memtime; perturbs little)
+#ifdef BH_CSR_TIMERS  // diagnostic build (make CXXFLAGS+=-DBH_CSR_TIMERS): the accumulators cost ~16 VGPRs
     const bool timed = a.stats_mode == 2 && (gw & 255) == 0;
+#else
+    constexpr bool timed = false;
+#endif
     long long t_kernel = timed ? (long long)__builtin_amdgcn_s_memtime() : 0, t_hit = 0, t_poll = 0, t_drain = 0, t_mfma = 0, t_need = 0;
     unsigned n_entries = 0, n_appends = 0, n_app_early = 0, n_app_mid = 0;
     // pending hits of the current group (wave-uniform ring indices)
@@ -294,12 +299,11 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                                 const int q = w2 * 32 + (hb * 4 + i4) * 4 + (lane >> 4);
                                 // agent-scope loads (sc1): the table is written by atomics from all eight XCDs, whose L2s are
                                 // not coherent with each other — a plain or nt load can be served a stale line by this XCD's
-                                // L2 forever, which silently disables the filter
-                                const unsigned* src = a.gthr + (size_t)q * 64 + (lane & 15) * 4;
-                                sl[i4].x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                sl[i4].y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                sl[i4].z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                sl[i4].w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                // L2 forever, which silently disables the filter.  One 16-byte buffer load per lane (four
+                                // dword atomic loads need four address pairs each: register spills).
+                                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(gthr_rsrc, (q * 64 + (lane & 15) * 4) * 4, 0, /*sc1*/ 16);
+                                sl[i4] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
                             }
 #pragma unroll
                             for (int i4 = 0; i4 < 4; ++i4) {
