@@ -86,6 +86,7 @@ struct bh_index {
     bool finalized = false;
     std::vector<std::pair<int64_t, int64_t>> have;  // merged [begin, end) intervals uploaded
     hipStream_t stream = nullptr;
+    hipStream_t merge_stream = nullptr;  // merge / re-score of pass p runs beside the scan of pass p + 1
     DevBuf<bh_u64> cand, partial;
     DevBuf<unsigned> gthr;
     DevBuf<_Float16> qbuf;
@@ -295,6 +296,7 @@ void bh_index_destroy(bh_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    if (ix->merge_stream) (void)hipStreamDestroy(ix->merge_stream);
     for (auto e : ix->events) (void)hipEventDestroy(e);
     ix->cand.release();
     ix->partial.release();
@@ -369,10 +371,13 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     int rc;
     if ((rc = ix->qbuf.ensure((size_t)nq_pad * dp))) return rc;
     if ((rc = ix->cand.ensure((size_t)grid * bq * 2 * kp))) return rc;
-    if ((rc = ix->partial.ensure((size_t)grid * bq * kp))) return rc;
+    const size_t partial_elems = (size_t)grid * bq * kp;
+    if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: pass p is merged while pass p + 1 is scanned
     if ((rc = ix->gthr.ensure((size_t)bq * qs_max * 64 + grid))) return rc;
 
     hipStream_t st = ix->stream;
+    if (!ix->merge_stream) HIP_TRY(hipStreamCreateWithFlags(&ix->merge_stream, hipStreamNonBlocking));
+    hipStream_t ms = ix->merge_stream;
     // queries -> padded fp16 tile buffer (zero rows beyond nq)
     if (nq_pad > nq) HIP_TRY(hipMemsetAsync(ix->qbuf.p + (size_t)nq * dp, 0, (size_t)(nq_pad - nq) * dp * 2, st));
     HIP_TRY(bh_launch_convert_rows(q_dev, q_dtype, nq, ix->dim, ix->qbuf.p, dp, st));
@@ -381,7 +386,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     hipEvent_t ev_begin = ix->event(0), ev_end = ix->event(1);
     if (!ev_begin || !ev_end) return fail(BH_EHIP, "hipEventCreate failed");
     for (int p = 0; p < n_pass; ++p)
-        if (!ix->event(2 + 3 * p + 2)) return fail(BH_EHIP, "hipEventCreate failed");
+        if (!ix->event(2 + 4 * p + 3)) return fail(BH_EHIP, "hipEventCreate failed");
 
     HIP_TRY(hipEventRecord(ev_begin, st));
     double alg_bytes = 0;
@@ -396,7 +401,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.n_tiles = ix->n_tiles;
         sa.qtile = ix->qbuf.p + (size_t)q0 * dp;
         sa.cand = ix->cand.p;
-        sa.partial = ix->partial.p;
+        bh_u64* partial_p = ix->partial.p + (size_t)(p & 1) * partial_elems;
+        sa.partial = partial_p;
         sa.gthr = ix->gthr.p;
         sa.share = g_opt.share_threshold;
         sa.nontemporal = g_opt.nontemporal;
@@ -407,14 +413,18 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.pair_window = g_opt.pair_window;
         sa.progress = ix->gthr.p + (size_t)bq * qs_max * 64;  // [grid] words behind the slot table
         if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
-        HIP_TRY(hipEventRecord(ix->event(2 + 3 * p), st));
+        // this pass overwrites the partial set that pass p - 2 left for its merge: wait for that merge
+        if (p >= 2) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * (p - 2) + 3), 0));
+        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p), st));
         if (g_opt.scan_kernel == 1 && qw == 1 && bh_scan8_supports(dp))
             HIP_TRY(bh_launch_scan8(sa, dp, kp, grid, st));
         else
             HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
-        HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 1), st));
+        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 1), st));
+        // merge + canonical re-score on the side stream, beside the next pass's scan
+        HIP_TRY(hipStreamWaitEvent(ms, ix->event(2 + 4 * p + 1), 0));
         BhMergeArgs ma;
-        ma.partial = ix->partial.p;
+        ma.partial = partial_p;
         ma.n_lists = grid / qs;
         ma.bq = tile;
         ma.corpus = ix->rows;
@@ -425,11 +435,14 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         ma.id_offset = id_offset;
         ma.out_scores = out_scores_dev + (size_t)q0 * k;
         ma.out_ids = reinterpret_cast<long long*>(out_ids_dev) + (size_t)q0 * k;
-        HIP_TRY(bh_launch_merge_rescore(ma, kp, nq_tile, st));
-        HIP_TRY(hipEventRecord(ix->event(2 + 3 * p + 2), st));
+        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 2), ms));
+        HIP_TRY(bh_launch_merge_rescore(ma, kp, nq_tile, ms));
+        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 3), ms));
         // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
         alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + (double)tile * ix->dim * 2.0 + (double)tile * k * 12.0;
     }
+    // the search ends when the last merges have: bring the side stream back into the main one
+    for (int p = std::max(0, n_pass - 2); p < n_pass; ++p) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * p + 3), 0));
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipStreamSynchronize(st));
 
@@ -445,10 +458,10 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     c.merge_ms = 0;
     for (int p = 0; p < n_pass; ++p) {
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 3 * p), ix->event(2 + 3 * p + 1)));
+        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p), ix->event(2 + 4 * p + 1)));
         c.scan_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 3 * p + 1), ix->event(2 + 3 * p + 2)));
-        c.merge_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p + 2), ix->event(2 + 4 * p + 3)));
+        c.merge_ms += ms;  // (runs beside the next pass's scan: not additive with scan_ms)
     }
     float tot = 0;
     HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
