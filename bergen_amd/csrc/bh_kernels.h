@@ -228,3 +228,6 @@ struct BhClsHeadArgs {
     int batch, d, n_labels;
 };
 hipError_t bh_launch_cls_head(const BhClsHeadArgs& a, hipStream_t stream);
+
+hipError_t bh_launch_scatter_f16(unsigned short* dst, const unsigned long long* pos, const unsigned short* val, int n,
+                                 hipStream_t stream);

@@ -321,6 +321,21 @@ __global__ void __launch_bounds__(256) bh_csr_merge_rescore_kernel(BhCsrMergeArg
     }
 }
 
+// dst[pos[i]] = val[i]: builds the dense fp16 query matrix on the device from the queries' non-zeros (the matrix is
+// mostly zeros: a memset plus a few thousand scattered halves instead of a 15 MB host-to-device copy)
+__global__ void __launch_bounds__(256) bh_scatter_f16_kernel(unsigned short* dst, const unsigned long long* pos,
+                                                             const unsigned short* val, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[pos[i]] = val[i];
+}
+
+hipError_t bh_launch_scatter_f16(unsigned short* dst, const unsigned long long* pos, const unsigned short* val, int n,
+                                 hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_scatter_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, pos, val, n);
+    return hipGetLastError();
+}
+
 hipError_t bh_launch_csr_scan(const BhCsrScanArgs& a, int kp, int grid, size_t smem, hipStream_t stream) {
     static size_t attr[2] = {0, 0};
     const void* fn = kp == 64 ? reinterpret_cast<const void*>(bh_csr_scan_topk_kernel<64>)

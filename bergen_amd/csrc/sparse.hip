@@ -11,6 +11,7 @@
 // There is no CPU fallback: every entry point that computes needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -40,6 +41,7 @@ struct bh_sparse_index {
     BhDevBuf<unsigned> sinfo, pairs;
     BhDevBuf<unsigned char> outbuf;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_b[4] = {nullptr, nullptr, nullptr, nullptr};  // timing events of odd query tiles (tiles are pipelined in pairs)
     bh_counters counters{};
 };
 
@@ -115,6 +117,7 @@ int bh_sparse_create(bh_sparse_index** out, int64_t n_rows, int32_t vocab) {
     ix->vocab = vocab;
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ix->ev[i]);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ix->ev_b[i]);
     int rc = e == hipSuccess ? ix->row_ptr.ensure((size_t)n_rows + 1) : bh_fail(BH_EHIP, "stream/event: %s", hipGetErrorString(e));
     if (rc == BH_OK) {
         const long long zero = 0;
@@ -147,6 +150,8 @@ void bh_sparse_destroy(bh_sparse_index* ix) {
     ix->pairs.release();
     ix->outbuf.release();
     for (auto& e : ix->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : ix->ev_b)
         if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -247,7 +252,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     if ((rc = ix->bitmap.ensure((size_t)n_words))) return rc;
     if ((rc = ix->prefix.ensure((size_t)n_words))) return rc;
     if ((rc = ix->W.ensure((size_t)(max_slots + 1) * 64))) return rc;
-    if ((rc = ix->qdense.ensure((size_t)kTileQ * V))) return rc;
+    if ((rc = ix->qdense.ensure((size_t)nq * V))) return rc;  // every query, dense fp16 (the re-score kernel indexes it by term)
     const size_t out_bytes = (size_t)nq * k * (sizeof(float) + sizeof(long long));
     if ((rc = ix->outbuf.ensure(out_bytes + 16))) return rc;
     float* d_scores = reinterpret_cast<float*>(ix->outbuf.p);
@@ -262,11 +267,31 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const float* q32 = static_cast<const float*>(q_host);
     // non-zero terms of every query, once (fp16 bit patterns)
     std::vector<std::vector<std::pair<int, unsigned short>>> qnz((size_t)nq);
-    for (int q = 0; q < nq; ++q)
-        for (int t = 0; t < V; ++t) {
-            const unsigned short b = q_dtype == BH_F16 ? q16[(size_t)q * V + t] : f32_to_f16_bits(q32[(size_t)q * V + t]);
-            if (b & 0x7fffu) qnz[(size_t)q].emplace_back(t, b);
+    for (int q = 0; q < nq; ++q) {
+        auto& out = qnz[(size_t)q];
+        if (q_dtype == BH_F16) {  // the rows are almost all zeros: skip them eight bytes at a time
+            const unsigned short* row = q16 + (size_t)q * V;
+            int t = 0;
+            for (; t < V && ((uintptr_t)(row + t) & 7u); ++t)
+                if (row[t] & 0x7fffu) out.emplace_back(t, row[t]);
+            for (; t + 4 <= V; t += 4) {
+                unsigned long long w;
+                memcpy(&w, row + t, 8);
+                if ((w & 0x7fff7fff7fff7fffull) == 0) continue;
+                for (int u = 0; u < 4; ++u)
+                    if (row[t + u] & 0x7fffu) out.emplace_back(t + u, row[t + u]);
+            }
+            for (; t < V; ++t)
+                if (row[t] & 0x7fffu) out.emplace_back(t, row[t]);
+        } else {
+            const float* row = q32 + (size_t)q * V;
+            for (int t = 0; t < V; ++t) {
+                if (row[t] == 0.0f) continue;  // (+-0)
+                const unsigned short b = f32_to_f16_bits(row[t]);
+                if (b & 0x7fffu) out.emplace_back(t, b);
+            }
         }
+    }
     const bool mfma = g_sparse_kernel == 1;
     const int waves_per_wg = mfma ? 8 : 16;
     if ((rc = ix->cand.ensure((size_t)grid * waves_per_wg * 64 * 2 * kp))) return rc;
@@ -275,14 +300,59 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     const int mfma_table_bytes = kLdsBytes - mfma_fixed;  // for sinfo (4 B per slot) + pairs (4 B per pair)
     if (mfma && mfma_table_bytes < 4096) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile tables", V);
 
-    std::vector<unsigned> bm((size_t)n_words);
-    std::vector<unsigned short> pf((size_t)n_words);
-    std::vector<unsigned short> Wh((size_t)(max_slots + 1) * 64);
-    std::vector<unsigned short> qd((size_t)kTileQ * V);
+    if (mfma) {  // full size up front: a growing buffer must not be reallocated under a tile that is still running
+        if ((rc = ix->sinfo.ensure((size_t)mfma_table_bytes / 4 + 64))) return rc;
+        if ((rc = ix->pairs.ensure((size_t)mfma_table_bytes / 4 + 64))) return rc;
+        if ((rc = ix->WhT.ensure(64 * 64))) return rc;
+    }
+    // Host tables come in two sets: while the GPU works on tile p the host builds tile p + 1 (its copies are enqueued
+    // behind tile p's kernels); a set is reused only after the tile that used it has completed.
+    std::vector<unsigned> bm_s[2] = {std::vector<unsigned>((size_t)n_words), std::vector<unsigned>((size_t)n_words)};
+    std::vector<unsigned short> pf_s[2] = {std::vector<unsigned short>((size_t)n_words), std::vector<unsigned short>((size_t)n_words)};
+    std::vector<unsigned short> Wh_s[2];
+    if (!mfma) Wh_s[0].resize((size_t)(max_slots + 1) * 64), Wh_s[1].resize((size_t)(max_slots + 1) * 64);
     std::vector<unsigned> gt(64 * 64, 0x007fffffu);
     std::vector<int> term_cnt((size_t)V, 0);
-    std::vector<unsigned> sinfo_h, pairs_h;
-    std::vector<unsigned short> WhT_h((size_t)64 * 64);
+    std::vector<unsigned> sinfo_s[2], pairs_s[2];
+    std::vector<unsigned short> WhT_s[2] = {std::vector<unsigned short>((size_t)64 * 64), std::vector<unsigned short>((size_t)64 * 64)};
+    // the dense fp16 query matrix for the re-score kernel, built ON the device from the non-zeros (memset + scatter)
+    {
+        std::vector<unsigned long long> qpos;
+        std::vector<unsigned short> qval;
+        for (int q = 0; q < nq; ++q)
+            for (auto& tv : qnz[(size_t)q]) {
+                qpos.push_back((unsigned long long)q * V + (unsigned long long)tv.first);
+                qval.push_back(tv.second);
+            }
+        const size_t nz = qpos.size();
+        if ((rc = ix->W.ensure(std::max((size_t)(max_slots + 1) * 64, (nz * 10 + 64) / 2)))) return rc;  // staging for (pos, val)
+        unsigned long long* d_pos = reinterpret_cast<unsigned long long*>(ix->W.p);
+        unsigned short* d_val = reinterpret_cast<unsigned short*>(d_pos + nz);
+        BH_HIP_TRY(hipMemsetAsync(ix->qdense.p, 0, (size_t)nq * V * 2, st));
+        if (nz) {
+            BH_HIP_TRY(hipMemcpyAsync(d_pos, qpos.data(), nz * 8, hipMemcpyHostToDevice, st));
+            BH_HIP_TRY(hipMemcpyAsync(d_val, qval.data(), nz * 2, hipMemcpyHostToDevice, st));
+            BH_HIP_TRY(bh_launch_scatter_f16(reinterpret_cast<unsigned short*>(ix->qdense.p), d_pos, d_val, (int)nz, st));
+        }
+        BH_HIP_TRY(hipStreamSynchronize(st));  // (qpos / qval are locals; W is reused by the broadcast kernel's tiles)
+    }
+    struct Pending {
+        bool on = false;
+        int nt = 0;
+    } pend[2];
+    double scan_ms = 0, merge_ms = 0, bytes = 0;
+    auto collect = [&](int b) -> int {  // wait for the tile that used set b, take its timings
+        if (!pend[b].on) return BH_OK;
+        hipEvent_t* ev = b ? ix->ev_b : ix->ev;
+        BH_HIP_TRY(hipEventSynchronize(ev[3]));
+        float ms = 0;
+        BH_HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2]));
+        scan_ms += ms;
+        BH_HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3]));
+        merge_ms += ms;
+        pend[b].on = false;
+        return BH_OK;
+    };
     bh_counters& c = ix->counters;
     c = bh_counters{};
     c.n_rows = ix->n_rows;
@@ -291,11 +361,19 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     c.n_workgroups = grid;
     c.k_padded = kp;
     c.query_tile = kTileQ;
-    double scan_ms = 0, merge_ms = 0, bytes = 0;
     int n_pass = 0;
     BH_HIP_TRY(hipEventRecord(ix->ev[0], st));
     int q0 = 0;
     while (q0 < nq) {
+        const int par = n_pass & 1;
+        if ((rc = collect(par))) return rc;
+        hipEvent_t* tev = par ? ix->ev_b : ix->ev;
+        auto& bm = bm_s[par];
+        auto& pf = pf_s[par];
+        auto& Wh = Wh_s[par];
+        auto& sinfo_h = sinfo_s[par];
+        auto& pairs_h = pairs_s[par];
+        auto& WhT_h = WhT_s[par];
         // ---- tile: as many queries as fit (<= 64 queries; distinct terms / pairs within the kernel's LDS budget)
         std::fill(bm.begin(), bm.end(), 0u);
         int nt = 0, n_slots = 0, n_pairs_tot = 0;
@@ -322,14 +400,10 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             run += __builtin_popcount(bm[w]);
         }
         auto slot_of = [&](int t) { return (int)pf[t >> 5] + __builtin_popcount(bm[t >> 5] & ((1u << (t & 31)) - 1u)); };
-        std::fill(qd.begin(), qd.begin() + (size_t)nt * V, (unsigned short)0);
-        for (int j = 0; j < nt; ++j)
-            for (auto& tv : qnz[(size_t)(q0 + j)]) qd[(size_t)j * V + tv.first] = tv.second;
         BH_HIP_TRY(hipMemcpyAsync(ix->bitmap.p, bm.data(), (size_t)n_words * 4, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->prefix.p, pf.data(), (size_t)n_words * 2, hipMemcpyHostToDevice, st));
-        BH_HIP_TRY(hipMemcpyAsync(ix->qdense.p, qd.data(), (size_t)nt * V * 2, hipMemcpyHostToDevice, st));
         BH_HIP_TRY(hipMemcpyAsync(ix->gthr.p, gt.data(), 64 * 64 * 4, hipMemcpyHostToDevice, st));
-        BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+        BH_HIP_TRY(hipEventRecord(tev[1], st));
         bool floor_zero = false;
         if (!mfma) {
             std::fill(Wh.begin(), Wh.begin() + (size_t)(n_slots + 1) * 64, (unsigned short)0);
@@ -351,7 +425,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             sa.cand = ix->cand.p;
             sa.partial = ix->partial.p;
             sa.gthr = ix->gthr.p;
-            BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+            BH_HIP_TRY(hipEventRecord(tev[1], st));
             BH_HIP_TRY(bh_launch_csr_scan(sa, kp, grid, (size_t)sa.off_thr + 256, st));
         } else {
             // head = the (up to) 64 terms used by the most queries of the tile; the rest are tail terms with pair lists
@@ -439,7 +513,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             if (want_stats) BH_HIP_TRY(hipMemsetAsync(ma2.stats, 0, 72 * sizeof(unsigned), st));
             const size_t smem2 = (size_t)ma2.off_tiles + 8 * BH_CSR_MFMA_WAVE_LDS;
             if (smem2 > (size_t)kLdsBytes) return bh_fail(BH_EHIP, "internal: sparse tile exceeds LDS (%zu bytes)", smem2);
-            BH_HIP_TRY(hipEventRecord(ix->ev[1], st));
+            BH_HIP_TRY(hipEventRecord(tev[1], st));
             // Pre-pass: the same kernel over a short prefix of the corpus with a small grid, only to fill the threshold
             // slot table (its candidate lists are overwritten by the main launch, which scans the prefix again).
             // 64 workgroups: one per slot of the table (a slot nobody wrote leaves the bound open)
@@ -452,7 +526,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             }
             BH_HIP_TRY(bh_launch_csr_scan_mfma(ma2, kp, grid, smem2, st));
         }
-        BH_HIP_TRY(hipEventRecord(ix->ev[2], st));
+        BH_HIP_TRY(hipEventRecord(tev[2], st));
         BhCsrMergeArgs ma{};
         ma.floor_zero = floor_zero ? 1 : 0;
         ma.partial = ix->partial.p;
@@ -460,36 +534,35 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         ma.entries = ix->entries.p;
         ma.row_ptr = ix->row_ptr.p;
         ma.n_rows = ix->n_rows;
-        ma.q_dense = ix->qdense.p;
+        ma.q_dense = ix->qdense.p + (size_t)q0 * V;
         ma.vocab = V;
         ma.k = k;
         ma.id_offset = id_offset;
         ma.out_scores = d_scores + (size_t)q0 * k;
         ma.out_ids = d_ids + (size_t)q0 * k;
         BH_HIP_TRY(bh_launch_csr_merge_rescore(ma, kp, nt, st));
-        BH_HIP_TRY(hipEventRecord(ix->ev[3], st));
-        BH_HIP_TRY(hipStreamSynchronize(st));  // the host tables are rebuilt for the next tile
+        BH_HIP_TRY(hipEventRecord(tev[3], st));
+        pend[par].on = true;
+        pend[par].nt = nt;
         if (mfma && getenv("BH_SPARSE_STATS")) {
+            BH_HIP_TRY(hipStreamSynchronize(st));
             unsigned stv[72];
             BH_HIP_TRY(hipMemcpy(stv, ix->gthr.p + 64 * 64, sizeof(stv), hipMemcpyDeviceToHost));
             fprintf(stderr, "[bh sparse stats] groups_with_hits=%u appended=%u compactions=%u polls=%u\n", stv[0], stv[1], stv[2], stv[3]);
-            for (int w = 0; w < 8; ++w) {  // sampled waves: s_memtime ticks
+            for (int w = 0; w < 8; ++w) {  // sampled waves (BH_CSR_TIMERS builds): s_memtime ticks
                 const unsigned* o = stv + 8 + w * 8;
                 if (o[0])
                     fprintf(stderr, "[bh sparse wave %d] total=%u entries=%u appends=%u (groups 0-3: %u, 4-15: %u) final thr q0=%g q5=%g\n",
                             w * 256, o[0], o[6], o[7], o[4], o[5], *reinterpret_cast<const float*>(&o[2]), *reinterpret_cast<const float*>(&o[3]));
             }
         }
-        float ms = 0;
-        BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]));
-        scan_ms += ms;
-        BH_HIP_TRY(hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]));
-        merge_ms += ms;
         // nnz*(2+2) + (N+1)*8 per query-tile pass (+ the tile's results)
         bytes += (double)ix->nnz * 4.0 + (double)(ix->n_rows + 1) * 8.0 + (double)nt * k * 12.0;
         ++n_pass;
         q0 += nt;
     }
+    if ((rc = collect(0))) return rc;
+    if ((rc = collect(1))) return rc;
     BH_HIP_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     BH_HIP_TRY(hipMemcpyAsync(out_ids, d_ids, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
     BH_HIP_TRY(hipStreamSynchronize(st));
