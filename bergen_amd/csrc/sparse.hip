@@ -31,6 +31,7 @@ struct bh_sparse_index {
     int64_t nnz = 0;
     bool finalized = false;
     hipStream_t stream = nullptr;
+    hipStream_t merge_stream = nullptr;  // merge / re-score of tile p runs beside the scan of tile p + 1
     BhDevBuf<unsigned> entries;
     BhDevBuf<long long> row_ptr;
     BhDevBuf<bh_u64> cand, partial;
@@ -153,6 +154,7 @@ void bh_sparse_destroy(bh_sparse_index* ix) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : ix->ev_b)
         if (e) (void)hipEventDestroy(e);
+    if (ix->merge_stream) (void)hipStreamDestroy(ix->merge_stream);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -247,7 +249,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     if (max_slots < 8) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile weights", V);
     const int grid = ix->n_cu;
     int rc;
-    if ((rc = ix->partial.ensure((size_t)grid * 64 * kp))) return rc;
+    const size_t partial_elems = (size_t)grid * 64 * kp;
+    if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: tile p is merged while tile p + 1 is scanned
     if ((rc = ix->gthr.ensure(64 * 64 + 8 + 64))) return rc;  // [64 queries][64 slots] (csr_mfma.hip); csr_topk.hip uses the first 64 words
     if ((rc = ix->bitmap.ensure((size_t)n_words))) return rc;
     if ((rc = ix->prefix.ensure((size_t)n_words))) return rc;
@@ -263,6 +266,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         d_ids = reinterpret_cast<long long*>(ix->outbuf.p + (((size_t)nq * k * sizeof(float) + 15) / 16 * 16));
     }
     hipStream_t st = ix->stream;
+    if (!ix->merge_stream) BH_HIP_TRY(hipStreamCreateWithFlags(&ix->merge_stream, hipStreamNonBlocking));
+    hipStream_t mst = ix->merge_stream;
     const unsigned short* q16 = static_cast<const unsigned short*>(q_host);
     const float* q32 = static_cast<const float*>(q_host);
     // non-zero terms of every query, once (fp16 bit patterns)
@@ -423,7 +428,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             sa.off_w = off_w;
             sa.off_thr = off_w + (n_slots + 1) * 128;
             sa.cand = ix->cand.p;
-            sa.partial = ix->partial.p;
+            sa.partial = ix->partial.p + (size_t)par * partial_elems;
             sa.gthr = ix->gthr.p;
             BH_HIP_TRY(hipEventRecord(tev[1], st));
             BH_HIP_TRY(bh_launch_csr_scan(sa, kp, grid, (size_t)sa.off_thr + 256, st));
@@ -491,7 +496,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             ma2.off_thr = (ma2.off_pairs + n_pairs * 4 + 15) / 16 * 16;
             ma2.off_tiles = (ma2.off_thr + 512 + 64 * 144 + 15) / 16 * 16;  // published[64] bound[64] | WhT image | per-wave tiles
             ma2.cand = ix->cand.p;
-            ma2.partial = ix->partial.p;
+            ma2.partial = ix->partial.p + (size_t)par * partial_elems;
             ma2.gthr = ix->gthr.p;
             ma2.ablate = g_sparse_ablate;
             // Non-negative corpus and tile: scores are >= 0, a zero-score document can only enter a top-k that has fewer
@@ -529,7 +534,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         BH_HIP_TRY(hipEventRecord(tev[2], st));
         BhCsrMergeArgs ma{};
         ma.floor_zero = floor_zero ? 1 : 0;
-        ma.partial = ix->partial.p;
+        ma.partial = ix->partial.p + (size_t)par * partial_elems;
         ma.n_lists = grid;
         ma.entries = ix->entries.p;
         ma.row_ptr = ix->row_ptr.p;
@@ -540,8 +545,9 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         ma.id_offset = id_offset;
         ma.out_scores = d_scores + (size_t)q0 * k;
         ma.out_ids = d_ids + (size_t)q0 * k;
-        BH_HIP_TRY(bh_launch_csr_merge_rescore(ma, kp, nt, st));
-        BH_HIP_TRY(hipEventRecord(tev[3], st));
+        BH_HIP_TRY(hipStreamWaitEvent(mst, tev[2], 0));  // side stream: behind this tile's scan, beside the next tile's
+        BH_HIP_TRY(bh_launch_csr_merge_rescore(ma, kp, nt, mst));
+        BH_HIP_TRY(hipEventRecord(tev[3], mst));
         pend[par].on = true;
         pend[par].nt = nt;
         if (mfma && getenv("BH_SPARSE_STATS")) {
