@@ -18,7 +18,8 @@ Synthetic inputs: corpus rows ~ N(0, I) generated on the dev
 normalize(q + 0.3*noise) planted at rows drawn with seed 3.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
-`cpu_baseline` objects.  The oracle is used here only as the checker / CPU baseline.
+`cpu_baseline` objects.  oracle/ is imported by the `cpu_baseline` leg only; the parity gates here recompute canonical
+scores with numpy (parity proper lives in tests/).
 """
 import argparse
 import json
@@ -187,7 +188,7 @@ def splade_legs(args, device_index):
       (`BertEncoder.encode_splade`; the [B, T, vocab] logits are never materialised);
     * search: SURVEY §8d S4 — synthetic CSR corpus (V = 30 522, ~110 terms per document kept, Zipf term ids), 64-query
       tiles, top-k; roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per tile pass.
-    A 200 k-document slice is checked bit-exactly against the oracle's canonical sparse search."""
+    Self-check on a 200 k-document slice: both HIP kernels agree bit for bit, canonical order, scores recomputed in numpy."""
     from bergen_amd import BertEncoder, SparseIndex, synth
     out = {}
     cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
@@ -240,14 +241,30 @@ def splade_legs(args, device_index):
             best = (dt, ix.counters())
     dt, c = best
     gbps = c["algorithmic_bytes"] / (c["scan_ms"] * 1e-3) / 1e9
-    from oracle import c_oracle  # checker only
+    # self-check without the oracle (parity proper lives in tests/): on a 200 k-document slice the two independent HIP
+    # kernels (csr_mfma.hip / csr_topk.hip) must agree bit for bit, rows must come in canonical order, and the scores
+    # must equal the canonical score (fp32 of the fp64 sum in term order) recomputed here with numpy
+    from bergen_amd import _lib
     m = min(len(blk[0]) - 1, 200_000)
     sub = SparseIndex(m, V, device=device_index)
     sub.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
     sub.finalize()
     s2, i2 = sub.search(q[:8], args.k)
-    ws, wi = c_oracle.sparse_canonical_search(blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]], V, q[:8], args.k)
-    ok = bool(np.array_equal(i2, wi) and np.array_equal(s2.view(np.uint32), ws.view(np.uint32)))
+    _lib.set_option("sparse_kernel", 0)
+    s0, i0 = sub.search(q[:8], args.k)
+    _lib.set_option("sparse_kernel", 1)
+    ok = bool(np.array_equal(i2, i0) and np.array_equal(s2.view(np.uint32), s0.view(np.uint32)))
+    ok &= bool((np.diff(s2, axis=1) <= 0).all())
+    ok &= bool(np.all((np.diff(s2, axis=1) < 0) | (np.diff(i2, axis=1) > 0)))
+    qd = q[:8].astype(np.float64)
+    for a in range(8):
+        for b in range(0, args.k, 7):
+            r = int(i2[a, b])
+            t = blk[1][blk[0][r]:blk[0][r + 1]]
+            w = blk[2][blk[0][r]:blk[0][r + 1]].astype(np.float64)
+            o = np.argsort(t, kind="stable")
+            acc = np.cumsum(qd[a, t[o]] * w[o])
+            ok &= bool(np.float32(acc[-1] if len(acc) else 0.0) == s2[a, b])
     out["splade_search"] = {
         "queries_per_s": 256 / dt, "docs": args.splade_docs, "nnz": int(ix.nnz), "scan_ms_per_pass": c["scan_ms"] / c["n_passes"],
         "roofline": {"bound": "hbm", "kernel": "bh_csr_scan_mfma_kernel", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -331,7 +348,6 @@ def main():
     # ---- parity gate (rank 0): planted positives on top + canonical scores of returned ids -------
     parity = "skipped"
     if rank == 0:
-        from oracle import c_oracle
         s_np, i_np = res[0].cpu().numpy(), res[1].cpu().numpy()
         ok = bool((np.diff(s_np, axis=1) <= 0).all())
         owner = {}  # row -> query whose plant was written last (plants can collide on a row)
@@ -345,8 +361,10 @@ def main():
             # re-score the first 4 queries' hits on the CPU from regenerated rows: the canonical
             # scores must match bit-for-bit
             got_rows = _regenerate_rows(i_np[:4].reshape(-1), dim, queries, plant_rows, n_total, device)
-            want = c_oracle.canonical_scores(queries[:4].cpu().numpy(), got_rows,
-                                             np.arange(4 * k, dtype=np.int64).reshape(4, k))
+            # (canonical score = fp32 of the SEQUENTIAL fp64 sum of the exact fp16 x fp16 products; cumsum is sequential)
+            qf = queries[:4].cpu().numpy().astype(np.float64)
+            xf = got_rows.astype(np.float64).reshape(4, k, dim)
+            want = np.cumsum(qf[:, None, :] * xf, axis=-1)[..., -1].astype(np.float32)
             ok &= bool(np.array_equal(want.view(np.uint32), s_np[:4].view(np.uint32)))
         parity = "pass" if ok else "FAIL"
 
