@@ -5,7 +5,7 @@ V = 30 522, ~180 terms per document, Zipf term ids), 64-query tiles, top-50.
   python profiles/bench_sparse.py [--docs 8000000] [--queries 256] [--out gpurun_out/sparse_bench.json]
 
 Reports queries/s and the HBM roofline fraction of the CSR scan kernel (algorithmic bytes = nnz*4 + (N+1)*8 per tile
-pass), and checks the first queries against the oracle on a slice of the corpus."""
+pass), and self-checks the first queries on a slice of the corpus (both HIP kernels + a numpy canonical re-score)."""
 import argparse
 import json
 import os
