@@ -60,17 +60,18 @@ class MeanPooler:
     """sum_t h_t m_t / sum_t m_t  (reference dense.py:64-69)."""
 
     @staticmethod
-    def pool(outputs, mask):
-        outputs = outputs.masked_fill(~mask[..., None].bool(), 0.)
-        return outputs.sum(dim=1) / mask.sum(dim=1)[..., None]
+    def pool(hidden, attention_mask):
+        keep = attention_mask.bool().unsqueeze(-1)
+        summed = torch.where(keep, hidden, torch.zeros((), dtype=hidden.dtype, device=hidden.device)).sum(dim=1)
+        return summed / attention_mask.sum(dim=1).unsqueeze(-1)
 
 
 class ClsPooler:
     """h[:, 0]  (reference dense.py:71-75)."""
 
     @staticmethod
-    def pool(outputs, *args):
-        return outputs[:, 0]
+    def pool(hidden, *unused):
+        return hidden[:, 0]
 
 
 class DotProduct:
@@ -78,8 +79,13 @@ class DotProduct:
     metric = "ip"
 
     @staticmethod
-    def sim(query_embds, doc_embds):
-        return torch.mm(query_embds, doc_embds.t())
+    def sim(q, d):
+        return q @ d.transpose(0, 1)
+
+
+def _unit_rows(x):
+    # (the reference's epsilon, added to the norm: dense.py:87-88)
+    return x / (x.norm(dim=-1, keepdim=True) + 1e-9)
 
 
 class CosineSim:
@@ -87,10 +93,8 @@ class CosineSim:
     metric = "cos"
 
     @staticmethod
-    def sim(query_embds, doc_embds):
-        query_embds = query_embds / (torch.norm(query_embds, dim=-1, keepdim=True) + 1e-9)
-        doc_embds = doc_embds / (torch.norm(doc_embds, dim=-1, keepdim=True) + 1e-9)
-        return torch.mm(query_embds, doc_embds.t())
+    def sim(q, d):
+        return _unit_rows(q) @ _unit_rows(d).transpose(0, 1)
 
 
 class Dense(Retriever):
@@ -119,18 +123,15 @@ class Dense(Retriever):
         else:
             self.query_encoder = self.model  # otherwise symmetric (dense.py:19-20)
         self.tokenizer = tokenizer if tokenizer is not None else AutoTokenizer.from_pretrained(self.model_name)
-        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        if hasattr(self.model, "eval"):
-            self.model.eval()
+        self.device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        for enc in {id(self.model): self.model, id(self.query_encoder): self.query_encoder}.values():
+            if hasattr(enc, "eval"):
+                enc.eval()
         if self.query_encoder is not self.model:
             self.query_encoder = self.query_encoder.to(self.device)
-            if hasattr(self.query_encoder, "eval"):
-                self.query_encoder.eval()
-        self.max_len = max_len
-        self.similarity = similarity
-        self.pooler = pooler
-        self.prompt_q = "" if prompt_q is None else prompt_q
-        self.prompt_d = "" if prompt_d is None else prompt_d
+        self.max_len, self.pooler, self.similarity = max_len, pooler, similarity
+        self.prompt_q = prompt_q or ""
+        self.prompt_d = prompt_d or ""
 
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
@@ -142,20 +143,18 @@ class Dense(Retriever):
                 return {"embedding": encoder.encode_pooled(kwargs, self.pooler)}
             except ValueError:
                 pass  # a pooler the kernels do not know: pool the hidden states in torch below
-        kwargs = {key: value.to(self.device) for key, value in kwargs.items()}
-        outputs = encoder(**kwargs)
-        emb = self.pooler.pool(outputs[0], kwargs['attention_mask'])
-        return {"embedding": emb}
+        on_device = {name: t.to(self.device) for name, t in kwargs.items()}
+        hidden = encoder(**on_device)[0]
+        return {"embedding": self.pooler.pool(hidden, on_device["attention_mask"])}
 
     def collate_fn(self, batch, query_or_doc=None):
-        key = 'generated_query' if query_or_doc == "query" else "content"
-        content = [sample[key] for sample in batch]
-        if query_or_doc == "query":
-            content = ["{}{}".format(self.prompt_q, text) for text in content]
-        if query_or_doc == "doc":
-            content = ["{}{}".format(self.prompt_d, text) for text in content]
-        return self.tokenizer(content, padding="longest", truncation="longest_first", max_length=self.max_len,
-                              return_tensors='pt')
+        """Texts of the batch (queries: `generated_query`, documents: `content`) with the configured prompt in front,
+        tokenised to the longest of the batch (reference dense.py:49-58)."""
+        is_query = query_or_doc == "query"
+        prefix = self.prompt_q if is_query else self.prompt_d if query_or_doc == "doc" else ""
+        texts = [prefix + row['generated_query' if is_query else "content"] for row in batch]
+        return self.tokenizer(texts, padding="longest", truncation="longest_first", max_length=self.max_len, return_tensors='pt')
 
-    def similarity_fn(self, query_embds, doc_embds):
-        return self.similarity.sim(query_embds, doc_embds)
+    def similarity_fn(self, q, d):
+        """[Bq, dim] x [n, dim] -> [Bq, n] (API compatibility; bergen_amd.Retrieve never materialises this matrix)."""
+        return self.similarity.sim(q, d)

@@ -16,7 +16,6 @@ are the fp16 logits of an fp16 model); `sort_by_score_indexes` keeps Python's st
 retrieval order, as in the reference.
 """
 from abc import ABC, abstractmethod
-from collections import defaultdict
 
 import torch
 from torch.utils.data import DataLoader
@@ -83,36 +82,38 @@ class Rerank:
 
     @torch.no_grad()
     def eval(self, dataset):
-        dev = 'cuda' if torch.cuda.is_available() else 'cpu'
-        self.model.model = self.model.model.to(dev)
-        dataloader = DataLoader(dataset, batch_size=self.batch_size, collate_fn=self.model.collate_fn)
-        q_ids, d_ids, scores = list(), list(), list()
-        for batch in tqdm(dataloader, desc=f'Reranking: {self.model.model_name}'):
-            q_ids += batch.pop('q_id')
-            d_ids += batch.pop('d_id')
-            outputs = self.model(batch)
-            scores.append(outputs['score'].detach().cpu())
-        scores = torch.cat(scores).ravel()
-        q_ids_sorted, d_ids_sorted, scores_sorted = self.sort_by_score_indexes(scores, q_ids, d_ids)
+        """Scores every (query, passage) row of `dataset` and returns, per query, the passages by descending score:
+        {"score": list of 1-D tensors, "doc_id": list of lists, "q_id": list} (modules/rerank.py:24-48)."""
+        target = 'cuda' if torch.cuda.is_available() else 'cpu'
+        self.model.model = self.model.model.to(target)
+        loader = DataLoader(dataset, batch_size=self.batch_size, collate_fn=self.model.collate_fn)
+        seen_q, seen_d, parts = [], [], []
+        for batch in tqdm(loader, desc=f'Reranking: {self.model.model_name}'):
+            seen_q.extend(batch.pop('q_id'))
+            seen_d.extend(batch.pop('d_id'))
+            parts.append(self.model(batch)['score'].detach().cpu())
+        flat = torch.cat(parts).reshape(-1)
+        q_sorted, d_sorted, s_sorted = self.sort_by_score_indexes(flat, seen_q, seen_d)
         self.model.model.to('cpu')
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
-        return {"score": scores_sorted, "doc_id": d_ids_sorted, "q_id": q_ids_sorted}
+        return {"score": s_sorted, "doc_id": d_sorted, "q_id": q_sorted}
 
     def sort_by_score_indexes(self, scores, q_ids, d_ids):
-        """Per query (first-appearance order), documents by descending score; the score lists stay ragged
+        """Group by query (first-appearance order), order each group by descending score; ties keep the incoming
+        (retrieval) order, like Python's stable sort in the reference; the score lists stay ragged
         (modules/rerank.py:50-65)."""
-        ranking = defaultdict(list)
-        q_ids_sorted, doc_ids_sorted, scores_sorted = list(), list(), list()
-        for i, (q_id, d_id) in enumerate(zip(q_ids, d_ids)):
-            ranking[q_id].append((scores[i], d_id))
-        for q_id in ranking:
-            sorted_list = sorted(ranking[q_id], key=lambda x: x[0], reverse=True)
-            score_sorted, d_id_sorted = zip(*sorted_list)
-            scores_sorted.append(torch.stack(score_sorted))
-            doc_ids_sorted.append(list(d_id_sorted))
-            q_ids_sorted.append(q_id)
-        return q_ids_sorted, doc_ids_sorted, scores_sorted
+        rows_of = {}
+        for row, q in enumerate(q_ids):
+            rows_of.setdefault(q, []).append(row)
+        out_q, out_d, out_s = [], [], []
+        for q, rows in rows_of.items():
+            group = scores[torch.as_tensor(rows, dtype=torch.long)]
+            order = torch.argsort(group, descending=True, stable=True)
+            out_q.append(q)
+            out_d.append([d_ids[rows[j]] for j in order.tolist()])
+            out_s.append(group[order])
+        return out_q, out_d, out_s
 
     def get_clean_model_name(self):
         return self.model_name

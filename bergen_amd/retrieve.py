@@ -83,60 +83,54 @@ class Retrieve:
 
     # ------------------------------------------------------------------ indexing (encode)
     def index(self, dataset, index_path, query_or_doc, overwrite_index=False):
-        dataset = dataset[query_or_doc]
-        # if dataset has not been encoded before (retrieve.py:40)
-        if not os.path.exists(index_path) or self.continue_batch != None or overwrite_index:
-            if self.model.model_name in ('bm25', 'oracle_provenance'):
-                raise NotImplementedError(f"{self.model.model_name} is out of scope of the dense backend (SURVEY §2)")
-            dataset = dataset.remove_columns(['id'])
-            self._resident.pop(index_path, None)
-            _ = self.encode_and_save(dataset, save_path=index_path, query_or_doc=query_or_doc)
+        """Encode `dataset[query_or_doc]` into `index_path` unless the folder already exists (cache by existence;
+        `continue_batch` and `overwrite_index` force the encode) — reference retrieve.py:37-50."""
+        have = os.path.exists(index_path)
+        if have and self.continue_batch is None and not overwrite_index:
+            return
+        if self.model.model_name in ('bm25', 'oracle_provenance'):
+            raise NotImplementedError(f"{self.model.model_name} is out of scope of the dense backend (SURVEY §2)")
+        self._resident.pop(index_path, None)
+        split = dataset[query_or_doc].remove_columns(['id'])
+        self.encode_and_save(split, save_path=index_path, query_or_doc=query_or_doc)
+
+    def _flush_chunk(self, save_path, last_batch, pieces):
+        """One chunk file, named after the LAST batch it holds; sparse COO for SPLADE (retrieve.py:135-141,196-197)."""
+        block = torch.cat(pieces)
+        if getattr(self.model, 'sparse', False) or 'splade' in self.model.model_name:
+            block = block.to_sparse()
+        torch.save(block, self.get_chunk_path(save_path, last_batch))
 
     @torch.no_grad()
     def encode_and_save(self, dataset, save_path, query_or_doc, chunk_size=150000):
-        """Encode a dataset into embedding_chunk_<last_batch_idx>.pt files (retrieve.py:110-144)."""
-        save_every_n_batches = chunk_size // self.batch_size  # batch_size > 150000 -> ZeroDivisionError below, as in the reference
-        total_n_batches = len(dataset) // self.batch_size + int(bool(len(dataset) % self.batch_size))
+        """Encode a dataset into embedding_chunk_<last_batch_idx>.pt files with the reference's cadence: a chunk is
+        closed after batch i when i is a non-zero multiple of chunk_size // batch_size, and after the last batch
+        (retrieve.py:110-144; first chunk 150000 // B + 1 batches, later ones 150000 // B)."""
+        cadence = chunk_size // self.batch_size  # 0 for batch_size > chunk_size: ZeroDivisionError below, as in the reference
+        n_batches = (len(dataset) + self.batch_size - 1) // self.batch_size
         os.makedirs(save_path, exist_ok=True)
-        dataloader = DataLoader(
-            dataset,
-            batch_size=self.batch_size,
-            collate_fn=lambda batch: self.model.collate_fn(batch, query_or_doc),
-            num_workers=self.num_workers,
-        )
-        embs_list = list()
-        dev = 'cuda' if torch.cuda.is_available() else 'cpu'
-        self.model.model = self.model.model.to(dev)
-        # this process's contiguous range of batches [b_lo, b_hi)
-        per_rank = -(-total_n_batches // self.encode_world)
-        b_lo = min(total_n_batches, self.encode_rank * per_rank)
-        b_hi = min(total_n_batches, b_lo + per_rank)
+        # this process's contiguous range of batches [b_lo, b_hi): everything for a single process
+        share = -(-n_batches // self.encode_world)
+        b_lo = min(n_batches, self.encode_rank * share)
+        b_hi = min(n_batches, b_lo + share)
+        source = dataset
         if self.encode_world > 1:
             from torch.utils.data import Subset
-            rows = range(b_lo * self.batch_size, min(len(dataset), b_hi * self.batch_size))
-            dataloader = DataLoader(Subset(dataset, rows), batch_size=self.batch_size,
-                                    collate_fn=lambda batch: self.model.collate_fn(batch, query_or_doc),
-                                    num_workers=self.num_workers)
-        for i, batch in tqdm(enumerate(dataloader, start=b_lo), total=b_hi - b_lo,
-                             desc=f'Encoding: {self.model.model_name}', file=sys.stderr):
-            if self.continue_batch != None:
-                if i <= self.continue_batch:
-                    continue
-            outputs = self.model(query_or_doc, batch)
-            emb = outputs['embedding']
-            if save_path != None:
-                emb = emb.detach().cpu()
-            embs_list.append(emb)
-            # save chunk (retrieve.py:135-141)
-            if i % save_every_n_batches == 0 and i != 0 or i == b_hi - 1:  # (b_hi = total_n_batches for one process)
-                chunk_save_path = self.get_chunk_path(save_path, i)
-                embs = torch.cat(embs_list)
-                if 'splade' in self.model.model_name or getattr(self.model, 'sparse', False):
-                    embs = embs.to_sparse()
-                torch.save(embs, chunk_save_path)
-                embs_list = list()
+            source = Subset(dataset, range(b_lo * self.batch_size, min(len(dataset), b_hi * self.batch_size)))
+        loader = DataLoader(source, batch_size=self.batch_size, num_workers=self.num_workers,
+                            collate_fn=lambda rows: self.model.collate_fn(rows, query_or_doc))
+        self.model.model = self.model.model.to('cuda' if torch.cuda.is_available() else 'cpu')
+        pieces = []
+        progress = tqdm(enumerate(loader, start=b_lo), total=b_hi - b_lo, desc=f'Encoding: {self.model.model_name}',
+                        file=sys.stderr)
+        for i, batch in progress:
+            if self.continue_batch is not None and i <= self.continue_batch:
+                continue  # resume: batches up to continue_batch were saved by an earlier run
+            pieces.append(self.model(query_or_doc, batch)['embedding'].detach().cpu())
+            if (i != 0 and i % cadence == 0) or i == b_hi - 1:
+                self._flush_chunk(save_path, i, pieces)
+                pieces = []
         self.model.model = self.model.model.to('cpu')
-        return None
 
     # ------------------------------------------------------------------ resident index
     def _build_resident(self, chunk_iter, dataset_size, dim, metric):
@@ -230,22 +224,15 @@ class Retrieve:
         metric = "sparse" if (sparse_queries or getattr(self.model, "sparse", False)) else _metric_of(self.model)
         index = self._resident_index(doc_embeds_path, dataset_size=len(dataset['doc']), metric=metric)
 
-        # separate query embedding in chunks (retrieve.py:81) — one fused search per chunk
-        chunks = torch.split(query_embeds, self.batch_size_sim, dim=0)
-        scores_sorted_topk, indices_sorted_topk = list(), list()
-        for chunk in tqdm(chunks, desc='Retrieving docs...', total=len(chunks)):
-            s, i = index.search(chunk.contiguous(), top_k_documents)
-            scores_sorted_topk.append(torch.from_numpy(s))
-            indices_sorted_topk.append(torch.from_numpy(i))
-        scores_sorted_topk = torch.cat(scores_sorted_topk, dim=0)
-        indices_sorted_topk = torch.cat(indices_sorted_topk, dim=0)
-
-        doc_ids = self._map_doc_ids(dataset['doc'], indices_sorted_topk)
-        return {
-            "score": scores_sorted_topk,
-            "q_id": q_ids,
-            "doc_id": doc_ids
-        }
+        # one fused search per batch_size_sim queries (the reference splits the same way, retrieve.py:81)
+        found_scores, found_rows = [], []
+        pieces = query_embeds.split(self.batch_size_sim, dim=0)
+        for part in tqdm(pieces, total=len(pieces), desc='Retrieving docs...'):
+            part_scores, part_rows = index.search(part.contiguous(), top_k_documents)
+            found_scores.append(torch.from_numpy(part_scores))
+            found_rows.append(torch.from_numpy(part_rows))
+        all_scores, all_rows = torch.cat(found_scores), torch.cat(found_rows)
+        return {"score": all_scores, "q_id": q_ids, "doc_id": self._map_doc_ids(dataset['doc'], all_rows)}
 
     @staticmethod
     def _map_doc_ids(doc_dataset, indices):

@@ -59,10 +59,10 @@ class Splade(Retriever):
         return {"embedding": emb}
 
     def collate_fn(self, batch, query_or_doc=None):
-        key = 'generated_query' if query_or_doc == "query" else "content"
-        content = [sample[key] for sample in batch]
-        return self.tokenizer(content, padding=True, truncation=True, max_length=self.max_len, return_tensors='pt')
+        field = 'generated_query' if query_or_doc == "query" else "content"
+        return self.tokenizer([row[field] for row in batch], padding=True, truncation=True, max_length=self.max_len,
+                              return_tensors='pt')
 
-    def similarity_fn(self, query_embds, doc_embds):
+    def similarity_fn(self, q, d):
         """API compatibility only (materialises [Bq, n]); bergen_amd.Retrieve searches with the CSR kernel."""
-        return torch.sparse.mm(query_embds.to_sparse(), doc_embds.t()).to_dense()
+        return torch.sparse.mm(q.to_sparse(), d.transpose(0, 1)).to_dense()
