@@ -105,7 +105,7 @@ struct BhAttnArgs {
 };
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
-                                        int max_len_long, int n_heads, hipStream_t stream);
+                                        int max_len_long, int n_heads, hipStream_t stream, int short_max = 128);
 
 struct BhEmbedArgs {
     const int* tok;  // [n_rows] token id / position id / token-type id of each packed row

@@ -56,6 +56,7 @@ struct bh_encoder {
     std::map<std::string, bool> have;
     bool committed = false;
     int gemm_variant = 0;
+    int attn_short = 128;  // sequences up to this length use the 4-wave attention workgroups
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
     BhDevBuf<unsigned> SEG;  // SPLADE head: per (sequence, term) running max of relu(logit)
@@ -374,6 +375,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
         e->gemm_variant = (int)value;
         return BH_OK;
     }
+    if (std::string(name) == "attn_short_len") {
+        if (value < 32 || value > 512 || (value & 31)) return bh_fail(BH_EINVAL, "attn_short_len must be a multiple of 32 in 32..512");
+        e->attn_short = (int)value;
+        return BH_OK;
+    }
     return bh_fail(BH_EINVAL, "unknown encoder option '%s'", name);
 }
 
@@ -429,11 +435,11 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     // attention length buckets: sequences of at most 128 tokens first, then the longer ones
     int n_short = 0, max_len_long = 0;
     for (int b = 0; b < batch; ++b)
-        if (len[b] <= 128) sidx[n_short++] = b;
+        if (len[b] <= e->attn_short) sidx[n_short++] = b;
     {
         int w = n_short;
         for (int b = 0; b < batch; ++b)
-            if (len[b] > 128) {
+            if (len[b] > e->attn_short) {
                 sidx[w++] = b;
                 max_len_long = std::max(max_len_long, len[b]);
             }
@@ -526,7 +532,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         aa.seq_off = e->seq_off.p;
         aa.seq_len = d_len;
         aa.d_model = d;
-        BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st));
+        BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short));
         // attention output projection, then LayerNorm(projection + layer input)
         if ((rc = gemm(e, e->CTX.p, d, L.wo, d, e->Y.p, d, m_pad, d, d, L.bo, 1, nullptr, 0, 0))) return rc;
         BhLnArgs la{};

@@ -179,7 +179,8 @@ int bh_encoder_set_tensor(bh_encoder* enc, const char* name, const void* host, i
  * cls.predictions.* tensor was given, the head's transform weights must be complete too). */
 int bh_encoder_commit(bh_encoder* enc);
 /* name in {"gemm_variant" (0 = auto, 1..5 explicit tile configurations, 6 = generic bounds-checked kernel;
- * bench sweeps)}. */
+ * bench sweeps), "attn_short_len" (32..512, multiple of 32; default 128: longest sequence whose attention runs in a
+ * 4-wave workgroup)}. */
 int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
 
 /* One forward pass over a HOST batch in the layout of an HF BatchEncoding (row-major
