@@ -412,6 +412,29 @@ def main():
             "index_build_seconds": build_s,
             "parity_check": parity,
         }
+        if world == 1 and args.query_split is None:
+            # secondary figure: the same search with paired workgroups (library option query_split = 2, default cache
+            # policy): two workgroups of one XCD share the corpus stream through L2, 256 queries per launch, half the HBM
+            # traffic per query.  Not the headline configuration (per-launch roofline fraction is lower); same results.
+            _lib.set_option("query_split", 2)
+            _lib.set_option("nontemporal", 0)
+            s_alt, i_alt = ix.search(queries, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                s_alt, i_alt = ix.search(queries, k)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            ca = ix.counters()
+            same = bool(torch.equal(torch.as_tensor(s_alt), torch.as_tensor(res[0])) and
+                        torch.equal(torch.as_tensor(i_alt), torch.as_tensor(res[1])))
+            out["paired_workgroups"] = {
+                "queries_per_s": nq / dt, "query_tile": ca["query_tile"], "passes_per_step": ca["n_passes"],
+                "avg_launch_ms": ca["scan_ms"] / ca["n_passes"],
+                "roofline_frac": ca["algorithmic_bytes"] / ca["n_passes"] / (ca["scan_ms"] / ca["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "same_results_as_headline": same}
+            _lib.set_option("query_split", 1)
+            _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
         if not args.no_encoder and world == 1:
