@@ -377,7 +377,8 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("n_rows") == hi - lo and tj.get("dim") == dim:
+                # (PMC counters are per kernel: the committed file was collected on the 128-query kernel unless it says otherwise)
+                if tj.get("n_rows") == hi - lo and tj.get("dim") == dim and tj.get("query_tile", 128) == c["query_tile"]:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -402,7 +403,7 @@ def main():
                 "rows_per_gpu": hi - lo, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of partial top-k" if world > 1 else ""),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "bh_scan_topk_kernel",
+                "bound": "hbm", "kernel": "bh_scan_topk192_kernel" if c["query_tile"] == 192 else "bh_scan_topk_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_scan_ms, "launches": n_launch,
@@ -416,6 +417,7 @@ def main():
             # secondary figure: the same search with paired workgroups (library option query_split = 2, default cache
             # policy): two workgroups of one XCD share the corpus stream through L2, 256 queries per launch, half the HBM
             # traffic per query.  Not the headline configuration (per-launch roofline fraction is lower); same results.
+            _lib.set_option("scan_kernel", 0)  # (the paired mode belongs to the 128-query kernel)
             _lib.set_option("query_split", 2)
             _lib.set_option("nontemporal", 0)
             s_alt, i_alt = ix.search(queries, k)
@@ -435,6 +437,19 @@ def main():
                 "same_results_as_headline": same}
             _lib.set_option("query_split", 1)
             _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
+            # and the 128-query kernel on its own (the headline runs the 192-query kernel where it applies)
+            ix.search(queries, k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                ix.search(queries, k)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            cb = ix.counters()
+            out["tile128"] = {"queries_per_s": nq / dt, "query_tile": cb["query_tile"], "passes_per_step": cb["n_passes"],
+                              "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
+                              "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            _lib.set_option("scan_kernel", 2)
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
         if not args.no_encoder and world == 1:

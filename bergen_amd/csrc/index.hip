@@ -53,7 +53,7 @@ struct Options {
     int query_split = 1;
     int pair_window = 0;
     int dma_interleave = 1;
-    int scan_kernel = 0;  // 0 = scan_topk.hip (4 waves), 1 = scan_topk8.hip (8 waves, split dimensions)
+    int scan_kernel = 2;  // 2 = scan_topk192.hip where it applies (d = 768, k <= 56), else 0 = scan_topk.hip (4 waves); 1 = scan_topk8.hip
 } g_opt;
 
 int pad_dim(int dim) {
@@ -211,7 +211,7 @@ int bh_set_option(const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "dma_interleave must be 0 or 1");
         g_opt.dma_interleave = (int)value;
     } else if (s == "scan_kernel") {
-        if (value != 0 && value != 1) return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves) or 1 (8 waves)");
+        if (value < 0 || value > 2) return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves), 1 (8 waves) or 2 (192-query tile)");
         g_opt.scan_kernel = (int)value;
     } else if (s == "pair_window") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
@@ -354,11 +354,13 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
 
     const int dp = ix->dim_padded;
     int qw = (g_opt.query_tile == 256 && bh_scan_supports(dp, kp, 2)) ? 2 : 1;
-    const int bq = 128 * qw;
+    const bool use192 = g_opt.scan_kernel == 2 && bh_scan192_supports(dp, kp);
+    if (use192) qw = 1;
+    const int bq = use192 ? 192 : 128 * qw;
     const int grid = ix->n_cu * g_opt.workgroups_per_cu;
     // passes: a launch scans for qs * bq queries (qs = 2: paired workgroups share the corpus stream through L2,
     // scan_topk.hip); the last queries run unsplit when no more than bq are left
-    const int qs_max = (g_opt.query_split == 2 && grid % 16 == 0) ? 2 : 1;
+    const int qs_max = (g_opt.query_split == 2 && grid % 16 == 0 && !use192) ? 2 : 1;
     std::vector<std::pair<int, int>> passes;  // (first query, qs)
     for (int q0 = 0; q0 < nq;) {
         const int qs = (qs_max == 2 && nq - q0 > bq) ? 2 : 1;
@@ -416,7 +418,9 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         // this pass overwrites the partial set that pass p - 2 left for its merge: wait for that merge
         if (p >= 2) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * (p - 2) + 3), 0));
         HIP_TRY(hipEventRecord(ix->event(2 + 4 * p), st));
-        if (g_opt.scan_kernel == 1 && qw == 1 && bh_scan8_supports(dp))
+        if (use192)
+            HIP_TRY(bh_launch_scan192(sa, dp, kp, grid, st));
+        else if (g_opt.scan_kernel == 1 && qw == 1 && bh_scan8_supports(dp))
             HIP_TRY(bh_launch_scan8(sa, dp, kp, grid, st));
         else
             HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));

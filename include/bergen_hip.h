@@ -123,7 +123,8 @@ int bh_bench_counters(const bh_index* ix, bh_counters* out);
 /* Tuning knobs (process-wide; bench sweeps and A/B comparisons; results are identical for every valid setting).
  * Dense scan: "query_tile" (128|256), "share_threshold" (0|1), "nontemporal" (0|1), "dma_interleave" (0|1, default 1),
  * "query_split" (1|2: paired workgroups share the corpus stream through L2), "pair_window" (0..64), "scan_kernel"
- * (0 = 4-wave kernel, default; 1 = 8-wave split-dimension kernel), "ring_variant" (0..4).  Sparse scan: "sparse_kernel"
+ * (2 = 192-query tile where it applies [d = 768, k <= 56] else the 4-wave kernel, default; 0 = 4-wave kernel; 1 = 8-wave
+ * split-dimension kernel), "ring_variant" (0..4).  Sparse scan: "sparse_kernel"
  * (1 = csr_mfma.hip, default; 0 = csr_topk.hip).  Encoder GEMM: "gemm_stagger_phases", "gemm_stagger_pct".
  * "ablate" / "sparse_ablate" switch parts of the kernels OFF for profiling: results are INVALID while they are set. */
 int bh_set_option(const char* name, int64_t value);

@@ -35,7 +35,7 @@ def usage(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_production_kernels_do_not_spill():
-    srcs = ["scan_topk.hip", "scan_topk8.hip", "gemm_f16_c.hip", "gemm_f16.hip", "attention.hip", "csr_topk.hip", "csr_mfma.hip", "merge_rescore.hip",
+    srcs = ["scan_topk.hip", "scan_topk192.hip", "scan_topk8.hip", "gemm_f16_c.hip", "gemm_f16.hip", "attention.hip", "csr_topk.hip", "csr_mfma.hip", "merge_rescore.hip",
             "encoder_ops.hip"]
     with ThreadPoolExecutor(len(srcs)) as ex:
         results = dict(zip(srcs, ex.map(usage, srcs)))

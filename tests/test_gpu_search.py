@@ -12,7 +12,7 @@ from tests.conftest import gap_tolerance
 pytestmark = pytest.mark.gpu
 
 SPLIT_DEFAULT = 1  # library default of "query_split" (restored after the option tests)
-KERNEL_DEFAULT = 0  # library default of "scan_kernel"
+KERNEL_DEFAULT = 2  # library default of "scan_kernel" (192-query tile where it applies, else the 4-wave kernel)
 
 
 @pytest.fixture(scope="module")
@@ -224,8 +224,9 @@ def test_device_resident_sources_and_queries(amd):
     ws, wi = c_oracle.canonical_search(q, x, 50, id_offset=1_000_000)
     compare.assert_bit_exact(s.cpu().numpy(), i.cpu().numpy(), ws, wi, "device path")
     c = ix.counters()
-    assert c["n_passes"] == 1 and c["query_tile"] == 128 and c["scan_ms"] > 0
-    assert c["algorithmic_bytes"] == 6000 * 768 * 2 + 128 * 768 * 2 + 128 * 50 * 12
+    tile = c["query_tile"]  # 192 (d = 768, k <= 56: scan_topk192.hip) or 128
+    assert c["n_passes"] == 1 and tile in (128, 192) and c["scan_ms"] > 0
+    assert c["algorithmic_bytes"] == 6000 * 768 * 2 + tile * 768 * 2 + tile * 50 * 12
     ix.close()
 
 
@@ -370,3 +371,42 @@ def test_eight_wave_kernel_ties_and_options(amd):
         _lib.set_option("scan_kernel", KERNEL_DEFAULT)
         _lib.set_option("share_threshold", 1)
         _lib.set_option("nontemporal", 1)
+
+
+@pytest.mark.parametrize("kern", [0, 2])
+@pytest.mark.parametrize("n,nq,k", [(33, 1, 5), (9001, 191, 50), (9001, 192, 50), (9001, 193, 50), (70001, 400, 50), (12345, 600, 56)])
+def test_query_tile_kernels_match_oracle(amd, kern, n, nq, k):
+    """scan_kernel 0 (128-query tile, 32x32x16 MFMA) and 2 (192-query tile, 16x16x32 MFMA) at d = 768: same bit-exact
+    results, including the pass boundaries of the 192-query tile."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(n + nq)
+    x = rng.standard_normal((n, 768)).astype(np.float16)
+    q = rng.standard_normal((nq, 768)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    try:
+        _lib.set_option("scan_kernel", kern)
+        ix = amd.FlatIndex(n, 768, metric="ip")
+        ix.upload(x)
+        ix.finalize()
+        s, i = ix.search(q, k)
+        tile = ix.counters()["query_tile"]
+        ix.close()
+        assert tile == (192 if kern == 2 else 128)
+        compare.assert_bit_exact(s, i, ws, wi, f"kernel {kern} n={n} nq={nq} k={k}")
+    finally:
+        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
+
+
+def test_tile192_kernel_exact_ties(amd):
+    from bergen_amd import _lib
+    rng = np.random.default_rng(78)
+    x = rng.integers(-2, 3, size=(5000, 768)).astype(np.float16)
+    q = rng.integers(-2, 3, size=(70, 768)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, 50)
+    try:
+        for kern in (2, 0):
+            _lib.set_option("scan_kernel", kern)
+            s, i = _search(amd, x, q, 50)
+            compare.assert_bit_exact(s, i, ws, wi, f"ties, kernel {kern}")
+    finally:
+        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
