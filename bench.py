@@ -448,7 +448,14 @@ def main():
             cb = ix.counters()
             out["tile128"] = {"queries_per_s": nq / dt, "query_tile": cb["query_tile"], "passes_per_step": cb["n_passes"],
                               "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
-                              "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                              "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "traffic": None}
+            try:  # PMC-derived HBM bytes per launch of THIS kernel (profiles/hbm_traffic.json, collected on the 128-query kernel)
+                tj = json.load(open(args.traffic_json))
+                if tj.get("n_rows") == hi - lo and tj.get("dim") == dim and tj.get("query_tile", 128) == cb["query_tile"]:
+                    out["tile128"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
             _lib.set_option("scan_kernel", 2)
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
