@@ -414,58 +414,73 @@ def main():
             "parity_check": parity,
         }
         if world == 1 and args.query_split is None:
-            # secondary figure: the same search with paired workgroups (library option query_split = 2, default cache
-            # policy): two workgroups of one XCD share the corpus stream through L2, 256 queries per launch, half the HBM
-            # traffic per query.  Not the headline configuration (per-launch roofline fraction is lower); same results.
-            _lib.set_option("scan_kernel", 0)  # (the paired mode belongs to the 128-query kernel)
-            _lib.set_option("query_split", 2)
-            _lib.set_option("nontemporal", 0)
-            s_alt, i_alt = ix.search(queries, k)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
+            try:
+                # secondary figure: the same search with paired workgroups (library option query_split = 2, default cache
+                # policy): two workgroups of one XCD share the corpus stream through L2, 256 queries per launch, half the HBM
+                # traffic per query.  Not the headline configuration (per-launch roofline fraction is lower); same results.
+                _lib.set_option("scan_kernel", 0)  # (the paired mode belongs to the 128-query kernel)
+                _lib.set_option("query_split", 2)
+                _lib.set_option("nontemporal", 0)
                 s_alt, i_alt = ix.search(queries, k)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps
-            ca = ix.counters()
-            same = bool(torch.equal(torch.as_tensor(s_alt), torch.as_tensor(res[0])) and
-                        torch.equal(torch.as_tensor(i_alt), torch.as_tensor(res[1])))
-            out["paired_workgroups"] = {
-                "queries_per_s": nq / dt, "query_tile": ca["query_tile"], "passes_per_step": ca["n_passes"],
-                "avg_launch_ms": ca["scan_ms"] / ca["n_passes"],
-                "roofline_frac": ca["algorithmic_bytes"] / ca["n_passes"] / (ca["scan_ms"] / ca["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "same_results_as_headline": same}
-            _lib.set_option("query_split", 1)
-            _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
-            # and the 128-query kernel on its own (the headline runs the 192-query kernel where it applies)
-            ix.search(queries, k)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    s_alt, i_alt = ix.search(queries, k)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / args.steps
+                ca = ix.counters()
+                same = bool(torch.equal(torch.as_tensor(s_alt), torch.as_tensor(res[0])) and
+                            torch.equal(torch.as_tensor(i_alt), torch.as_tensor(res[1])))
+                out["paired_workgroups"] = {
+                    "queries_per_s": nq / dt, "query_tile": ca["query_tile"], "passes_per_step": ca["n_passes"],
+                    "avg_launch_ms": ca["scan_ms"] / ca["n_passes"],
+                    "roofline_frac": ca["algorithmic_bytes"] / ca["n_passes"] / (ca["scan_ms"] / ca["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "same_results_as_headline": same}
+                _lib.set_option("query_split", 1)
+                _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
+                # and the 128-query kernel on its own (the headline runs the 192-query kernel where it applies)
                 ix.search(queries, k)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / args.steps
-            cb = ix.counters()
-            out["tile128"] = {"queries_per_s": nq / dt, "query_tile": cb["query_tile"], "passes_per_step": cb["n_passes"],
-                              "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
-                              "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                              "traffic": None}
-            try:  # PMC-derived HBM bytes per launch of THIS kernel (profiles/hbm_traffic.json, collected on the 128-query kernel)
-                tj = json.load(open(args.traffic_json))
-                if tj.get("n_rows") == hi - lo and tj.get("dim") == dim and tj.get("query_tile", 128) == cb["query_tile"]:
-                    out["tile128"]["traffic"] = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-            _lib.set_option("scan_kernel", 2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    ix.search(queries, k)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / args.steps
+                cb = ix.counters()
+                out["tile128"] = {"queries_per_s": nq / dt, "query_tile": cb["query_tile"], "passes_per_step": cb["n_passes"],
+                                  "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
+                                  "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "traffic": None}
+                try:  # PMC-derived HBM bytes per launch of THIS kernel (profiles/hbm_traffic.json, collected on the 128-query kernel)
+                    tj = json.load(open(args.traffic_json))
+                    if tj.get("n_rows") == hi - lo and tj.get("dim") == dim and tj.get("query_tile", 128) == cb["query_tile"]:
+                        out["tile128"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+            except Exception as exc:  # a secondary figure must never cost the headline line
+                out["secondary_error"] = repr(exc)
+            finally:
+                _lib.set_option("query_split", 1)
+                _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
+                _lib.set_option("scan_kernel", 2)
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
         if not args.no_encoder and world == 1:
             ix.close()  # the search index is no longer needed: give the HBM back before the encoder leg
-            out.update(encoder_leg(args, local_rank))
+            try:
+                out.update(encoder_leg(args, local_rank))
+            except Exception as exc:
+                out["encoder_error"] = repr(exc)
             if not args.no_splade:
-                out.update(splade_legs(args, local_rank))
+                try:
+                    out.update(splade_legs(args, local_rank))
+                except Exception as exc:
+                    out["splade_error"] = repr(exc)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, dim, k)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, dim, k)
+            except Exception as exc:
+                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + repr(exc)}
         print(json.dumps(out), flush=True)
     ix.close()
     if world > 1:
