@@ -39,6 +39,7 @@ class bh_counters(ctypes.Structure):
         ("merge_ms", ctypes.c_double),
         ("total_ms", ctypes.c_double),
         ("algorithmic_bytes", ctypes.c_double),
+        ("shader_mhz", ctypes.c_double),
     ]
 
 
@@ -87,6 +88,7 @@ SYMBOLS = {
     "bh_merge_topk": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "bh_merge_topk_device": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "bh_bench_counters": (ctypes.c_int, [_vp, ctypes.POINTER(bh_counters)]),
+    "bh_debug_scan_timeline": (_i64, [_vp, _vp, _i64]),
     "bh_set_option": (ctypes.c_int, [ctypes.c_char_p, _i64]),
     "bh_encoder_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(bh_encoder_config)]),
     "bh_encoder_set_tensor": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, _i32, _i64]),

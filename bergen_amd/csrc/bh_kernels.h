@@ -21,6 +21,7 @@ struct BhScanArgs {
     unsigned* progress;      // [grid] qsplit = 2: tiles started per workgroup (zeroed by the host), pacing hint only
     int dma_interleave;      // 1: LDS-DMA refills issued one per line between the MFMAs instead of all after the barrier
     int pair_window;         // qsplit = 2: a workgroup may run at most this many tiles ahead of its partner (0 = free-running)
+    bh_u64* clk;             // optional diagnostics [grid][2]: shader cycles and 100 MHz ticks of the scan loop (scan_topk256.hip)
 };
 
 // scan_topk.hip
@@ -32,6 +33,15 @@ bool bh_scan8_supports(int dim_padded);
 // scan_topk192.hip (192 queries per pass on v_mfma_f32_16x16x32_f16; d = 768, k <= 56 only)
 hipError_t bh_launch_scan192(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan192_supports(int dim_padded, int kp);
+// timeline diagnostics of scan_topk256.hip (ablate 5): workgroup 0 records, for BH_TL_TILES tiles from ordinal BH_TL_TILE0,
+// per wave and stage five s_memtime values (before the vmcnt wait, after it, after the barrier, stage end, cycles spent in
+// LDS-DMA issue) behind the [grid][2] clock words of BhScanArgs::clk
+#define BH_TL_TILE0 1200
+#define BH_TL_TILES 6
+#define BH_TL_WORDS (8 * BH_TL_TILES * 2 * 5)
+// scan_topk256.hip (8 waves, two per SIMD, 256 queries per pass; d in {384, 512, 768})
+hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
+bool bh_scan256_supports(int dim_padded, int kp);
 
 struct BhMergeArgs {
     const bh_u64* partial;   // [G][BQ][KP]

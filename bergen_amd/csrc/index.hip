@@ -53,7 +53,9 @@ struct Options {
     int query_split = 1;
     int pair_window = 0;
     int dma_interleave = 1;
-    int scan_kernel = 2;  // 2 = scan_topk192.hip where it applies (d = 768, k <= 56), else 0 = scan_topk.hip (4 waves); 1 = scan_topk8.hip
+    // 3 = scan_topk256.hip (8 waves, 256-query tile) where it applies (d in {384, 512, 768}), else scan_topk.hip;
+    // 2 = scan_topk192.hip where it applies (d = 768, k <= 56); 0 = scan_topk.hip (4 waves); 1 = scan_topk8.hip
+    int scan_kernel = 3;
 } g_opt;
 
 int pad_dim(int dim) {
@@ -89,6 +91,7 @@ struct bh_index {
     hipStream_t merge_stream = nullptr;  // merge / re-score of pass p runs beside the scan of pass p + 1
     DevBuf<bh_u64> cand, partial;
     DevBuf<unsigned> gthr;
+    DevBuf<bh_u64> clk;  // [grid][2] shader cycles / 100 MHz ticks of the last scan launch (diagnostics)
     DevBuf<_Float16> qbuf;
     DevBuf<unsigned char> staging;
     std::vector<hipEvent_t> events;
@@ -202,7 +205,7 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "nontemporal") {
         g_opt.nontemporal = value != 0;
     } else if (s == "ablate") {
-        if (value < 0 || value > 4) return fail(BH_EINVAL, "ablate must be 0..4");
+        if (value < 0 || value > 63) return fail(BH_EINVAL, "ablate must be 0..63");
         g_opt.ablate = (int)value;  // bench-only: results are NOT valid search results when != 0
     } else if (s == "query_split") {
         if (value != 1 && value != 2) return fail(BH_EINVAL, "query_split must be 1 or 2");
@@ -211,13 +214,14 @@ int bh_set_option(const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "dma_interleave must be 0 or 1");
         g_opt.dma_interleave = (int)value;
     } else if (s == "scan_kernel") {
-        if (value < 0 || value > 2) return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves), 1 (8 waves) or 2 (192-query tile)");
+        if (value < 0 || value > 3)
+            return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves), 1 (8 waves, split dims), 2 (192-query tile) or 3 (256-query tile)");
         g_opt.scan_kernel = (int)value;
     } else if (s == "pair_window") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
         g_opt.pair_window = (int)value;
     } else if (s == "ring_variant") {
-        if (value < 0 || value > 4) return fail(BH_EINVAL, "ring_variant must be 0..4");
+        if (value < 0 || value > 7) return fail(BH_EINVAL, "ring_variant must be 0..7");
         g_opt.ring_variant = (int)value;
     } else if (s == "sparse_kernel") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_kernel must be 0 (broadcast) or 1 (mfma)");
@@ -301,6 +305,7 @@ void bh_index_destroy(bh_index* ix) {
     ix->cand.release();
     ix->partial.release();
     ix->gthr.release();
+    ix->clk.release();
     ix->qbuf.release();
     ix->staging.release();
     if (ix->rows) (void)hipFree(ix->rows);
@@ -354,13 +359,14 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
 
     const int dp = ix->dim_padded;
     int qw = (g_opt.query_tile == 256 && bh_scan_supports(dp, kp, 2)) ? 2 : 1;
+    const bool use256 = g_opt.scan_kernel == 3 && bh_scan256_supports(dp, kp);
     const bool use192 = g_opt.scan_kernel == 2 && bh_scan192_supports(dp, kp);
-    if (use192) qw = 1;
-    const int bq = use192 ? 192 : 128 * qw;
+    if (use192 || use256) qw = 1;
+    const int bq = use256 ? 256 : use192 ? 192 : 128 * qw;
     const int grid = ix->n_cu * g_opt.workgroups_per_cu;
     // passes: a launch scans for qs * bq queries (qs = 2: paired workgroups share the corpus stream through L2,
     // scan_topk.hip); the last queries run unsplit when no more than bq are left
-    const int qs_max = (g_opt.query_split == 2 && grid % 16 == 0 && !use192) ? 2 : 1;
+    const int qs_max = (g_opt.query_split == 2 && grid % 16 == 0 && !use192 && !use256) ? 2 : 1;
     std::vector<std::pair<int, int>> passes;  // (first query, qs)
     for (int q0 = 0; q0 < nq;) {
         const int qs = (qs_max == 2 && nq - q0 > bq) ? 2 : 1;
@@ -376,6 +382,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     const size_t partial_elems = (size_t)grid * bq * kp;
     if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: pass p is merged while pass p + 1 is scanned
     if ((rc = ix->gthr.ensure((size_t)bq * qs_max * 64 + grid))) return rc;
+    if ((rc = ix->clk.ensure((size_t)grid * 2 + BH_TL_WORDS, true, ix->stream))) return rc;
 
     hipStream_t st = ix->stream;
     if (!ix->merge_stream) HIP_TRY(hipStreamCreateWithFlags(&ix->merge_stream, hipStreamNonBlocking));
@@ -413,12 +420,15 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.qsplit = qs;
         sa.dma_interleave = g_opt.dma_interleave;
         sa.pair_window = g_opt.pair_window;
+        sa.clk = use256 ? ix->clk.p : nullptr;
         sa.progress = ix->gthr.p + (size_t)bq * qs_max * 64;  // [grid] words behind the slot table
         if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
         // this pass overwrites the partial set that pass p - 2 left for its merge: wait for that merge
         if (p >= 2) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * (p - 2) + 3), 0));
         HIP_TRY(hipEventRecord(ix->event(2 + 4 * p), st));
-        if (use192)
+        if (use256)
+            HIP_TRY(bh_launch_scan256(sa, dp, kp, grid, st));
+        else if (use192)
             HIP_TRY(bh_launch_scan192(sa, dp, kp, grid, st));
         else if (g_opt.scan_kernel == 1 && qw == 1 && bh_scan8_supports(dp))
             HIP_TRY(bh_launch_scan8(sa, dp, kp, grid, st));
@@ -471,6 +481,17 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
     c.total_ms = tot;
     c.algorithmic_bytes = alg_bytes;
+    c.shader_mhz = 0;
+    if (use256) {  // effective shader clock of the last scan launch: cycles per 100 MHz tick, averaged over the workgroups
+        std::vector<bh_u64> h((size_t)grid * 2);
+        HIP_TRY(hipMemcpy(h.data(), ix->clk.p, h.size() * sizeof(bh_u64), hipMemcpyDeviceToHost));
+        double cyc = 0, ticks = 0;
+        for (int g = 0; g < grid; ++g) {
+            cyc += (double)h[2 * g];
+            ticks += (double)h[2 * g + 1];
+        }
+        if (ticks > 0) c.shader_mhz = 100.0 * cyc / ticks;
+    }
     return BH_OK;
 }
 
@@ -570,6 +591,15 @@ int bh_merge_topk(const float* scores, const int64_t* ids, int32_t n_lists, int3
     }
     (void)hipFree(d_s);
     return rc;
+}
+
+int64_t bh_debug_scan_timeline(const bh_index* ix, uint64_t* out, int64_t max_words) {
+    if (!ix || !out || max_words < 0) return fail(BH_EINVAL, "null argument");
+    const int64_t n = std::min<int64_t>(max_words, (int64_t)ix->clk.cap);
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipMemcpy(out, ix->clk.p, (size_t)n * sizeof(bh_u64), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int bh_bench_counters(const bh_index* ix, bh_counters* out) {

@@ -1,0 +1,582 @@
+// scan_topk256.hip — fused inner-product + running top-k scan, 256 queries per corpus pass, two waves per SIMD
+// (option scan_kernel 3; the default wherever the fragments of 32 queries fit 128 + 64 registers: d <= 768).
+//
+// Same contract, candidate scheme and canonical re-score as scan_topk.hip (read that header first); same
+// reference lines replaced: torch.mm (models/retrievers/dense.py:81) + torch.topk (modules/retrieve.py:157).
+//
+// Why.  With ONE wave per SIMD (scan_topk.hip, scan_topk192.hip) everything a wave does besides MFMAs — the
+// LDS-DMA issue (the wave is blocked ~100 cycles per instruction while the memory pipeline is saturated), the LDS
+// latency after every stage barrier, the threshold filter — leaves the SIMD's matrix pipe idle: a pass costs the
+// SUM of the stream and the matrix work (round-1 finding: 3.0 us per 32-row tile where the stream needs 1.8 and
+// the MFMAs 1.2).  Here the workgroup has 8 waves, two per SIMD, each with the fragments of 32 queries and at
+// most 256 registers:
+//   * 256 queries ride on one pass of the corpus (HBM bytes per query: 1/2 of the 128-query kernel's, 3/4 of the
+//     192-query kernel's); every wave reads every stage from LDS against its own queries;
+//   * whatever blocks one wave (DMA issue, barrier, filter, compaction) is covered by its SIMD partner's MFMAs;
+//   * the LDS-DMA refill is spread over 8 waves (LS/2 instructions per wave and stage instead of LS);
+//   * fragment reads are a rolling pipeline PD fragments deep that never drains: the stage barrier is taken one
+//     stage EARLY (at the top of stage s every wave has waited for its pieces of stage s+1), so the first
+//     fragments of the next stage are requested while the last MFMAs of the current one run — no LDS-latency
+//     bubble behind the barrier.  The reads are inline asm with counted `s_waitcnt lgkmcnt(PD-1)` (hipcc waits
+//     lgkmcnt(0) for builtin loads in this loop shape).
+//
+// Register budget (launch bounds 512 x 2 -> 256 per lane; hipcc splits the file 128 VGPR + 128 AGPR as soon as an
+// AGPR is used): 48 fragments of 4 registers at d = 768 -> 32 pinned in AGPRs, 16 pinned in VGPRs; 16
+// accumulators, PD x 4 fragment-read registers, addresses and filter state in the remaining 64 VGPRs.
+//
+// LDS image, MFMA shape (v_mfma_f32_32x32x16_f16: lane l = query l & 31, 16 rows), filter, candidate buffers,
+// threshold slot table and exactness argument: scan_topk.hip.
+#include "bh_device.h"
+#include "bh_kernels.h"
+
+namespace {
+
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+template <int EPL>
+__device__ __forceinline__ void load_list256(u64 (&e)[EPL], const u64* buf, unsigned n, int lane) {
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const unsigned idx = r * 64 + lane;
+        e[r] = idx < n ? buf[idx] : 0ull;
+    }
+}
+
+template <int KP>
+__device__ __forceinline__ void sort_candidates256(u64 (&e)[2 * KP / 64], const u64* buf, unsigned n, int lane) {
+    load_list256<2 * KP / 64>(e, buf, n, lane);
+    bh_wave_sort_desc<2 * KP / 64>(e, lane);
+}
+
+// one A fragment (32 rows x 16 dims: 16 bytes per lane) from the LDS ring; completion is tracked by hand
+// (s_waitcnt lgkmcnt(n) below), the compiler only sees a register that becomes defined here
+__device__ __forceinline__ void lds_read_frag(half8& dst, unsigned addr, int imm) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm));
+}
+
+// acc += A x B on the matrix pipe, accumulator updated IN PLACE (the builtin lets hipcc put the result into a fresh tuple:
+// 8 more registers in this kernel, which it took from the pinned query fragments).  The accumulators live in VGPRs: the
+// filter reads them with plain VALU instructions (from AGPRs every score costs a v_accvgpr_read first).  `first` starts a
+// tile: C = 0 as an inline constant, no zeroing pass.  Hazards are the caller's: consecutive calls use different
+// accumulators (>= 3 MFMAs between two on the same one), wait states before the first VALU read of a result.
+__device__ __forceinline__ void mfma16_inplace(floatx4& acc, const half8& a, const half8& b, bool b_in_agpr, bool first) {
+    // (both flags are compile-time constants once the caller's loops are unrolled)
+    if (first) {
+        if (b_in_agpr)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b));
+        else
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+    } else {
+        if (b_in_agpr)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+        else
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+}
+
+// max of three without the NaN canonicalisation fmaxf() drags in (one v_max_f32 x, x, x per input): scores are finite
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+}  // namespace
+
+// NK32 = padded dim / 32 (k-steps of the 16x16x32 MFMA per row); KP = candidate list length; LS = 128-byte lines per
+// stage; R = ring depth in stages; PD = fragment reads in flight per wave; NT = non-temporal policy on the corpus stream;
+// ABL (bench-only, results invalid unless 0 or 32): bit flags  1 = no filter / candidate code, 2 = no LDS fragment reads,
+// 4 = no MFMA, 8 = no LDS-DMA refill inside the tile loop (the ring keeps its first contents), 16 = no stage barrier;
+// 32 = production path + s_memtime stamps of workgroup 0's waves (timeline diagnostics into a.clk, see BH_TL_*).
+// LM (who issues the LDS-DMA refill): 0 = all eight waves, half a stage's lines each; 1 = waves 0-3 only, at raised
+// priority; 2 = waves 4-7 only, at raised priority; 3 = waves 0-3, no priority change.
+// SCHED: 0 = rendezvous at the top of a stage, refill spread over the stage; 1 = rendezvous in the middle of the stage,
+// refill in one block right behind it; 2 = rendezvous in the middle, refill spread over the second half.
+template <int NK32, int KP, int LS, int R, int PD, bool NT, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD>
+__global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int D = NK32 * 32;
+    constexpr int LINES = D / 64;
+    static_assert(LINES % LS == 0 && LS % 2 == 0, "a stage is a whole number of line pairs and divides the row");
+    static_assert(R >= 3, "early rendezvous needs three ring slots");
+    constexpr int S = LINES / LS;          // stages per 32-row tile
+    constexpr int NF = LS * 4;             // A fragments per stage: (two k-steps) x (two 16-row blocks) per line
+    constexpr int BF = SCHED == 0 ? 0 : NF / 2;  // fragment of a stage at which its rendezvous is taken
+    constexpr bool SPLIT = LM == 0;
+    constexpr int DPW = SPLIT ? LS / 2 : LS;  // LDS-DMA instructions per (loading) wave and stage
+    static_assert(PD <= NF / 2 && NF % NBUF == 0 && NBUF >= PD, "fragment pipeline depth divides the stage; reads of the next stage start behind the rendezvous");
+    constexpr int STAGE_BYTES = 32 * LS * 128;
+    constexpr int CAP = 2 * KP;
+    constexpr int EPLC = CAP / 64;
+    constexpr int EPLK = KP / 64;
+    constexpr int NB = 2;    // 16-query blocks per wave
+    constexpr int BQ = 256;  // 8 waves x 32 queries
+    constexpr int ROW_BYTES = D * 2;
+    constexpr int RB = KP / 64;
+    // fragments in the accumulator half of the register file (all 128 of its registers; the MFMA accumulators are VGPRs)
+    constexpr int NPIN_A = NB * NK32 < 32 ? NB * NK32 : 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3;   // row group of the LDS-DMA pattern (rows 8 wr .. 8 wr + 7)
+    const int wl = wave >> 2;  // LM 0: which half of a stage's lines this wave fetches; else: loader half or not
+    const bool loader = SPLIT || (LM == 2 ? wl == 1 : wl == 0);
+    const int line0 = SPLIT ? wl * DPW : 0;  // first line of a stage this wave fetches
+    // The matrix pipe of a SIMD serves its two waves by priority, then age; the wave that also issues the refill (each
+    // issue blocks it for ~100 cycles while the memory pipeline is saturated) gets the priority.
+    if (LM == 1 || LM == 2) {
+        if (loader) __builtin_amdgcn_s_setprio(1);
+    }
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int q16 = lane & 15, lg = lane >> 4;
+
+    const int my_tiles = (a.n_tiles > b) ? (int)((a.n_tiles - b + G - 1) / G) : 0;  // < 2^27 (n_rows < 2^32)
+    const unsigned n_rows32 = (unsigned)a.n_rows;
+    u64* cand_wg = a.cand + (size_t)b * BQ * CAP;
+    u64* part_wg = a.partial + (size_t)b * BQ * KP;
+
+    // ---- queries -> registers (B fragments): lane (q16, lg), block nb, k-step s: the 8 halfs at k = 32 s + 8 lg of
+    // query (wave*2 + nb)*16 + q16
+    half8 qf[NB][NK32];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const _Float16* qrow = a.qtile + (size_t)((wave * NB + nb) * 16 + q16) * D;
+#pragma unroll
+        for (int s = 0; s < NK32; ++s) qf[nb][s] = *reinterpret_cast<const half8*>(qrow + 32 * s + 8 * lg);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < NK32; ++s) {
+            if (nb * NK32 + s < NPIN_A)
+                asm volatile("" : "+a"(qf[nb][s]));
+            else
+                asm volatile("" : "+v"(qf[nb][s]));
+        }
+
+    float thr[NB];       // candidate iff score > thr (per lane and block = per query)
+    unsigned cnt[NB];    // entries in the query's candidate buffer (identical in the four lanes of a query)
+    float best[NB][RB];  // this lane's RB best appended scores, descending
+    int next_poll = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        thr[nb] = -__builtin_inff();
+        cnt[nb] = 0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) best[nb][r] = -__builtin_inff();
+    }
+
+    // ---- LDS-DMA source pattern: lanes 8j..8j+7 fetch the eight 16-byte chunks of one line of row 8 wr + j, chunk
+    // order XOR-permuted by g(row) = (row >> 1) & 7 (conflict-free for the 16x16x32 fragment reads, scan_topk192.hip)
+    const int ld_row = 8 * wr + (lane >> 3);
+    const int ld_g = (ld_row >> 1) & 7;
+    const unsigned ld_off = (unsigned)ld_row * ROW_BYTES + (unsigned)(((lane & 7) ^ ld_g) << 4) + (unsigned)(line0 * 128);
+    // fragment read addresses in the stage the READ cursor is in: fragment f of a stage = line f >> 2, k-step parity
+    // sb = (f >> 1) & 1, row block rb = f & 1; lane reads row rb*16 + q16, chunk 4 sb + lg.  g(row) does not depend on rb:
+    // the second row block is the first one's address + 2048 (an immediate), one register per parity.
+    unsigned rdb[2];
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+        rdb[sb] = (unsigned)((q16 >> 3) * 1024 + (q16 & 7) * 128 + (((4 * sb + lg) ^ ((q16 >> 1) & 7)) << 4));
+
+    // Everything the cold paths derive from the lane id is computed from an OPAQUE copy of it: otherwise hipcc hoists the
+    // shuffle partners, sort directions and per-query predicates out of the tile loop and keeps ~40 vector and ~30
+    // scalar registers alive across the hot path.
+    auto opaque_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+    auto compact = [&](int nb, int qq) {
+        const int lane = opaque_lane();
+        const int q16 = lane & 15;
+        const int qi = (wave * NB + nb) * 16 + qq;
+        const unsigned n = __builtin_amdgcn_readlane(cnt[nb], qq);
+        u64* buf = cand_wg + (size_t)qi * CAP;
+        u64 e[EPLC];
+        sort_candidates256<KP>(e, buf, n, lane);
+#pragma unroll
+        for (int r = 0; r < EPLK; ++r) buf[r * 64 + lane] = e[r];
+        if (q16 == qq) cnt[nb] = n < (unsigned)KP ? n : (unsigned)KP;
+        const u64 kth = bh_shfl64(e[EPLK - 1], 63);
+        if (kth != 0ull) {
+            // rows arrive in ascending order inside a workgroup: a later row that merely TIES the KP-th best loses on
+            // row index, so the exclusive compare against the workgroup's own bound is exact
+            const float nt = bh_key_score(kth);
+            if (q16 == qq) thr[nb] = fmaxf(thr[nb], nt);
+        }
+    };
+
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    if (my_tiles > 0) {
+        const unsigned char* corpus = reinterpret_cast<const unsigned char*>(a.corpus);
+        int it = 0;  // issue cursor: tile ordinal, stage of the tile, ring slot
+        int ip = 0;
+        int islot = 0;
+        auto issue_line = [&](int j) {
+            const int itc = it < my_tiles ? it : my_tiles - 1;  // past the end: harmless re-fetch, uniform vmcnt arithmetic
+            const long long tile = b + (long long)itc * G;
+            const unsigned char* src = corpus + (size_t)tile * 32 * ROW_BYTES + (size_t)ip * LS * 128 + ld_off;
+            unsigned char* dst = smem + islot * STAGE_BYTES + line0 * 4096 + wr * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 128),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, NT ? 2 : 0);
+        };
+        auto advance_cursor = [&]() {
+            if (++ip == S) { ip = 0; ++it; }
+            if (++islot == R) islot = 0;
+        };
+#pragma unroll
+        for (int p = 0; p < R - 1; ++p) {
+            if (loader) {
+#pragma unroll
+                for (int j = 0; j < DPW; ++j) issue_line(j);
+            }
+            advance_cursor();
+        }
+
+        // ---- stage 0 landed (own pieces, then everybody's); start the fragment pipeline
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * DPW) : "memory");
+        int cslot = 0;
+        half8 ag[NBUF];  // fragment g of a stage lives in ag[g % NBUF]; NBUF = PD + 1 leaves one step between a buffer's last MFMA and its refill
+        if constexpr (!(ABL & 2)) {
+#pragma unroll
+            for (int f = 0; f < PD; ++f) lds_read_frag(ag[f], rdb[(f >> 1) & 1], (f >> 2) * 4096 + (f & 1) * 2048);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NBUF; ++f) ag[f] = qf[0][f];
+        }
+
+        for (int i = 0; i < my_tiles; ++i) {
+            // four independent accumulator chains (row block x query block): consecutive MFMAs never share one, so the
+            // stream does not depend on the back-to-back forwarding of a single chain (any instruction between two
+            // dependent MFMAs costs ~60 cycles: measured 48 instead of 32 cycles per 32x32x16 MFMA in this loop shape)
+            floatx4 acc[2][NB];  // (every element is first written by the tile's first MFMA on it, with C = 0)
+
+#pragma unroll
+            for (int part = 0; part < S; ++part) {
+                unsigned long long tl0 = 0, tl1 = 0, tl2 = 0, tl_dma = 0;
+                const bool tl_on = (ABL & 32) != 0 && b == 0 && i >= BH_TL_TILE0 && i < BH_TL_TILE0 + BH_TL_TILES;
+                const int nslot = cslot + 1 == R ? 0 : cslot + 1;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int ks = (part * LS + (f >> 2)) * 2 + ((f >> 1) & 1);  // k-step of 32 dims
+                    const int rb = f & 1;
+                    if (f == BF) {
+                        // Rendezvous of stage s, taken at its fragment BF.  Own pieces of stage s+1 landed (R-3 younger
+                        // stages stay in flight), then everybody's did, and everybody has left stage s-1, whose slot this
+                        // stage's refill overwrites.  With BF in the middle of the stage a wave runs from one stage into
+                        // the next without stopping: the filter / candidate code at a tile's end overlaps the other waves'
+                        // MFMAs, up to half a stage of skew is absorbed.
+                        if (tl_on) tl0 = __builtin_readcyclecounter();
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * DPW) : "memory");
+                        if (tl_on) tl1 = __builtin_readcyclecounter();
+                        if constexpr (!(ABL & 16)) asm volatile("s_barrier" ::: "memory");
+                        if (tl_on) tl2 = __builtin_readcyclecounter();
+                        if (SCHED == 1 && loader && !(ABL & 8)) {
+                            // the whole refill in one block right behind the barrier: the loading wave stalls here while its
+                            // SIMD partner has the most MFMA work ahead of it
+#pragma unroll
+                            for (int j = 0; j < DPW; ++j) issue_line(j);
+                            if (tl_on) tl_dma = __builtin_readcyclecounter() - tl2;
+                        }
+                    }
+                    if constexpr (!(ABL & 2)) {
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));
+                        asm volatile("" : "+v"(ag[f % NBUF]));
+                    }
+                    if constexpr ((ABL & 4) != 0) {
+                        if constexpr (!(ABL & 2)) asm volatile("" ::"v"(ag[f % NBUF]));
+                    } else {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            mfma16_inplace(acc[rb][nb], ag[f % NBUF], qf[nb][ks], nb * NK32 + ks < NPIN_A, part == 0 && f < 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!(ABL & 2)) {
+                        const int nf = f + PD;
+                        if (nf == NF) {  // the read cursor enters the next stage
+                            const int delta = nslot == 0 ? -(R - 1) * STAGE_BYTES : STAGE_BYTES;
+#pragma unroll
+                            for (int x = 0; x < 2; ++x) rdb[x] += (unsigned)delta;
+                        }
+                        const int rf = nf < NF ? nf : nf - NF;
+                        lds_read_frag(ag[nf % NBUF], rdb[(rf >> 1) & 1], (rf >> 2) * 4096 + (rf & 1) * 2048);
+                    }
+                    if constexpr (SCHED != 1) {
+                        // the stage's refill spread behind the barrier: one instruction every SP fragments
+                        constexpr int SP = (NF - BF) / DPW;
+                        if (f >= BF && (f - BF) % SP == SP / 2 && (f - BF) / SP < DPW) {
+                            if (loader && !(ABL & 8)) issue_line((f - BF) / SP);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                advance_cursor();
+                cslot = nslot;
+                if (tl_on && lane == 0) {
+                    bh_u64* rec = a.clk + 2 * G + ((size_t)(wave * BH_TL_TILES + (i - BH_TL_TILE0)) * S + part) * 5;
+                    rec[0] = tl0;
+                    rec[1] = tl1;
+                    rec[2] = tl2;
+                    rec[3] = __builtin_readcyclecounter();
+                    rec[4] = tl_dma;
+                }
+            }
+
+            // ---- threshold filter: lane (q16, lg) holds rows 16 rb + 4 lg + v of queries 16 nb + q16
+            const unsigned row0 = ((unsigned)b + (unsigned)i * (unsigned)G) * 32u;  // n_rows < 2^32 (bh_index_create)
+            // last MFMAs -> VALU reads of their results: the hardware does not interlock these, and the wait must be TIED to the
+            // accumulators (a bare asm nop is not ordered against plain register reads: hipcc sank it behind them and the
+            // filter saw the last block's scores one k-step short)
+            if constexpr (!(ABL & 4))
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            else {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[rb][nb][v] = 0.f;
+            }
+            bool over = false;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float m = max3_raw(acc[0][nb][0], acc[0][nb][1], acc[0][nb][2]);
+                m = max3_raw(m, acc[0][nb][3], acc[1][nb][0]);
+                m = max3_raw(m, acc[1][nb][1], acc[1][nb][2]);
+                m = max3_raw(m, acc[1][nb][3], acc[1][nb][3]);
+                if constexpr ((ABL & 1) != 0) {
+                    asm volatile("" ::"v"(m));
+                    m = -__builtin_inff();
+                }
+                over = over || (m > thr[nb]);
+            }
+            // ---- cold paths.  The fragment reads of the next tile's first k-steps are in flight and the compiler does not
+            // know it: the cold block starts by letting them land (code in there may move registers around).  The append of
+            // a tile's few survivors keeps the fragments alive and costs a few hundred cycles, which the half stage of slack
+            // between two rendezvous absorbs; the rare heavy parts (compaction of a full candidate buffer, the threshold
+            // exchange) run with the fragments DEAD and read them again at the end (they are still in the ring): 16
+            // registers more for that code.
+            const bool any_hit = __builtin_amdgcn_ballot_w64(over) != 0ull;
+            const bool do_poll = a.share && i >= next_poll;
+            if (__builtin_expect(any_hit || do_poll, 0)) {
+                if constexpr (!(ABL & 2)) {
+                    asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+                    for (int f = 0; f < NBUF; ++f) asm volatile("" : "+v"(ag[f]));
+                }
+                const int lane_c = opaque_lane();
+                const int q16 = lane_c & 15, lg = lane_c >> 4;
+                if (any_hit) {
+                    // (1) append survivors (room for 32 entries per query is guaranteed by (2) of the previous visit);
+                    //     slot = count + hits of the same query in the lower lane groups.  Hits are rare: the per-row test is
+                    //     a fall-through branch, the work sits out of line.
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        u64* cand_blk = cand_wg + (size_t)(wave * NB + nb) * 16 * CAP;  // uniform base, 32-bit per-lane index
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float sv = acc[rb][nb][v];
+                                if (__builtin_expect(__builtin_amdgcn_ballot_w64(sv > thr[nb]) != 0ull, 0)) {
+                                    const unsigned row = row0 + (unsigned)(rb * 16 + v) + 4u * (unsigned)lg;
+                                    const bool hit = (sv > thr[nb]) && (row < n_rows32);
+                                    const u64 hm = __builtin_amdgcn_ballot_w64(hit);
+                                    const unsigned h0 = (unsigned)(hm >> q16) & 1u, h1 = (unsigned)(hm >> (q16 + 16)) & 1u;
+                                    const unsigned h2 = (unsigned)(hm >> (q16 + 32)) & 1u, h3 = (unsigned)(hm >> (q16 + 48)) & 1u;
+                                    const unsigned below = lg == 0 ? 0u : lg == 1 ? h0 : lg == 2 ? h0 + h1 : h0 + h1 + h2;
+                                    if (hit) {
+                                        cand_blk[(unsigned)q16 * CAP + cnt[nb] + below] = bh_make_key(sv, row);
+                                        if constexpr (RB == 1) {
+                                            // lists of 64: the slot holds the best score of its workgroups; published right
+                                            // here (fire and forget) instead of tracked in a register
+                                            if (a.share)
+                                                __hip_atomic_fetch_max(a.gthr + (size_t)((wave * NB + nb) * 16 + q16) * 64 + (b & 63), bh_ordf(sv),
+                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        } else {
+                                            float x = sv;
+#pragma unroll
+                                            for (int r = 0; r < RB; ++r) {
+                                                const float hi = fmaxf(best[nb][r], x);
+                                                x = fminf(best[nb][r], x);
+                                                best[nb][r] = hi;
+                                            }
+                                        }
+                                    }
+                                    cnt[nb] += h0 + h1 + h2 + h3;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);  // one row at a time: keeps the live ranges of this cold code short
+                            }
+                    }
+                }
+                // (2) make room for the next visit: a tile adds at most 32 entries per query
+                u64 need[NB];
+                bool heavy = do_poll;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    need[nb] = __builtin_amdgcn_ballot_w64(cnt[nb] > (unsigned)(CAP - 32)) & 0xffffull;
+                    heavy = heavy || need[nb] != 0ull;
+                }
+                if (__builtin_expect(heavy, 0)) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        while (need[nb] != 0ull) {
+                            const int qq = __builtin_ctzll(need[nb]);
+                            need[nb] &= need[nb] - 1;
+                            compact(nb, qq);
+                        }
+                    }
+                // ---- threshold exchange through the slot table (filter hint only), geometric schedule (scan_topk.hip)
+                if (do_poll) {
+                    next_poll = i + 1 + (i >> 1);
+                    if constexpr (RB > 1) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int q = (wave * NB + nb) * 16 + q16;
+                            const float mine = best[nb][RB - 1];
+                            if (mine > -__builtin_inff()) {  // (re-published at every exchange: ~20 atomics per lane and pass)
+                                __hip_atomic_fetch_max(a.gthr + (size_t)q * 64 + (b & 63), bh_ordf(mine), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+                    // poll: 16 lanes x 4 slots cover one query, 4 queries per 16-byte agent-scope load (the per-XCD L2s are
+                    // not coherent: sc1), uniform base + 32-bit lane offset; one batch of four loads per query block
+                    const unsigned loff = (unsigned)lane_c * 16u;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const unsigned* tab = a.gthr + (size_t)(wave * NB + nb) * 16 * 64;
+                        uintx4 sl[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1"
+                                         : "=v"(sl[t])
+                                         : "v"(loff), "s"(tab), "n"(t * 1024)
+                                         : "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(sl[t]));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            unsigned mn = min(min(sl[t].x, sl[t].y), min(sl[t].z, sl[t].w));
+#pragma unroll
+                            for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
+                            // lanes 16g..16g+15 now hold the minimum of query 4 t + g of this block
+                            const unsigned got = (unsigned)__shfl((int)mn, (q16 & 3) * 16, 64);
+                            // a row that TIES the bound may still win on row index: inclusive compare
+                            if ((q16 >> 2) == t && got > BH_ORD_NEG_INF) thr[nb] = fmaxf(thr[nb], bh_unordf(got - 1u));
+                        }
+                    }
+                }
+                    // read the next tile's first fragments again (the read cursor already stands behind them)
+                    if constexpr (!(ABL & 2)) {
+#pragma unroll
+                        for (int f = 0; f < PD; ++f) lds_read_frag(ag[f], rdb[(f >> 1) & 1], (f >> 2) * 4096 + (f & 1) * 2048);
+                        asm volatile("s_waitcnt lgkmcnt(0)");
+#pragma unroll
+                        for (int f = 0; f < NBUF; ++f) asm volatile("" : "+v"(ag[f]));
+                    }
+                }
+            }
+        }
+        // drain: tail re-fetches and the fragment reads still in flight (their registers are dead to the compiler)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int f = 0; f < NBUF; ++f) asm volatile("" : "+v"(ag[f]));
+    }
+
+    if (a.clk != nullptr && tid == 0) {  // diagnostics: shader cycles and 100 MHz ticks this workgroup's scan loop took
+        a.clk[2 * b] = __builtin_readcyclecounter() - clk0;
+        a.clk[2 * b + 1] = wall_clock64() - rt0;
+    }
+
+    // ---- final: every wave sorts its queries' buffers and publishes the best KP
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        for (int qq = 0; qq < 16; ++qq) {
+            const int qi = (wave * NB + nb) * 16 + qq;
+            const unsigned n = __builtin_amdgcn_readlane(cnt[nb], qq);
+            u64 e[EPLC];
+            sort_candidates256<KP>(e, cand_wg + (size_t)qi * CAP, n, lane);
+#pragma unroll
+            for (int r = 0; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = e[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+
+template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD>
+static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t stream) {
+    constexpr size_t smem = (size_t)R * 32 * LS * 128;
+    const bool nt = a.nontemporal != 0;
+    static bool attr_done[2] = {false, false};
+    auto kern = nt ? bh_scan_topk256_kernel<NK32, KP, LS, R, PD, true, ABL, LM, SCHED, NBUF> : bh_scan_topk256_kernel<NK32, KP, LS, R, PD, false, ABL, LM, SCHED, NBUF>;
+    if (!attr_done[nt ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_done[nt ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <int NK32, int LS, int R, int PD>
+static hipError_t launch256_kp(const BhScanArgs& a, int kp, int grid, hipStream_t stream) {
+    switch (kp) {
+        case 64: return launch256_one<NK32, 64, LS, R, PD>(a, grid, stream);
+        case 128: return launch256_one<NK32, 128, LS, R, PD>(a, grid, stream);
+        case 256: return launch256_one<NK32, 256, LS, R, PD>(a, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// dims whose 32-query fragments fit two waves per SIMD: d <= 768 (192 registers); d = 1024 needs 256
+bool bh_scan256_supports(int dim_padded, int kp) {
+    return (dim_padded == 768 || dim_padded == 512 || dim_padded == 384) && (kp == 64 || kp == 128 || kp == 256);
+}
+
+hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream) {
+    if (!bh_scan256_supports(dim_padded, kp) || a.qsplit != 1) return hipErrorInvalidValue;
+    switch (dim_padded) {
+        case 384: return launch256_kp<12, 6, 6, 4>(a, kp, grid, stream);
+        case 512: return launch256_kp<16, 4, 9, 4>(a, kp, grid, stream);
+        case 768:
+            if (kp == 64) {
+                // bench-only: ablations and ring geometry / pipeline depth / loader variants of the headline geometry
+                switch (a.ablate) {
+                    case 1: return launch256_one<24, 64, 6, 6, 4, 1>(a, grid, stream);
+                    case 3: return launch256_one<24, 64, 6, 6, 4, 3>(a, grid, stream);
+                    case 5: return launch256_one<24, 64, 6, 6, 4, 5>(a, grid, stream);
+                    case 7: return launch256_one<24, 64, 6, 6, 4, 7>(a, grid, stream);
+                    case 11: return launch256_one<24, 64, 6, 6, 4, 11>(a, grid, stream);
+                    case 19: return launch256_one<24, 64, 6, 6, 4, 19>(a, grid, stream);
+                    case 27: return launch256_one<24, 64, 6, 6, 4, 27>(a, grid, stream);
+                    case 9: return launch256_one<24, 64, 6, 6, 4, 9>(a, grid, stream);
+                    case 17: return launch256_one<24, 64, 6, 6, 4, 17>(a, grid, stream);
+                    case 32:
+                        return a.ring_variant == 4 ? launch256_one<24, 64, 6, 6, 4, 32, 1, 0>(a, grid, stream)
+                                                   : launch256_one<24, 64, 6, 6, 4, 32>(a, grid, stream);
+                    case 43: return launch256_one<24, 64, 6, 6, 4, 43>(a, grid, stream);
+                    case 35: return launch256_one<24, 64, 6, 6, 4, 35>(a, grid, stream);
+                    case 33: return launch256_one<24, 64, 6, 6, 4, 33>(a, grid, stream);
+                    case 0: break;
+                    default: return hipErrorInvalidValue;
+                }
+                switch (a.ring_variant) {
+                    case 1: return launch256_one<24, 64, 6, 6, 4, 0, 0, 1>(a, grid, stream);  // all waves load
+                    case 2: return launch256_one<24, 64, 6, 6, 4, 0, 2, 1>(a, grid, stream);  // waves 4-7 load, raised priority
+                    case 3: return launch256_one<24, 64, 6, 6, 4, 0, 3, 1>(a, grid, stream);  // waves 0-3 load, no priority
+                    case 4: return launch256_one<24, 64, 6, 6, 4, 0, 1, 0>(a, grid, stream);  // rendezvous at the stage top, refill spread
+                    case 5: return launch256_one<24, 64, 6, 6, 4, 0, 1, 2>(a, grid, stream);  // rendezvous mid-stage, refill spread
+                    case 6: return launch256_one<24, 64, 6, 6, 3, 0, 1, 1, 4>(a, grid, stream);  // prefetch distance 3, four buffers
+                    case 7: return launch256_one<24, 64, 4, 9, 4>(a, grid, stream);
+                }
+            }
+            return launch256_kp<24, 6, 6, 4>(a, kp, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}

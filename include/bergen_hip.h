@@ -58,6 +58,7 @@ typedef struct bh_counters {
     double merge_ms;          /* sum of merge+rescore kernel durations */
     double total_ms;          /* first launch -> last kernel done (HIP events), excludes H2D/D2H */
     double algorithmic_bytes; /* sum over passes of N*d*2 + Bq*d*2 + Bq*k*12 */
+    double shader_mhz;        /* effective shader clock during the last scan launch (s_memtime per 100 MHz tick); 0 = not measured */
 } bh_counters;
 
 /* Library / device lifecycle ------------------------------------------------------- */
@@ -119,6 +120,11 @@ int bh_merge_topk_device(const float* scores_dev, const int64_t* ids_dev, int32_
 
 /* Counters of the last search on this index. */
 int bh_bench_counters(const bh_index* ix, bh_counters* out);
+
+/* Diagnostics: copies up to max_words 64-bit words of the last scan launch's clock / timeline record (per workgroup:
+ * shader cycles, 100 MHz ticks; then, with option "ablate" 5, workgroup 0's per-wave stage stamps — layout in
+ * bergen_amd/csrc/bh_kernels.h) into `out`; returns the number of words written or a negative error code. */
+int64_t bh_debug_scan_timeline(const bh_index* ix, uint64_t* out, int64_t max_words);
 
 /* Tuning knobs (process-wide; bench sweeps and A/B comparisons; results are identical for every valid setting).
  * Dense scan: "query_tile" (128|256), "share_threshold" (0|1), "nontemporal" (0|1), "dma_interleave" (0|1, default 1),
