@@ -53,6 +53,7 @@ def parse_args():
     p.add_argument("--share-threshold", type=int, default=None)
     p.add_argument("--nontemporal", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
     p.add_argument("--cpu-sample-queries", type=int, default=1000)
     p.add_argument("--no-encoder", action="store_true", help="skip the passages-encoded/s leg")
@@ -276,6 +277,23 @@ def splade_legs(args, device_index):
     return out
 
 
+def scan_kernel_name(query_tile):
+    """Kernel that serves a query tile of this width (bergen_amd/csrc/index.hip)."""
+    return {256: "bh_scan_topk256_kernel", 192: "bh_scan_topk192_kernel"}.get(query_tile, "bh_scan_topk_kernel")
+
+
+def pmc_traffic(path, kernel, n_rows, dim):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/hbm_traffic.json, keyed by kernel), or None
+    when that file holds no entry for this kernel at this index geometry."""
+    try:
+        ent = json.load(open(path)).get("kernels", {}).get(kernel)
+        if ent and ent.get("n_rows") == n_rows and ent.get("dim") == dim:
+            return ent.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -316,9 +334,13 @@ def main():
     searcher = bergen_amd.ShardedSearcher(ix, lo, rank=rank, world_size=world) if world > 1 else None
 
     def step():
-        if searcher is not None:
-            return searcher.search(queries, k)
-        return ix.search(queries, k)
+        # search_seconds includes the D2H of the result lists: [Q, k] fp32 + int64, 1.7 MB at Q = 2 837
+        r = searcher.search(queries, k) if searcher is not None else ix.search(queries, k)
+        if r is not None and r[0] is not None:
+            host = (torch.as_tensor(r[0]).cpu(), torch.as_tensor(r[1]).cpu())
+        else:
+            host = None
+        return r, host
 
     def barrier():
         torch.cuda.synchronize()
@@ -327,12 +349,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        res = step()
+        res, res_host = step()
     scan_ms = merge_ms = kernel_total_ms = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        res, res_host = step()
         c = ix.counters()
         scan_ms += c["scan_ms"]
         merge_ms += c["merge_ms"]
@@ -348,7 +370,7 @@ def main():
     # ---- parity gate (rank 0): planted positives on top + canonical scores of returned ids -------
     parity = "skipped"
     if rank == 0:
-        s_np, i_np = res[0].cpu().numpy(), res[1].cpu().numpy()
+        s_np, i_np = res_host[0].numpy(), res_host[1].numpy()
         ok = bool((np.diff(s_np, axis=1) <= 0).all())
         owner = {}  # row -> query whose plant was written last (plants can collide on a row)
         for qi in range(nq):
@@ -373,15 +395,8 @@ def main():
         per_launch_bytes = c["algorithmic_bytes"] / c["n_passes"]
         avg_scan_ms = scan_ms / n_launch
         achieved = per_launch_bytes / (avg_scan_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(args.traffic_json):
-            try:
-                tj = json.load(open(args.traffic_json))
-                # (PMC counters are per kernel: the committed file was collected on the 128-query kernel unless it says otherwise)
-                if tj.get("n_rows") == hi - lo and tj.get("dim") == dim and tj.get("query_tile", 128) == c["query_tile"]:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = pmc_traffic(args.traffic_json, scan_kernel_name(c["query_tile"]), hi - lo, dim)
+        flops_per_launch = 2.0 * c["query_tile"] * (hi - lo) * dim  # MFMA work of one launch (query tile padded to its full width)
         out = {
             "metric": "queries/sec (value) + passages-encoded/sec (passages_per_s), KILT-100w-sized corpus (21M x 768 fp16) "
                       "top-50, kilt_nq-dev-sized query set; % of HBM / MFMA roofline",
@@ -403,66 +418,46 @@ def main():
                 "rows_per_gpu": hi - lo, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of partial top-k" if world > 1 else ""),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "bh_scan_topk192_kernel" if c["query_tile"] == 192 else "bh_scan_topk_kernel",
+                "bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_scan_ms, "launches": n_launch,
+                # the same launch against the other roofline: a tile of 256 queries is 256 flop per corpus byte (ridge ~310)
+                "mfma_tflops": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12,
+                "mfma_frac": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                "shader_mhz": c.get("shader_mhz", 0.0),
             },
             "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,
                                    "stream_total": kernel_total_ms / args.steps},
             "index_build_seconds": build_s,
             "parity_check": parity,
         }
-        if world == 1 and args.query_split is None:
+        if world == 1 and args.query_split is None and not args.no_other_kernels:
+            # secondary figures: the same search on the earlier scan kernels (library option scan_kernel), with result equality
+            out["other_kernels"] = []
             try:
-                # secondary figure: the same search with paired workgroups (library option query_split = 2, default cache
-                # policy): two workgroups of one XCD share the corpus stream through L2, 256 queries per launch, half the HBM
-                # traffic per query.  Not the headline configuration (per-launch roofline fraction is lower); same results.
-                _lib.set_option("scan_kernel", 0)  # (the paired mode belongs to the 128-query kernel)
-                _lib.set_option("query_split", 2)
-                _lib.set_option("nontemporal", 0)
-                s_alt, i_alt = ix.search(queries, k)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
+                for kern, label in ((2, "192-query tile, one wave per SIMD"), (0, "128-query tile, one wave per SIMD")):
+                    _lib.set_option("scan_kernel", kern)
                     s_alt, i_alt = ix.search(queries, k)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / args.steps
-                ca = ix.counters()
-                same = bool(torch.equal(torch.as_tensor(s_alt), torch.as_tensor(res[0])) and
-                            torch.equal(torch.as_tensor(i_alt), torch.as_tensor(res[1])))
-                out["paired_workgroups"] = {
-                    "queries_per_s": nq / dt, "query_tile": ca["query_tile"], "passes_per_step": ca["n_passes"],
-                    "avg_launch_ms": ca["scan_ms"] / ca["n_passes"],
-                    "roofline_frac": ca["algorithmic_bytes"] / ca["n_passes"] / (ca["scan_ms"] / ca["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                    "same_results_as_headline": same}
-                _lib.set_option("query_split", 1)
-                _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
-                # and the 128-query kernel on its own (the headline runs the 192-query kernel where it applies)
-                ix.search(queries, k)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    ix.search(queries, k)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / args.steps
-                cb = ix.counters()
-                out["tile128"] = {"queries_per_s": nq / dt, "query_tile": cb["query_tile"], "passes_per_step": cb["n_passes"],
-                                  "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
-                                  "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                  "traffic": None}
-                try:  # PMC-derived HBM bytes per launch of THIS kernel (profiles/hbm_traffic.json, collected on the 128-query kernel)
-                    tj = json.load(open(args.traffic_json))
-                    if tj.get("n_rows") == hi - lo and tj.get("dim") == dim and tj.get("query_tile", 128) == cb["query_tile"]:
-                        out["tile128"]["traffic"] = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        s_alt, i_alt = ix.search(queries, k)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / args.steps
+                    cb = ix.counters()
+                    out["other_kernels"].append({
+                        "scan_kernel": kern, "what": label, "kernel": scan_kernel_name(cb["query_tile"]),
+                        "queries_per_s": nq / dt, "query_tile": cb["query_tile"], "passes_per_step": cb["n_passes"],
+                        "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
+                        "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "traffic": pmc_traffic(args.traffic_json, scan_kernel_name(cb["query_tile"]), hi - lo, dim),
+                        "same_results_as_headline": bool(torch.equal(torch.as_tensor(s_alt), torch.as_tensor(res[0])) and
+                                                         torch.equal(torch.as_tensor(i_alt), torch.as_tensor(res[1])))})
             except Exception as exc:  # a secondary figure must never cost the headline line
                 out["secondary_error"] = repr(exc)
             finally:
-                _lib.set_option("query_split", 1)
-                _lib.set_option("nontemporal", args.nontemporal if args.nontemporal is not None else 1)
-                _lib.set_option("scan_kernel", 2)
+                _lib.set_option("scan_kernel", 3)
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
         if not args.no_encoder and world == 1:

@@ -27,9 +27,6 @@ struct BhScanArgs {
 // scan_topk.hip
 hipError_t bh_launch_scan(const BhScanArgs& a, int dim_padded, int kp, int qw, int grid, hipStream_t stream);
 bool bh_scan_supports(int dim_padded, int kp, int qw);
-// scan_topk8.hip (8 waves per CU, dimensions split between the two waves of a SIMD; 128-query tiles)
-hipError_t bh_launch_scan8(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
-bool bh_scan8_supports(int dim_padded);
 // scan_topk192.hip (192 queries per pass on v_mfma_f32_16x16x32_f16; d = 768, k <= 56 only)
 hipError_t bh_launch_scan192(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan192_supports(int dim_padded, int kp);

@@ -54,7 +54,7 @@ struct Options {
     int pair_window = 0;
     int dma_interleave = 1;
     // 3 = scan_topk256.hip (8 waves, 256-query tile) where it applies (d in {384, 512, 768}), else scan_topk.hip;
-    // 2 = scan_topk192.hip where it applies (d = 768, k <= 56); 0 = scan_topk.hip (4 waves); 1 = scan_topk8.hip
+    // 2 = scan_topk192.hip where it applies (d = 768, k <= 56); 0 = scan_topk.hip (4 waves, 128-query tile)
     int scan_kernel = 3;
 } g_opt;
 
@@ -214,8 +214,8 @@ int bh_set_option(const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "dma_interleave must be 0 or 1");
         g_opt.dma_interleave = (int)value;
     } else if (s == "scan_kernel") {
-        if (value < 0 || value > 3)
-            return fail(BH_EINVAL, "scan_kernel must be 0 (4 waves), 1 (8 waves, split dims), 2 (192-query tile) or 3 (256-query tile)");
+        if (value != 0 && value != 2 && value != 3)
+            return fail(BH_EINVAL, "scan_kernel must be 0 (128-query tile), 2 (192-query tile) or 3 (256-query tile, two waves per SIMD)");
         g_opt.scan_kernel = (int)value;
     } else if (s == "pair_window") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
@@ -430,8 +430,6 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
             HIP_TRY(bh_launch_scan256(sa, dp, kp, grid, st));
         else if (use192)
             HIP_TRY(bh_launch_scan192(sa, dp, kp, grid, st));
-        else if (g_opt.scan_kernel == 1 && qw == 1 && bh_scan8_supports(dp))
-            HIP_TRY(bh_launch_scan8(sa, dp, kp, grid, st));
         else
             HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
         HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 1), st));

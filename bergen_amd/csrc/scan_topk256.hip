@@ -512,9 +512,14 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
 template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD>
 static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t smem = (size_t)R * 32 * LS * 128;
-    const bool nt = a.nontemporal != 0;
+    constexpr bool kProduction = ABL == 0 && LM == 1 && SCHED == 1 && NBUF == PD;
+    // the bench-only instantiations exist with the non-temporal stream policy only (compile time)
+    const bool nt = a.nontemporal != 0 || !kProduction;
     static bool attr_done[2] = {false, false};
-    auto kern = nt ? bh_scan_topk256_kernel<NK32, KP, LS, R, PD, true, ABL, LM, SCHED, NBUF> : bh_scan_topk256_kernel<NK32, KP, LS, R, PD, false, ABL, LM, SCHED, NBUF>;
+    void (*kern)(BhScanArgs) = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, true, ABL, LM, SCHED, NBUF>;
+    if constexpr (kProduction) {
+        if (!nt) kern = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, false, ABL, LM, SCHED, NBUF>;
+    }
     if (!attr_done[nt ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
@@ -546,34 +551,23 @@ hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int gr
         case 512: return launch256_kp<16, 4, 9, 4>(a, kp, grid, stream);
         case 768:
             if (kp == 64) {
-                // bench-only: ablations and ring geometry / pipeline depth / loader variants of the headline geometry
+                // bench-only: ablations (bit flags, see the kernel) and schedule variants of the headline geometry
                 switch (a.ablate) {
-                    case 1: return launch256_one<24, 64, 6, 6, 4, 1>(a, grid, stream);
-                    case 3: return launch256_one<24, 64, 6, 6, 4, 3>(a, grid, stream);
-                    case 5: return launch256_one<24, 64, 6, 6, 4, 5>(a, grid, stream);
-                    case 7: return launch256_one<24, 64, 6, 6, 4, 7>(a, grid, stream);
-                    case 11: return launch256_one<24, 64, 6, 6, 4, 11>(a, grid, stream);
-                    case 19: return launch256_one<24, 64, 6, 6, 4, 19>(a, grid, stream);
-                    case 27: return launch256_one<24, 64, 6, 6, 4, 27>(a, grid, stream);
-                    case 9: return launch256_one<24, 64, 6, 6, 4, 9>(a, grid, stream);
-                    case 17: return launch256_one<24, 64, 6, 6, 4, 17>(a, grid, stream);
-                    case 32:
-                        return a.ring_variant == 4 ? launch256_one<24, 64, 6, 6, 4, 32, 1, 0>(a, grid, stream)
-                                                   : launch256_one<24, 64, 6, 6, 4, 32>(a, grid, stream);
-                    case 43: return launch256_one<24, 64, 6, 6, 4, 43>(a, grid, stream);
-                    case 35: return launch256_one<24, 64, 6, 6, 4, 35>(a, grid, stream);
-                    case 33: return launch256_one<24, 64, 6, 6, 4, 33>(a, grid, stream);
+                    case 1: return launch256_one<24, 64, 6, 6, 4, 1>(a, grid, stream);    // no filter
+                    case 3: return launch256_one<24, 64, 6, 6, 4, 3>(a, grid, stream);    // no filter, no fragment reads
+                    case 7: return launch256_one<24, 64, 6, 6, 4, 7>(a, grid, stream);    // stream only
+                    case 9: return launch256_one<24, 64, 6, 6, 4, 9>(a, grid, stream);    // no filter, no refill
+                    case 11: return launch256_one<24, 64, 6, 6, 4, 11>(a, grid, stream);  // MFMA + rendezvous only
+                    case 32: return launch256_one<24, 64, 6, 6, 4, 32>(a, grid, stream);  // production + timeline stamps
+                    case 33: return launch256_one<24, 64, 6, 6, 4, 33>(a, grid, stream);  // no filter + timeline stamps
                     case 0: break;
                     default: return hipErrorInvalidValue;
                 }
                 switch (a.ring_variant) {
-                    case 1: return launch256_one<24, 64, 6, 6, 4, 0, 0, 1>(a, grid, stream);  // all waves load
-                    case 2: return launch256_one<24, 64, 6, 6, 4, 0, 2, 1>(a, grid, stream);  // waves 4-7 load, raised priority
-                    case 3: return launch256_one<24, 64, 6, 6, 4, 0, 3, 1>(a, grid, stream);  // waves 0-3 load, no priority
-                    case 4: return launch256_one<24, 64, 6, 6, 4, 0, 1, 0>(a, grid, stream);  // rendezvous at the stage top, refill spread
-                    case 5: return launch256_one<24, 64, 6, 6, 4, 0, 1, 2>(a, grid, stream);  // rendezvous mid-stage, refill spread
-                    case 6: return launch256_one<24, 64, 6, 6, 3, 0, 1, 1, 4>(a, grid, stream);  // prefetch distance 3, four buffers
-                    case 7: return launch256_one<24, 64, 4, 9, 4>(a, grid, stream);
+                    case 1: return launch256_one<24, 64, 6, 6, 4, 0, 0, 1>(a, grid, stream);     // all waves load
+                    case 2: return launch256_one<24, 64, 6, 6, 4, 0, 1, 0>(a, grid, stream);     // rendezvous at the stage top, refill spread
+                    case 3: return launch256_one<24, 64, 6, 6, 3, 0, 1, 1, 4>(a, grid, stream);  // prefetch distance 3, four buffers
+                    case 4: return launch256_one<24, 64, 4, 9, 4>(a, grid, stream);              // 4 lines x 9 stages
                 }
             }
             return launch256_kp<24, 6, 6, 4>(a, kp, grid, stream);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_VERSION 120 /* 0.1.2: + bi-encoder forward pass, sparse (SPLADE) index */
+#define BH_VERSION 130 /* 0.1.3: + 256-query-tile scan (two waves per SIMD), clock / timeline diagnostics */
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -129,8 +129,9 @@ int64_t bh_debug_scan_timeline(const bh_index* ix, uint64_t* out, int64_t max_wo
 /* Tuning knobs (process-wide; bench sweeps and A/B comparisons; results are identical for every valid setting).
  * Dense scan: "query_tile" (128|256), "share_threshold" (0|1), "nontemporal" (0|1), "dma_interleave" (0|1, default 1),
  * "query_split" (1|2: paired workgroups share the corpus stream through L2), "pair_window" (0..64), "scan_kernel"
- * (2 = 192-query tile where it applies [d = 768, k <= 56] else the 4-wave kernel, default; 0 = 4-wave kernel; 1 = 8-wave
- * split-dimension kernel), "ring_variant" (0..4).  Sparse scan: "sparse_kernel"
+ * (3 = 256-query tile, two waves per SIMD, where it applies [d in {384, 512, 768}] else the 4-wave kernel, default;
+ * 2 = 192-query tile where it applies [d = 768, k <= 56]; 0 = 4-wave kernel, 128-query tile), "ring_variant" (0..7:
+ * bench-only variants of the selected kernel).  Sparse scan: "sparse_kernel"
  * (1 = csr_mfma.hip, default; 0 = csr_topk.hip).  Encoder GEMM: "gemm_stagger_phases", "gemm_stagger_pct".
  * "ablate" / "sparse_ablate" switch parts of the kernels OFF for profiling: results are INVALID while they are set. */
 int bh_set_option(const char* name, int64_t value);

@@ -21,21 +21,33 @@ for sub in sorted(os.listdir(prof)):
             for c, vals in cs.items():
                 res.setdefault(k, {})[c] = {"launches": len(vals), "mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals)}
 summary = {"per_kernel": res}
-# the scan kernels of the run (bench.py times the 192-query kernel as the headline and the 128-query kernel as `tile128`);
-# hbm_traffic.json describes the HEADLINE kernel (192-query tile when it ran) and names its query tile
-scan = {k: cs for k, cs in res.items() if "bh_scan_topk" in k and "FETCH_SIZE" in cs}
+# the scan kernels of the run (bench.py times the default kernel as the headline and the earlier ones as `other_kernels`);
+# hbm_traffic.json is keyed by kernel name so that bench.py's roofline.traffic matches whatever kernel roofline.kernel names
+def base_name(k):
+    for name in ("bh_scan_topk256_kernel", "bh_scan_topk192_kernel", "bh_scan_topk_kernel"):
+        if name in k:
+            return name
+    return None
+
+
+scan = {k: cs for k, cs in res.items() if base_name(k) and "FETCH_SIZE" in cs}
+traffic = {}
 for k, cs in scan.items():
     rd = cs["FETCH_SIZE"]["mean"] * 1024 * 2
     wr = cs.get("WRITE_SIZE", {"mean": 0})["mean"] * 1024
-    tile = 192 if "topk192" in k else 128
-    summary.setdefault("scan_hbm_bytes_per_launch", {})[str(tile)] = {
-        "kernel": k, "read_corrected_x2": rd, "write": wr, "total": rd + wr, "fetch_size_raw": cs["FETCH_SIZE"]["mean"]}
-if scan and len(sys.argv) > 4:
-    head = max(scan, key=lambda k: ("topk192" in k, scan[k]["FETCH_SIZE"]["launches"]))
-    h = summary["scan_hbm_bytes_per_launch"]["192" if "topk192" in head else "128"]
-    json.dump({"n_rows": int(sys.argv[3]), "dim": int(sys.argv[4]), "query_tile": 192 if "topk192" in head else 128,
-               "hbm_bytes_per_launch": h["total"], "kernel": head,
+    name = base_name(k)
+    # a run may hold several instantiations of one kernel (ablations): keep the one with the most launches
+    if name in traffic and traffic[name]["launches"] >= cs["FETCH_SIZE"]["launches"]:
+        continue
+    traffic[name] = {"kernel_full": k, "launches": cs["FETCH_SIZE"]["launches"], "read_corrected_x2": rd, "write": wr,
+                     "hbm_bytes_per_launch": rd + wr, "fetch_size_raw": cs["FETCH_SIZE"]["mean"]}
+summary["scan_hbm_bytes_per_launch"] = traffic
+if traffic and len(sys.argv) > 4:
+    for ent in traffic.values():
+        ent["n_rows"] = int(sys.argv[3])
+        ent["dim"] = int(sys.argv[4])
+    json.dump({"kernels": traffic,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read side x2 per MI355X_MICROARCH.md"},
-              open(os.path.join(os.path.dirname(out), "hbm_traffic.json"), "w"))
+              open(os.path.join(os.path.dirname(out), "hbm_traffic.json"), "w"), indent=1)
 json.dump(summary, open(out, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])

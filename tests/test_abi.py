@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(handle, name), f"{name} missing from {_lib.LIB_PATH}"
-    assert _lib.lib().bh_version() == 120
+    assert _lib.lib().bh_version() == 130
 
 
 def test_library_contains_gfx950_code_object():

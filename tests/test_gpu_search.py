@@ -12,7 +12,7 @@ from tests.conftest import gap_tolerance
 pytestmark = pytest.mark.gpu
 
 SPLIT_DEFAULT = 1  # library default of "query_split" (restored after the option tests)
-KERNEL_DEFAULT = 2  # library default of "scan_kernel" (192-query tile where it applies, else the 4-wave kernel)
+KERNEL_DEFAULT = 3  # library default of "scan_kernel" (256-query tile where it applies, else the 4-wave kernel)
 
 
 @pytest.fixture(scope="module")
@@ -224,8 +224,8 @@ def test_device_resident_sources_and_queries(amd):
     ws, wi = c_oracle.canonical_search(q, x, 50, id_offset=1_000_000)
     compare.assert_bit_exact(s.cpu().numpy(), i.cpu().numpy(), ws, wi, "device path")
     c = ix.counters()
-    tile = c["query_tile"]  # 192 (d = 768, k <= 56: scan_topk192.hip) or 128
-    assert c["n_passes"] == 1 and tile in (128, 192) and c["scan_ms"] > 0
+    tile = c["query_tile"]  # 256 (d in {384, 512, 768}: scan_topk256.hip) or 128
+    assert c["n_passes"] == 1 and tile in (128, 256) and c["scan_ms"] > 0
     assert c["algorithmic_bytes"] == 6000 * 768 * 2 + tile * 768 * 2 + tile * 50 * 12
     ix.close()
 
@@ -331,53 +331,13 @@ def test_full_size_properties(amd):
         h.close()
 
 
-@pytest.mark.parametrize("n,d,nq,k", [
-    (33, 100, 129, 50), (1000, 128, 7, 56), (4097, 256, 130, 57), (3000, 384, 40, 120), (2500, 512, 33, 121),
-    (7777, 768, 300, 50), (20000, 768, 64, 50), (9000, 768, 200, 200), (1, 768, 1, 1), (31, 700, 5, 31),
-])
-@pytest.mark.parametrize("split", [1, 2])
-def test_eight_wave_kernel_matches_oracle(amd, n, d, nq, k, split):
-    """scan_kernel = 1 (scan_topk8.hip: dimensions split between the two waves of a SIMD): same bit-exact results."""
-    from bergen_amd import _lib
-    rng = np.random.default_rng(n * 31 + d + 5)
-    x = rng.standard_normal((n, d)).astype(np.float16)
-    q = rng.standard_normal((nq, d)).astype(np.float16)
-    ws, wi = c_oracle.canonical_search(q, x, k)
-    try:
-        _lib.set_option("scan_kernel", 1)
-        _lib.set_option("query_split", split)
-        s, i = _search(amd, x, q, k)
-        compare.assert_bit_exact(s, i, ws, wi, f"8-wave n={n} d={d} nq={nq} k={k} split={split}")
-    finally:
-        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
-        _lib.set_option("query_split", SPLIT_DEFAULT)
-
-
-def test_eight_wave_kernel_ties_and_options(amd):
-    from bergen_amd import _lib
-    rng = np.random.default_rng(77)
-    x = rng.integers(-2, 3, size=(5000, 768)).astype(np.float16)  # heavy exact ties
-    q = rng.integers(-2, 3, size=(70, 768)).astype(np.float16)
-    ws, wi = c_oracle.canonical_search(q, x, 50)
-    try:
-        _lib.set_option("scan_kernel", 1)
-        for share in (0, 1):
-            for nt in (0, 1):
-                _lib.set_option("share_threshold", share)
-                _lib.set_option("nontemporal", nt)
-                s, i = _search(amd, x, q, 50)
-                compare.assert_bit_exact(s, i, ws, wi, f"8-wave ties share={share} nt={nt}")
-    finally:
-        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
-        _lib.set_option("share_threshold", 1)
-        _lib.set_option("nontemporal", 1)
-
-
-@pytest.mark.parametrize("kern", [0, 2])
-@pytest.mark.parametrize("n,nq,k", [(33, 1, 5), (9001, 191, 50), (9001, 192, 50), (9001, 193, 50), (70001, 400, 50), (12345, 600, 56)])
+@pytest.mark.parametrize("kern", [0, 2, 3])
+@pytest.mark.parametrize("n,nq,k", [(33, 1, 5), (9001, 191, 50), (9001, 192, 50), (9001, 193, 50), (70001, 400, 50), (12345, 600, 56),
+                                    (9001, 255, 50), (9001, 256, 50), (9001, 257, 50)])
 def test_query_tile_kernels_match_oracle(amd, kern, n, nq, k):
-    """scan_kernel 0 (128-query tile, 32x32x16 MFMA) and 2 (192-query tile, 16x16x32 MFMA) at d = 768: same bit-exact
-    results, including the pass boundaries of the 192-query tile."""
+    """scan_kernel 0 (128-query tile, 32x32x16 MFMA, one wave per SIMD), 2 (192-query tile, 16x16x32 MFMA, one wave per SIMD)
+    and 3 (256-query tile, 16x16x32 MFMA, two waves per SIMD) at d = 768: same bit-exact results, including the pass
+    boundaries of the 192- and 256-query tiles."""
     from bergen_amd import _lib
     rng = np.random.default_rng(n + nq)
     x = rng.standard_normal((n, 768)).astype(np.float16)
@@ -391,10 +351,30 @@ def test_query_tile_kernels_match_oracle(amd, kern, n, nq, k):
         s, i = ix.search(q, k)
         tile = ix.counters()["query_tile"]
         ix.close()
-        assert tile == (192 if kern == 2 else 128)
+        assert tile == {0: 128, 2: 192, 3: 256}[kern]
         compare.assert_bit_exact(s, i, ws, wi, f"kernel {kern} n={n} nq={nq} k={k}")
     finally:
         _lib.set_option("scan_kernel", KERNEL_DEFAULT)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(30001, 384, 300, 50), (30001, 512, 300, 50), (30001, 500, 100, 120), (40001, 768, 300, 100),
+                                      (40001, 768, 260, 200), (20001, 384, 257, 248), (300001, 768, 64, 50)])
+def test_tile256_kernel_dims_and_list_lengths(amd, n, d, nq, k):
+    """The 256-query kernel (default) at every dim it serves (384 / 512 / 768) and every candidate-list length (64 / 128 / 256),
+    against the 4-wave kernel, whose results the oracle tests above pin."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(n + d + k)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    s, i = ix.search(q, k)
+    tile = ix.counters()["query_tile"]
+    ix.close()
+    assert tile == 256
+    compare.assert_bit_exact(s, i, ws, wi, f"256-query kernel n={n} d={d} nq={nq} k={k}")
 
 
 def test_tile192_kernel_exact_ties(amd):
@@ -404,9 +384,11 @@ def test_tile192_kernel_exact_ties(amd):
     q = rng.integers(-2, 3, size=(70, 768)).astype(np.float16)
     ws, wi = c_oracle.canonical_search(q, x, 50)
     try:
-        for kern in (2, 0):
-            _lib.set_option("scan_kernel", kern)
-            s, i = _search(amd, x, q, 50)
-            compare.assert_bit_exact(s, i, ws, wi, f"ties, kernel {kern}")
+        for kern in (3, 2, 0):
+            for share in (0, 1):
+                _lib.set_option("scan_kernel", kern)
+                _lib.set_option("share_threshold", share)
+                s, i = _search(amd, x, q, 50)
+                compare.assert_bit_exact(s, i, ws, wi, f"ties, kernel {kern}, share {share}")
     finally:
         _lib.set_option("scan_kernel", KERNEL_DEFAULT)

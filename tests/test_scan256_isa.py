@@ -1,0 +1,131 @@
+"""CPU: instruction-level checks of the 256-query scan kernel's generated code (cross-compiled for gfx950, no GPU needed).
+
+scan_topk256.hip issues its LDS fragment reads as inline asm and tracks their completion by hand (`s_waitcnt lgkmcnt(n)`);
+the compiler does not know that the destination registers are still in flight.  These tests read the ISA hipcc produced
+and check what the source can only promise:
+  * no instruction touches the destination of a fragment read before the wait that covers it (a register copy or spill
+    inserted by the register allocator in that window would move stale bytes);
+  * the tile loop of every production instantiation is free of scratch traffic (a reload in there also drains the whole
+    LDS-DMA pipeline through vmcnt) and holds exactly the expected number of MFMAs;
+  * the wait states between the last MFMAs and the first VALU read of their results are still in front of that read."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "bergen_amd", "csrc", "scan_topk256.hip")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+RESOURCE_LOG = ""
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "scan256.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", str(out),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=os.path.dirname(SRC))
+    assert r.returncode == 0, r.stderr[-2000:]
+    global RESOURCE_LOG
+    RESOURCE_LOG = r.stderr
+    res, name, body = {}, None, []
+    for line in open(out):
+        m = re.match(r"^(_Z22bh_scan_topk256_kernel\S+):", line)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name is not None:
+            body.append(line.rstrip("\n"))
+            if "s_endpgm" in line:
+                res[name] = body
+                name = None
+    assert res
+    return res
+
+
+def _regs(txt):
+    u = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", txt):
+        u.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", txt):
+        u.add(int(m.group(1)))
+    return u
+
+
+def _code(lines):
+    for i, l in enumerate(lines):
+        c = l.split(";")[0].strip()
+        if c and not c.startswith(".") and not c.endswith(":"):
+            yield i, c
+
+
+def production(name):
+    # template arguments: NK32, KP, LS, R, PD, NT, ABL, LM, SCHED, NBUF; production = ABL 0, LM 1, SCHED 1
+    m = re.search(r"kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+    assert m, name
+    nk32, kp, ls, r, pd, nt, abl, lm, sched, nbuf = (int(x) for x in m.groups())
+    return abl == 0 and lm == 1 and sched == 1, nk32, kp, ls
+
+
+def test_no_instruction_touches_a_fragment_register_in_flight(kernels):
+    for name, lines in kernels.items():
+        pending = []  # (line, destination registers) of LDS operations not yet covered by a wait, oldest first
+        for i, c in _code(lines):
+            m = re.match(r"s_waitcnt.*lgkmcnt\((\d+)\)", c)
+            if m:
+                del pending[:max(0, len(pending) - int(m.group(1)))]
+                continue
+            if c.startswith("s_waitcnt"):
+                continue
+            if c.startswith("ds_read_b128"):
+                pending.append((i, _regs(c.split(",")[0])))
+                continue
+            if c.startswith("ds_"):
+                pending.append((i, set()))
+                continue
+            used = _regs(c)
+            for j, dest in pending:
+                assert not (used & dest), f"{name}: line {i + 1} `{c}` touches the destination of the LDS read at line {j + 1}"
+
+
+def test_tile_loop_of_the_production_kernels(kernels):
+    seen = 0
+    for name, lines in kernels.items():
+        prod, nk32, kp, ls = production(name)
+        if not prod:
+            continue
+        seen += 1
+        start = next(i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l)
+        # the hot part of the tile loop ends at the wait states in front of the filter
+        end = next(i for i in range(start, len(lines)) if re.search(r"\bs_nop 15\b", lines[i]))
+        hot = [c for i, c in _code(lines[start:end])]
+        assert not any("scratch_" in c for c in hot), f"{name}: scratch traffic inside the tile loop"
+        n_mfma = sum(1 for c in hot if c.startswith("v_mfma_f32_16x16x32_f16"))
+        assert n_mfma == 4 * nk32, f"{name}: {n_mfma} MFMAs per tile, expected {4 * nk32}"   # 2 row blocks x 2 query blocks x k-steps
+        n_read = sum(1 for c in hot if c.startswith("ds_read_b128"))
+        assert n_read == 2 * nk32, f"{name}: {n_read} fragment reads per tile"
+        # the wait states must precede the first VALU instruction that reads an accumulator
+        tail = [c for i, c in _code(lines[end:end + 12])]
+        assert tail[0].startswith("s_nop 15") and tail[1].startswith("s_nop 7"), f"{name}: {tail[:3]}"
+        assert not any(c.startswith("v_") for c in hot[-2:] if not c.startswith("v_mfma")), name
+    assert seen >= 6  # dims 384 / 512 / 768 x candidate lists 64 / 128 / 256 x nt / default policy
+
+
+def test_headline_kernel_uses_the_whole_register_file_without_scratch(kernels):
+    cur, usage = None, {}
+    for line in RESOURCE_LOG.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            usage[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            usage[cur][m.group(1).strip()] = int(m.group(2))
+    head = [u for n, u in usage.items() if re.search(r"kernelILi24ELi64ELi6ELi6ELi4ELb[01]ELi0ELi1ELi1ELi4E", n)]
+    assert len(head) == 2
+    for u in head:
+        assert u["ScratchSize"] == 0 and u["Occupancy"] == 2 and u["VGPRs"] <= 128 and u["AGPRs"] <= 128, u
