@@ -54,6 +54,8 @@ class bh_encoder_config(ctypes.Structure):
         ("type_vocab_size", ctypes.c_int32),
         ("activation", ctypes.c_int32),
         ("ln_eps", ctypes.c_float),
+        ("head_dim", ctypes.c_int32),
+        ("position_offset", ctypes.c_int32),
     ]
 
 

@@ -9,6 +9,7 @@ Reference `_target_` paths (``models.retrievers.dense.*``) are mapped onto this 
 BERGEN retriever yaml instantiates the MI355X-native classes unchanged.
 """
 import importlib
+from collections.abc import Mapping
 
 # reference target -> native target
 TARGET_ALIASES = {
@@ -45,6 +46,8 @@ def instantiate(cfg, **overrides):
                 cfg = OmegaConf.to_container(cfg, resolve=True)
         except Exception:
             pass
+    if not isinstance(cfg, dict) and isinstance(cfg, Mapping):
+        cfg = dict(cfg)  # any other read-only mapping (a DictConfig without omegaconf importable, a MappingProxy ...)
     if not isinstance(cfg, dict):
         return cfg
     if "_target_" not in cfg:

@@ -83,8 +83,9 @@ namespace {
 int build_slots(bh_encoder* e) {
     const bh_encoder_config& c = e->cfg;
     const size_t d = c.hidden, dff = c.intermediate;
+    const size_t da = (size_t)c.n_heads * 64;  // attention width: heads padded to 64 dims (= d for 64-dim heads)
     size_t total = (size_t)c.vocab_size * d + (size_t)c.max_position * d + (size_t)c.type_vocab_size * d + 2 * d;
-    const size_t per_layer = 2 * d * d + 2 * d + d * d + d + d * d + d + 2 * d + dff * d + dff + d * dff + d + 2 * d;
+    const size_t per_layer = 2 * da * d + 2 * da + da * d + da + d * da + d + 2 * d + dff * d + dff + d * dff + d + 2 * d;
     total += per_layer * c.n_layers;
     total += 64;
     BH_HIP_TRY(hipMalloc((void**)&e->arena, total * sizeof(_Float16)));
@@ -110,11 +111,11 @@ int build_slots(bh_encoder* e) {
     e->layers.resize(c.n_layers);
     for (int l = 0; l < c.n_layers; ++l) {
         Layer& L = e->layers[l];
-        L.wqk = take(2 * d * d);
-        L.bqk = take(2 * d);
-        L.wv = take(d * d);
-        L.bv = take(d);
-        L.wo = take(d * d);
+        L.wqk = take(2 * da * d);
+        L.bqk = take(2 * da);
+        L.wv = take(da * d);
+        L.bv = take(da);
+        L.wo = take(d * da);
         L.bo = take(d);
         L.ln1g = take(d);
         L.ln1b = take(d);
@@ -125,13 +126,13 @@ int build_slots(bh_encoder* e) {
         L.ln2g = take(d);
         L.ln2b = take(d);
         const std::string pre = "encoder.layer." + std::to_string(l) + ".";
-        S[pre + "attention.self.query.weight"] = {L.wqk, (int64_t)(d * d)};
-        S[pre + "attention.self.key.weight"] = {L.wqk + d * d, (int64_t)(d * d)};
-        S[pre + "attention.self.query.bias"] = {L.bqk, (int64_t)d};
-        S[pre + "attention.self.key.bias"] = {L.bqk + d, (int64_t)d};
-        S[pre + "attention.self.value.weight"] = {L.wv, (int64_t)(d * d)};
-        S[pre + "attention.self.value.bias"] = {L.bv, (int64_t)d};
-        S[pre + "attention.output.dense.weight"] = {L.wo, (int64_t)(d * d)};
+        S[pre + "attention.self.query.weight"] = {L.wqk, (int64_t)(da * d)};
+        S[pre + "attention.self.key.weight"] = {L.wqk + da * d, (int64_t)(da * d)};
+        S[pre + "attention.self.query.bias"] = {L.bqk, (int64_t)da};
+        S[pre + "attention.self.key.bias"] = {L.bqk + da, (int64_t)da};
+        S[pre + "attention.self.value.weight"] = {L.wv, (int64_t)(da * d)};
+        S[pre + "attention.self.value.bias"] = {L.bv, (int64_t)da};
+        S[pre + "attention.output.dense.weight"] = {L.wo, (int64_t)(d * da)};
         S[pre + "attention.output.dense.bias"] = {L.bo, (int64_t)d};
         S[pre + "attention.output.LayerNorm.weight"] = {L.ln1g, (int64_t)d};
         S[pre + "attention.output.LayerNorm.bias"] = {L.ln1b, (int64_t)d};
@@ -230,9 +231,11 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
     if (c.n_layers <= 0 || c.hidden <= 0 || c.n_heads <= 0 || c.intermediate <= 0 || c.vocab_size <= 0 ||
         c.max_position <= 0 || c.type_vocab_size <= 0)
         return bh_fail(BH_EINVAL, "encoder config has non-positive fields");
-    if (c.hidden % 64 != 0 || c.hidden > 2048 || c.hidden != c.n_heads * 64)
-        return bh_fail(BH_EUNSUPPORTED, "hidden=%d heads=%d unsupported: head dim must be 64, hidden <= 2048", c.hidden,
-                       c.n_heads);
+    const int hd = c.head_dim == 0 ? 64 : c.head_dim;
+    if (c.hidden % 64 != 0 || c.hidden > 2048 || hd < 8 || hd > 64 || hd % 8 != 0 || c.hidden != c.n_heads * hd || c.n_heads * 64 > 2048)
+        return bh_fail(BH_EUNSUPPORTED, "hidden=%d heads=%d head_dim=%d unsupported: hidden = heads * head_dim, a multiple of 64, "
+                       "head_dim 8..64, heads * 64 <= 2048", c.hidden, c.n_heads, hd);
+    if (c.position_offset < 0 || c.position_offset >= c.max_position) return bh_fail(BH_EINVAL, "position_offset %d", c.position_offset);
     if (c.intermediate % 64 != 0) return bh_fail(BH_EUNSUPPORTED, "intermediate=%d must be a multiple of 64", c.intermediate);
     if (c.activation != 0) return bh_fail(BH_EUNSUPPORTED, "activation %d unsupported (0 = erf-GELU)", c.activation);
     int dev = 0;
@@ -397,9 +400,11 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if (batch == 0) return BH_OK;
     if (!input_ids || !out) return bh_fail(BH_EINVAL, "null buffer");
     const bh_encoder_config& c = e->cfg;
-    if (seq_len > c.max_position) return bh_fail(BH_EINVAL, "seq_len %d exceeds max_position %d", seq_len, c.max_position);
+    if (seq_len + c.position_offset > c.max_position)
+        return bh_fail(BH_EINVAL, "seq_len %d exceeds max_position %d", seq_len, c.max_position - c.position_offset);
     if (batch > 65535) return bh_fail(BH_EUNSUPPORTED, "batch %d too large (max 65535)", batch);
     const int d = c.hidden, dff = c.intermediate;
+    const int da = c.n_heads * 64;  // attention width (heads padded to 64 dims)
 
     // ---- packing plan (host)
     std::vector<long long> off(batch);
@@ -461,7 +466,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             const long long ty = token_type_ids ? token_type_ids[i] : 0;
             if (ty < 0 || ty >= c.type_vocab_size) return bh_fail(BH_EINVAL, "token type %lld out of range", ty);
             tok[r] = (int)id;
-            pos[r] = t;
+            pos[r] = t + c.position_offset;
             typ[r] = (int)ty;
             ++r;
         }
@@ -473,9 +478,9 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     const size_t M = (size_t)m_pad;
     if ((rc = e->X.ensure(M * d))) return rc;
     if ((rc = e->Y.ensure(M * d))) return rc;
-    if ((rc = e->QK.ensure(M * 2 * d))) return rc;
-    if ((rc = e->VT.ensure(M * d))) return rc;
-    if ((rc = e->CTX.ensure(M * d, /*zero_new=*/true, st))) return rc;  // rows between sequences are never written
+    if ((rc = e->QK.ensure(M * 2 * da))) return rc;
+    if ((rc = e->VT.ensure(M * da))) return rc;
+    if ((rc = e->CTX.ensure(M * da, /*zero_new=*/true, st))) return rc;  // rows between sequences are never written
     if ((rc = e->H.ensure(M * dff))) return rc;
     if ((rc = e->ibuf.ensure(ib.size()))) return rc;
     if ((rc = e->seq_off.ensure(batch))) return rc;
@@ -513,28 +518,28 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     BH_HIP_TRY(bh_launch_embed_ln(ea, st));
 
     // the blocked V^T layout is written by the persistent GEMM only (256-row tiles of the weight operand)
-    const bool vt_blocked = (d % 256 == 0) && (e->gemm_variant == 0 || (e->gemm_variant >= 7 && e->gemm_variant <= 9));
+    const bool vt_blocked = (da % 256 == 0) && (e->gemm_variant == 0 || (e->gemm_variant >= 7 && e->gemm_variant <= 9));
     for (int l = 0; l < c.n_layers; ++l) {
         const Layer& L = e->layers[l];
         // Q | K projections: QK[m][2d] = X Wqk^T + bqk
-        if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * d, m_pad, 2 * d, d, L.bqk, 1, nullptr, 0, 0))) return rc;
-        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][d][64] = Wv X^T + bv (bias per row)
-        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, d, m_pad, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? d : 0)))
+        if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * da, m_pad, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
+        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][da][64] = Wv X^T + bv (bias per row)
+        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, da, m_pad, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0)))
             return rc;
         BhAttnArgs aa{};
         aa.qk = e->QK.p;
-        aa.ldqk = 2 * d;
+        aa.ldqk = 2 * da;
         aa.vt = e->VT.p;
         aa.ldvt = m_pad;
         aa.vt_blocked = vt_blocked ? 1 : 0;
         aa.ctx = e->CTX.p;
-        aa.ldc = d;
+        aa.ldc = da;
         aa.seq_off = e->seq_off.p;
         aa.seq_len = d_len;
-        aa.d_model = d;
+        aa.d_model = da;
         BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short));
         // attention output projection, then LayerNorm(projection + layer input)
-        if ((rc = gemm(e, e->CTX.p, d, L.wo, d, e->Y.p, d, m_pad, d, d, L.bo, 1, nullptr, 0, 0))) return rc;
+        if ((rc = gemm(e, e->CTX.p, da, L.wo, da, e->Y.p, d, m_pad, d, da, L.bo, 1, nullptr, 0, 0))) return rc;
         BhLnArgs la{};
         la.in = e->Y.p;
         la.residual = e->X.p;  // X <- LayerNorm(Y + X)

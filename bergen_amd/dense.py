@@ -14,10 +14,20 @@ range-partitions the dataset, one process per GPU, weights loaded once per proce
 `similarity_fn` exists for API compatibility (it materialises the [Bq, n] matrix the fused
 search kernel avoids); `bergen_amd.retrieve.Retrieve` never calls it.
 """
+import logging
 import os
 from abc import ABC, abstractmethod
 
 import torch
+
+log = logging.getLogger("bergen_amd")
+_warned = set()
+
+
+def encoder_backend(model):
+    """'hip' when `model` is the hand-written gfx950 forward pass, 'hf' when it is a torch / transformers module."""
+    from .encoder import BertEncoder
+    return "hip" if isinstance(model, BertEncoder) else "hf"
 
 
 def _native_encoder(model):
@@ -25,15 +35,26 @@ def _native_encoder(model):
 
     On a GPU box every BERT-architecture checkpoint (all dense retrievers of the reference's
     config/retriever/*.yaml except repllama) runs on bergen_amd.BertEncoder; BERGEN_AMD_ENCODER=hf keeps the
-    HF torch module (debugging / A-B comparison).  Other architectures stay on their HF implementation.
+    HF torch module (debugging / A-B comparison).  Other architectures stay on their HF implementation — never
+    silently: the reason is logged once per cause (logger "bergen_amd", WARNING) and the plug-ins expose the
+    outcome as `.backend` ('hip' | 'hf').
     """
     from .encoder import BertEncoder
-    if isinstance(model, BertEncoder) or not torch.cuda.is_available():
+    if isinstance(model, BertEncoder):
         return model
-    if os.environ.get("BERGEN_AMD_ENCODER", "hip") == "hf":
-        return model
-    if BertEncoder.supports(model):
+    why = None
+    if not torch.cuda.is_available():
+        why = "no GPU visible"
+    elif os.environ.get("BERGEN_AMD_ENCODER", "hip") == "hf":
+        why = "BERGEN_AMD_ENCODER=hf"
+    else:
+        why = BertEncoder.unsupported_reason(model)
+    if why is None:
         return BertEncoder.from_hf(model, device=torch.cuda.current_device())
+    name = getattr(getattr(model, "config", None), "_name_or_path", None) or type(model).__name__
+    if (name, why) not in _warned:
+        _warned.add((name, why))
+        log.warning("bergen_amd: encoder %s stays on the HF torch implementation (%s); the HIP forward pass is NOT in use", name, why)
     return model
 
 
@@ -133,16 +154,22 @@ class Dense(Retriever):
         self.prompt_q = prompt_q or ""
         self.prompt_d = prompt_d or ""
 
+    @property
+    def backend(self):
+        """'hip' when the document encoder runs on the hand-written kernels, 'hf' when it stayed on torch."""
+        return encoder_backend(self.model)
+
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
         encoder = self.model if query_or_doc == "doc" else self.query_encoder
         # fused path: the native encoder takes the HOST BatchEncoding straight through the C ABI, pools on the
         # device and returns the [B, d] embedding (reference dense.py:38-46 in one call)
         if hasattr(encoder, "encode_pooled"):
-            try:
+            from .encoder import pool_mode_or_none
+            if pool_mode_or_none(self.pooler) is not None:
+                # (errors of the forward pass itself — sequence too long, token id out of range, empty mask — propagate)
                 return {"embedding": encoder.encode_pooled(kwargs, self.pooler)}
-            except ValueError:
-                pass  # a pooler the kernels do not know: pool the hidden states in torch below
+            # a pooler the kernels do not know: pool the hidden states in torch below
         on_device = {name: t.to(self.device) for name, t in kwargs.items()}
         hidden = encoder(**on_device)[0]
         return {"embedding": self.pooler.pool(hidden, on_device["attention_mask"])}

@@ -36,17 +36,132 @@ def _pool_mode(pooler):
     raise ValueError(f"no fused pooling for {pooler!r}; use encoder(**kwargs)[0] and pool in torch")
 
 
-class BertEncoder:
-    def __init__(self, config, state_dict, device=0):
-        """config: HF BertConfig (or any object / dict with the same field names)."""
-        get = (lambda k, dflt=None: config.get(k, dflt)) if isinstance(config, dict) else \
-            (lambda k, dflt=None: getattr(config, k, dflt))
-        act = get("hidden_act", "gelu")
-        if act != "gelu":
-            raise ValueError(f"hidden_act={act!r} unsupported (erf-GELU only)")
+def pool_mode_or_none(pooler):
+    """The fused pooling mode of `pooler`, or None when the kernels have none for it."""
+    try:
+        return _pool_mode(pooler)
+    except (ValueError, KeyError):
+        return None
+
+
+SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert")
+
+# DistilBERT names -> BERT names (same post-LN block, no token types, no pooler)
+_DISTIL = (("embeddings.word_embeddings.", "embeddings.word_embeddings."),
+           ("embeddings.position_embeddings.", "embeddings.position_embeddings."),
+           ("embeddings.LayerNorm.", "embeddings.LayerNorm."),
+           (".attention.q_lin.", ".attention.self.query."), (".attention.k_lin.", ".attention.self.key."),
+           (".attention.v_lin.", ".attention.self.value."), (".attention.out_lin.", ".attention.output.dense."),
+           (".sa_layer_norm.", ".attention.output.LayerNorm."), (".ffn.lin1.", ".intermediate.dense."),
+           (".ffn.lin2.", ".output.dense."), (".output_layer_norm.", ".output.LayerNorm."))
+
+
+def _cfg_get(config):
+    return (lambda k, dflt=None: config.get(k, dflt)) if isinstance(config, dict) else \
+        (lambda k, dflt=None: getattr(config, k, dflt))
+
+
+def canonical_config(config):
+    """HF config of a BERT-family model -> the fields the kernels need, under BERT's names.  Raises ValueError with the
+    reason when the architecture is outside what the HIP forward pass computes."""
+    get = _cfg_get(config)
+    mt = get("model_type", "bert") or "bert"
+    if mt not in SUPPORTED_MODEL_TYPES:
+        raise ValueError(f"model_type {mt!r} (BERT / DistilBERT / RoBERTa-family encoders only)")
+    if mt == "distilbert":
+        c = dict(hidden_size=get("dim"), num_attention_heads=get("n_heads"), num_hidden_layers=get("n_layers"),
+                 intermediate_size=get("hidden_dim"), hidden_act=get("activation", "gelu"), type_vocab_size=1,
+                 layer_norm_eps=1e-12, position_offset=0)
+        if get("sinusoidal_pos_embds", False) not in (False, None):
+            pass  # (the sinusoids are stored in the position table like learned ones)
+    else:
+        c = dict(hidden_size=get("hidden_size"), num_attention_heads=get("num_attention_heads"),
+                 num_hidden_layers=get("num_hidden_layers"), intermediate_size=get("intermediate_size"),
+                 hidden_act=get("hidden_act", "gelu"), type_vocab_size=get("type_vocab_size", 2),
+                 layer_norm_eps=get("layer_norm_eps", 1e-12),
+                 # RoBERTa numbers positions from padding_idx + 1 (modeling_roberta.create_position_ids_from_input_ids)
+                 position_offset=0 if mt == "bert" else int(get("pad_token_id", 1)) + 1)
         pet = get("position_embedding_type", "absolute")
         if pet not in (None, "absolute"):
-            raise ValueError(f"position_embedding_type={pet!r} unsupported")
+            raise ValueError(f"position_embedding_type {pet!r}")
+    c.update(vocab_size=get("vocab_size"), max_position_embeddings=get("max_position_embeddings"), model_type=mt)
+    if c["hidden_act"] != "gelu":
+        raise ValueError(f"hidden_act {c['hidden_act']!r} (erf-GELU only)")
+    d, nh = int(c["hidden_size"]), int(c["num_attention_heads"])
+    hd = d // max(1, nh)
+    if d != nh * hd or hd % 8 != 0 or not 8 <= hd <= 64:
+        raise ValueError(f"head dim {d / max(1, nh):g} (multiples of 8 up to 64)")
+    if d % 64 != 0 or d > 2048 or nh * 64 > 2048:
+        raise ValueError(f"hidden_size {d} with {nh} heads (multiple of 64, heads * 64 <= 2048)")
+    c["head_dim"] = hd
+    return c
+
+
+def canonical_state_dict(cfg, state_dict):
+    """Rename a BERT-family state dict to BertModel's names, drop what the forward pass does not use, pad heads
+    narrower than 64 dims (see bh_encoder_config.head_dim).  Returns {name: tensor}."""
+    mt, d, nh, hd = cfg["model_type"], int(cfg["hidden_size"]), int(cfg["num_attention_heads"]), int(cfg["head_dim"])
+    out = {}
+    for name, t in state_dict.items():
+        key = name
+        for pre in ("bert.", "distilbert.", "roberta.", "model."):
+            if key.startswith(pre):
+                key = key[len(pre):]
+        if key.endswith("position_ids") or key.endswith("token_type_ids"):
+            continue
+        if mt == "distilbert":
+            if key.startswith("transformer.layer."):
+                key = "encoder.layer." + key[len("transformer.layer."):]
+            for a, b in _DISTIL:
+                if a in key:
+                    key = key.replace(a, b)
+                    break
+            if key.startswith(("vocab_transform.", "vocab_layer_norm.", "vocab_projector.", "pre_classifier.")):
+                continue  # DistilBERT task heads: not used by the reference's retrievers
+        elif mt != "bert":
+            # RobertaClassificationHead = dense + tanh + out_proj on the <s> token: BertPooler + classifier by another name
+            if key.startswith("classifier.dense."):
+                key = "pooler.dense." + key[len("classifier.dense."):]
+            elif key.startswith("classifier.out_proj."):
+                key = "classifier." + key[len("classifier.out_proj."):]
+            elif key.startswith("lm_head."):
+                continue
+        out[key] = t
+    if mt == "distilbert" or "embeddings.token_type_embeddings.weight" not in out:
+        out["embeddings.token_type_embeddings.weight"] = torch.zeros(int(cfg["type_vocab_size"]), d, dtype=torch.float16)
+    if hd != 64:
+        scale = (64.0 / hd) ** 0.5
+        for key in list(out):
+            t = out[key]
+            if ".attention.self." in key and key.endswith(".weight"):      # [nh*hd, d] -> [nh*64, d]
+                w = t.detach().float().reshape(nh, hd, d)
+                if ".query." in key:
+                    w = w * scale
+                p = torch.zeros(nh, 64, d)
+                p[:, :hd] = w
+                out[key] = p.reshape(nh * 64, d)
+            elif ".attention.self." in key and key.endswith(".bias"):      # [nh*hd] -> [nh*64]
+                bvec = t.detach().float().reshape(nh, hd)
+                if ".query." in key:
+                    bvec = bvec * scale
+                p = torch.zeros(nh, 64)
+                p[:, :hd] = bvec
+                out[key] = p.reshape(nh * 64)
+            elif key.endswith("attention.output.dense.weight"):            # [d, nh*hd] -> [d, nh*64]
+                w = t.detach().float().reshape(d, nh, hd)
+                p = torch.zeros(d, nh, 64)
+                p[:, :, :hd] = w
+                out[key] = p.reshape(d, nh * 64)
+    return out
+
+
+class BertEncoder:
+    def __init__(self, config, state_dict, device=0):
+        """config: HF config of a BERT-family encoder (BertConfig, DistilBertConfig, RobertaConfig / XLMRobertaConfig; or a
+        dict with the same field names); state_dict: the matching HF state dict (task-model prefixes tolerated)."""
+        canon = canonical_config(config)
+        state_dict = canonical_state_dict(canon, state_dict)
+        get = canon.get
         self._h = None
         _lib.init(device)
         self.device_index = device
@@ -58,7 +173,8 @@ class BertEncoder:
             n_layers=int(get("num_hidden_layers")), hidden=self.hidden_size, n_heads=int(get("num_attention_heads")),
             intermediate=int(get("intermediate_size")), vocab_size=int(get("vocab_size")),
             max_position=int(get("max_position_embeddings")), type_vocab_size=int(get("type_vocab_size")),
-            activation=0, ln_eps=float(get("layer_norm_eps", 1e-12)))
+            activation=0, ln_eps=float(get("layer_norm_eps", 1e-12)), head_dim=int(get("head_dim")),
+            position_offset=int(get("position_offset", 0)))
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))
         self._h = h
@@ -110,12 +226,20 @@ class BertEncoder:
         return cls(model.config, model.state_dict(), device=device)
 
     @staticmethod
-    def supports(model):
+    def unsupported_reason(model):
+        """None when the HIP forward pass covers this HF model's architecture, else a short reason."""
         cfg = getattr(model, "config", None)
-        return (cfg is not None and getattr(cfg, "model_type", None) == "bert"
-                and getattr(cfg, "hidden_act", "gelu") == "gelu"
-                and getattr(cfg, "position_embedding_type", "absolute") in (None, "absolute")
-                and cfg.hidden_size == cfg.num_attention_heads * 64 and cfg.hidden_size <= 2048)
+        if cfg is None:
+            return "no .config"
+        try:
+            canonical_config(cfg)
+        except (ValueError, TypeError) as exc:
+            return str(exc)
+        return None
+
+    @staticmethod
+    def supports(model):
+        return BertEncoder.unsupported_reason(model) is None
 
     # -- nn.Module-like surface used by Retrieve / Dense -------------------------------------------
     def to(self, *args, **kwargs):

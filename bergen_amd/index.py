@@ -58,6 +58,8 @@ def _prepare(x):
 class FlatIndex:
     """n_rows x dim fp16 index resident on one MI355X.  metric: 'ip' | 'cos'."""
 
+    MAX_K = 248  # candidate lists of 64 / 128 / 256 entries with a margin of 8 (csrc/index.hip: pick_kp)
+
     def __init__(self, n_rows, dim, metric="ip", device=0):
         self._h = None
         _lib.init(device)

@@ -54,6 +54,12 @@ class CrossEncoder(Reranker):
         if hasattr(self.model, "eval"):
             self.model.eval()
 
+    @property
+    def backend(self):
+        """'hip' when the model runs on the hand-written kernels, 'hf' when it stayed on torch (a warning was logged)."""
+        from .dense import encoder_backend
+        return encoder_backend(self.model)
+
     def collate_fn(self, examples, query_or_doc=None):
         question = [e['query'] for e in examples]
         doc = [e['doc'] for e in examples]

@@ -76,18 +76,27 @@ class Retrieve:
         self.pyserini_num_threads = pyserini_num_threads
         self.device = device
         self.num_workers = num_workers
-        # instantiate model (reference: hydra instantiate, retrieve.py:34); an already-built
-        # plug-in object is accepted as well
-        self.model = instantiate(init_args) if isinstance(init_args, dict) or init_args is None else init_args
+        # instantiate model (reference: hydra instantiate, retrieve.py:34).  rag.py hands over an OmegaConf DictConfig;
+        # config.instantiate converts that (and any other mapping) and passes an already-built plug-in object through
+        self.model = instantiate(init_args)
         self._resident = {}  # doc_embeds_path -> (FlatIndex, signature)
 
     # ------------------------------------------------------------------ indexing (encode)
     def index(self, dataset, index_path, query_or_doc, overwrite_index=False):
         """Encode `dataset[query_or_doc]` into `index_path` unless the folder already exists (cache by existence;
         `continue_batch` and `overwrite_index` force the encode) — reference retrieve.py:37-50."""
-        have = os.path.exists(index_path)
-        if have and self.continue_batch is None and not overwrite_index:
-            return
+        if self.encode_world > 1:
+            # Several processes fill ONE folder: its existence says nothing about this rank's range (the first rank to
+            # get here creates it).  This rank is done when the chunk file named after ITS last batch exists.
+            n_batches = (len(dataset[query_or_doc]) + self.batch_size - 1) // self.batch_size
+            b_lo, b_hi = self._batch_range(n_batches)
+            mine_done = b_hi <= b_lo or os.path.exists(self.get_chunk_path(index_path, b_hi - 1))
+            if mine_done and self.continue_batch is None and not overwrite_index:
+                return
+        else:
+            have = os.path.exists(index_path)
+            if have and self.continue_batch is None and not overwrite_index:
+                return
         if self.model.model_name in ('bm25', 'oracle_provenance'):
             raise NotImplementedError(f"{self.model.model_name} is out of scope of the dense backend (SURVEY §2)")
         self._resident.pop(index_path, None)
@@ -99,7 +108,11 @@ class Retrieve:
         block = torch.cat(pieces)
         if getattr(self.model, 'sparse', False) or 'splade' in self.model.model_name:
             block = block.to_sparse()
-        torch.save(block, self.get_chunk_path(save_path, last_batch))
+        # written under a temporary name and renamed: other processes (multi-rank encoding, a concurrent reader) take the
+        # existence of a chunk file as "complete"
+        final = self.get_chunk_path(save_path, last_batch)
+        torch.save(block, final + '.tmp')
+        os.replace(final + '.tmp', final)
 
     @torch.no_grad()
     def encode_and_save(self, dataset, save_path, query_or_doc, chunk_size=150000):
@@ -110,9 +123,7 @@ class Retrieve:
         n_batches = (len(dataset) + self.batch_size - 1) // self.batch_size
         os.makedirs(save_path, exist_ok=True)
         # this process's contiguous range of batches [b_lo, b_hi): everything for a single process
-        share = -(-n_batches // self.encode_world)
-        b_lo = min(n_batches, self.encode_rank * share)
-        b_hi = min(n_batches, b_lo + share)
+        b_lo, b_hi = self._batch_range(n_batches)
         source = dataset
         if self.encode_world > 1:
             from torch.utils.data import Subset
@@ -131,6 +142,36 @@ class Retrieve:
                 self._flush_chunk(save_path, i, pieces)
                 pieces = []
         self.model.model = self.model.model.to('cpu')
+
+    def _batch_range(self, n_batches, rank=None):
+        """Contiguous range of batches [b_lo, b_hi) that process `rank` of `encode_world` encodes."""
+        rank = self.encode_rank if rank is None else rank
+        share = -(-n_batches // self.encode_world)
+        b_lo = min(n_batches, rank * share)
+        return b_lo, min(n_batches, b_lo + share)
+
+    def wait_for_index(self, index_path, n_rows, timeout_s=None, poll_s=0.5):
+        """Multi-process encoding: block until every rank's last chunk file is in `index_path` (each rank writes it after
+        all its other chunks).  No collective is involved — the ranks only share the folder.  TimeoutError after
+        `timeout_s` seconds (default: BERGEN_AMD_INDEX_WAIT_S or 3600)."""
+        if self.encode_world <= 1:
+            return
+        import time
+        n_batches = (n_rows + self.batch_size - 1) // self.batch_size
+        need = []
+        for r in range(self.encode_world):
+            b_lo, b_hi = self._batch_range(n_batches, r)
+            if b_hi > b_lo:
+                need.append(self.get_chunk_path(index_path, b_hi - 1))
+        limit = float(os.environ.get("BERGEN_AMD_INDEX_WAIT_S", "3600")) if timeout_s is None else timeout_s
+        t0 = time.time()
+        while True:
+            missing = [f for f in need if not os.path.exists(f)]
+            if not missing:
+                return
+            if time.time() - t0 > limit:
+                raise TimeoutError(f"index {index_path}: still waiting for {len(missing)} rank(s), e.g. {missing[0]}")
+            time.sleep(poll_s)
 
     # ------------------------------------------------------------------ resident index
     def _build_resident(self, chunk_iter, dataset_size, dim, metric):
@@ -213,6 +254,9 @@ class Retrieve:
         q_ids = _column(dataset['query'], 'id')
         if self.model.model_name == "bm25":
             raise NotImplementedError("bm25 is out of scope of the dense backend (SURVEY §2)")
+        # several encoding processes share the folders: wait until every rank's range is there
+        self.wait_for_index(query_embeds_path, len(dataset['query']))
+        self.wait_for_index(doc_embeds_path, len(dataset['doc']))
 
         query_embeds = utils.load_embeddings(query_embeds_path)
         sparse_queries = bool(query_embeds.is_sparse)
@@ -222,16 +266,28 @@ class Retrieve:
             self.model.model = self.model.model.to('cpu')  # free HBM for the index (retrieve.py:78)
 
         metric = "sparse" if (sparse_queries or getattr(self.model, "sparse", False)) else _metric_of(self.model)
+        # the kernels carry candidate lists of at most 256 (dense) / 128 (sparse) entries: refuse a larger k BEFORE the
+        # index is read and uploaded (the reference accepts any k; INTEGRATION.md "Limits")
+        k_max = SparseIndex.MAX_K if metric == "sparse" else FlatIndex.MAX_K
+        if not 0 < int(top_k_documents) <= k_max:
+            raise ValueError(f"top_k_documents={top_k_documents} outside 1..{k_max} supported by the {metric} search kernels")
         index = self._resident_index(doc_embeds_path, dataset_size=len(dataset['doc']), metric=metric)
 
-        # one fused search per batch_size_sim queries (the reference splits the same way, retrieve.py:81)
-        found_scores, found_rows = [], []
-        pieces = query_embeds.split(self.batch_size_sim, dim=0)
-        for part in tqdm(pieces, total=len(pieces), desc='Retrieving docs...'):
-            part_scores, part_rows = index.search(part.contiguous(), top_k_documents)
-            found_scores.append(torch.from_numpy(part_scores))
-            found_rows.append(torch.from_numpy(part_rows))
-        all_scores, all_rows = torch.cat(found_scores), torch.cat(found_rows)
+        # ONE search call for the whole query set: the index is resident, the library walks it once per query TILE
+        # (256 / 192 / 128 queries, chosen by the kernel).  The reference's batch_size_sim split (retrieve.py:81) bounded
+        # its [Bq, n] score matrix, which does not exist here; splitting by it (1024 = 4 x 256 exactly, but 5.3 x 192)
+        # could only add corpus passes.  Sparse search keeps the split: its host side builds per-tile term tables.
+        if metric == "sparse":
+            found_scores, found_rows = [], []
+            pieces = query_embeds.split(self.batch_size_sim, dim=0)
+            for part in tqdm(pieces, total=len(pieces), desc='Retrieving docs...'):
+                part_scores, part_rows = index.search(part.contiguous(), top_k_documents)
+                found_scores.append(torch.from_numpy(part_scores))
+                found_rows.append(torch.from_numpy(part_rows))
+            all_scores, all_rows = torch.cat(found_scores), torch.cat(found_rows)
+        else:
+            s_np, i_np = index.search(query_embeds.contiguous(), top_k_documents)
+            all_scores, all_rows = torch.from_numpy(s_np), torch.from_numpy(i_np)
         return {"score": all_scores, "q_id": q_ids, "doc_id": self._map_doc_ids(dataset['doc'], all_rows)}
 
     @staticmethod
@@ -279,6 +335,12 @@ class Retrieve:
     # ------------------------------------------------------------------ misc (retrieve.py:190-197)
     def tokenize(self, example):
         return self.model.tokenize(example)
+
+    @property
+    def backend(self):
+        """'hip' when the plug-in's encoder runs on the hand-written kernels, 'hf' when it stayed on torch."""
+        from .dense import encoder_backend
+        return getattr(self.model, "backend", None) or encoder_backend(getattr(self.model, "model", None))
 
     def get_clean_model_name(self):
         return self.model.model_name.replace('/', '_')

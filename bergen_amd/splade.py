@@ -47,6 +47,12 @@ class Splade(Retriever):
             if hasattr(self.query_encoder, "eval"):
                 self.query_encoder.eval()
 
+    @property
+    def backend(self):
+        """'hip' when the model runs on the hand-written kernels, 'hf' when it stayed on torch (a warning was logged)."""
+        from .dense import encoder_backend
+        return encoder_backend(self.model)
+
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
         encoder = self.model if query_or_doc == "doc" else self.query_encoder

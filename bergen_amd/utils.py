@@ -182,51 +182,76 @@ def get_by_id(dataset, ids, field=None):
     return idxs
 
 
+def _rows_of_ids(table, ids):
+    """Rows of the ids that exist in `table` (IdIndex or the reference's dict), in the order given."""
+    if isinstance(table, IdIndex):
+        rows, found = table.get_many(ids)
+        return [int(r) for r in rows[found]]
+    return [table[i] for i in ids if i in table]
+
+
 def prepare_dataset_from_ids(dataset, q_ids, d_ids, multi_doc=False, query_field="content", oracle_provenance=False):
-    """Reference utils.py:116-178: join the (query id, ranked doc ids) lists back to text — the dataset the rerank and
-    generation stages consume.  Same rows, same keys (including the reference's `ranking_labels` spelling in the
-    per-row dicts), same str-id assertions; returns a `datasets.Dataset`."""
+    """Join (query ids, ranked doc ids) back to text — the dataset the rerank and generation stages consume.
+
+    Behaviour of the reference's utils.prepare_dataset_from_ids (utils.py:116-178) — same rows in the same order, same
+    column names (its `ranking_labels` spelling on the joined rows included), same refusal of non-string ids — built
+    column-wise: every hit of every query goes through ONE id lookup (`IdIndex.get_many`, a vectorised binary search)
+    and ONE batched read of the passage texts, instead of two lookups and one dataset read per query."""
     import datasets
-    if q_ids is None and d_ids is None:
-        dataset_dict = {'query': dataset['query'][query_field], 'q_id': dataset['query']['id']}
-        if 'label' in dataset['query'].features:
-            dataset_dict['label'] = dataset['query']['label']
-        if 'ranking_label' in dataset['query'].features:
-            dataset_dict['ranking_label'] = dataset['query']['ranking_label']
-        return datasets.Dataset.from_dict(dataset_dict)
-    use_oracle = oracle_provenance and "doc" in dataset['query'].features
-    if not use_oracle:
+    queries = dataset['query']
+    if q_ids is None and d_ids is None:  # no ranking: the queries with whatever labels the split carries
+        cols = {'query': queries[query_field], 'q_id': queries['id']}
+        for name in ('label', 'ranking_label'):
+            if name in queries.features:
+                cols[name] = queries[name]
+        return datasets.Dataset.from_dict(cols)
+
+    from_query_rows = bool(oracle_provenance) and "doc" in queries.features  # oracle passages travel with the query
+    if not from_query_rows:
         assert isinstance(d_ids[0][0], str), f"{d_ids[0]}"
         assert isinstance(next(iter(dataset['doc'].id2index.keys())), str), \
             "Dataset id type is not string, real index retrieval will fail and retrieve nothing. Please convert to string in dataset_processor!"
-    labels = get_by_id(dataset['query'], q_ids, 'label')
-    ranking_labels = get_by_id(dataset['query'], q_ids, 'ranking_label')
-    queries = get_by_id(dataset['query'], q_ids, query_field)
 
-    def mygen():
+    q_text = get_by_id(queries, q_ids, query_field)
+    q_label = get_by_id(queries, q_ids, 'label')
+    q_ranking = get_by_id(queries, q_ids, 'ranking_label')
+
+    # ---- passages of every query: ids as ranked, texts and corpus rows of the ids the corpus knows
+    if from_query_rows:
+        hit_ids = [get_by_id(queries, q, 'doc_id')[0] for q in q_ids]
+        hit_text = [get_by_id(queries, q, 'doc')[0] for q in q_ids]
+        hit_rows = [[None] * len(ids) for ids in hit_ids]
+    else:
+        corpus = dataset['doc']
+        hit_ids = [list(ids) for ids in d_ids[:len(q_ids)]]
+        hit_rows = [_rows_of_ids(corpus.id2index, ids) for ids in hit_ids]
+        flat = [r for rows in hit_rows for r in rows]
+        texts = corpus[flat]['content'] if flat else []
+        hit_text, at = [], 0
+        for rows in hit_rows:
+            hit_text.append(texts[at:at + len(rows)])
+            at += len(rows)
+
+    cols = defaultdict(list)
+    if multi_doc:  # one row per query, its passages as lists
+        cols['doc'], cols['query'], cols['q_id'] = hit_text, [q_text[i] for i in range(len(q_ids))], list(q_ids)
+        cols['d_id'], cols['d_idx'] = hit_ids, hit_rows
+        if len(q_label) > 0:
+            cols['label'] = [q_label[i] for i in range(len(q_ids))]
+        if len(q_ranking) > 0:
+            cols['ranking_labels'] = [q_ranking[i] for i in range(len(q_ids))]
+    else:  # one row per (query, passage)
         for i, q_id in enumerate(q_ids):
-            if use_oracle:
-                docs = get_by_id(dataset['query'], q_id, 'doc')[0]
-                d_ids_ = get_by_id(dataset['query'], q_id, 'doc_id')[0]
-                doc_idxs = [None for _ in d_ids_]
-            else:
-                docs = get_by_id(dataset['doc'], d_ids[i], 'content')
-                d_ids_ = d_ids[i]
-                doc_idxs = get_by_id(dataset['doc'], d_ids[i])
-            if multi_doc:
-                x = {'doc': docs, 'query': queries[i], 'q_id': q_id, 'd_id': d_ids_, 'd_idx': doc_idxs}
-                if len(labels) > 0:
-                    x['label'] = labels[i]
-                if len(ranking_labels) > 0:
-                    x['ranking_labels'] = ranking_labels[i]
-                yield x
-            else:
-                for d_id, doc, d_idx in zip(d_ids_, docs, doc_idxs):
-                    x = {'d_id': d_id, 'd_idx': d_idx, 'doc': doc, 'query': queries[i], 'q_id': q_id}
-                    if len(labels) > 0:
-                        x['label'] = labels[i]
-                    if len(ranking_labels) > 0:
-                        x['ranking_labels'] = ranking_labels[i]
-                    yield x
-
-    return datasets.Dataset.from_generator(mygen)
+            n = min(len(hit_ids[i]), len(hit_text[i]), len(hit_rows[i]))
+            cols['d_id'] += hit_ids[i][:n]
+            cols['d_idx'] += hit_rows[i][:n]
+            cols['doc'] += hit_text[i][:n]
+            cols['query'] += [q_text[i]] * n
+            cols['q_id'] += [q_id] * n
+            if len(q_label) > 0:
+                cols['label'] += [q_label[i]] * n
+            if len(q_ranking) > 0:
+                cols['ranking_labels'] += [q_ranking[i]] * n
+        if not cols:
+            cols = {'d_id': [], 'd_idx': [], 'doc': [], 'query': [], 'q_id': []}
+    return datasets.Dataset.from_dict(dict(cols))

@@ -143,7 +143,7 @@ int bh_set_option(const char* name, int64_t value);
  * head dim 64.  RetroMAE / contriever / e5 / bge checkpoints are all of this class. */
 typedef struct bh_encoder_config {
     int32_t n_layers;        /* num_hidden_layers */
-    int32_t hidden;          /* hidden_size (multiple of 64, = n_heads * 64) */
+    int32_t hidden;          /* hidden_size (multiple of 64; = n_heads * head_dim) */
     int32_t n_heads;         /* num_attention_heads */
     int32_t intermediate;    /* intermediate_size */
     int32_t vocab_size;
@@ -151,6 +151,13 @@ typedef struct bh_encoder_config {
     int32_t type_vocab_size;
     int32_t activation;      /* 0 = erf-GELU ("gelu") */
     float ln_eps;            /* layer_norm_eps */
+    int32_t head_dim;        /* 0 or 64: hidden / n_heads = 64.  8..56 (e5-small, bge-small, MiniLM: 32): the attention kernel
+                                works on 64-wide heads, the CALLER stores query / key / value weights and biases zero-padded to
+                                64 rows per head ([n_heads*64, hidden]; query rows scaled by sqrt(64 / head_dim), which turns
+                                the kernel's 1/sqrt(64) into 1/sqrt(head_dim)) and attention.output.dense.weight zero-padded
+                                to 64 columns per head ([hidden, n_heads*64]) */
+    int32_t position_offset; /* added to the token index to form the position id: 0 = BERT, padding_idx + 1 (= 2) = RoBERTa /
+                                XLM-R with right-padded inputs */
 } bh_encoder_config;
 
 typedef struct bh_encoder bh_encoder;

@@ -1,0 +1,154 @@
+"""GPU: the REAL model-loading path of the plug-ins — ``Dense`` / ``Splade`` / ``CrossEncoder`` constructed from a checkpoint
+directory with NO injected model, exactly as the reference does (models/retrievers/dense.py:16-20, splade.py:17-19,
+models/rerankers/crossencoder.py:18): ``AutoModel*.from_pretrained -> _native_encoder -> BertEncoder.from_hf``.
+
+The hub is unreachable here, so the checkpoints are random-init HF models written with ``save_pretrained`` next to a toy
+WordPiece tokenizer; one per architecture family the reference's shipped configs use and the kernels cover:
+BERT with 64-dim heads (retromae.yaml, e5-*-v2, bge-base ...), BERT with 32-dim heads (e5-small-v2.yaml:3,
+bge-small-en-v1.5.yaml:3, reranker/minilm6.yaml:3), DistilBERT (tasb.yaml:3), XLM-R (bge-m3.yaml:3, reranker/bge-m3.yaml:3).
+Expected values: HF's own forward pass of the same checkpoint in fp32 on the CPU (floating point: cosine >= 0.999 and
+max-abs error <= 3e-2 * max|ref| per embedding, the encoder tolerance of DESIGN.md)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+WORDS = ["the", "a", "of", "and", "to", "in", "is", "for", "on", "with", "as", "by", "at", "from", "that", "this", "it", "an",
+         "be", "are", "was", "were", "which", "or", "not", "but", "have", "has", "had", "one", "two", "three", "river", "city",
+         "music", "science", "history", "language", "water", "energy", "planet", "animal", "plant", "human", "machine", "number",
+         "where", "who", "what", "when", "why", "how", "many", "first", "last", "large", "small", "capital", "country", "war"]
+TEXTS = ["the capital of the country is a large city on the river", "what is the history of music and science",
+         "water and energy for the planet", "how many animal and plant", "who was the first human machine",
+         "a small number", "when was the last war in the city that was large", "language"]
+
+
+@pytest.fixture(scope="module")
+def toy_tokenizer_files():
+    """A WordPiece tokenizer with BERT's normaliser / pre-tokeniser / [CLS] A [SEP] B [SEP] template over a toy vocabulary."""
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    vocab = ["[CLS]", "[PAD]", "[SEP]", "[UNK]", "[MASK]"] + WORDS + ["?", ".", ","]
+    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer(lowercase=True)
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
+                                                     special_tokens=[("[CLS]", 0), ("[SEP]", 2)])
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
+                                  mask_token="[MASK]", model_input_names=["input_ids", "token_type_ids", "attention_mask"])
+    assert tok.pad_token_id == 1  # = RoBERTa's padding_idx, so that its position ids are the plain 2, 3, ... of real tokens
+    return tok, len(vocab)
+
+
+def _save(model, tok, path):
+    model = model.half().eval()
+    model.save_pretrained(path)
+    tok.save_pretrained(path)
+    return path
+
+
+def _base_kwargs(vocab):
+    return dict(vocab_size=vocab, num_hidden_layers=2, max_position_embeddings=66, hidden_act="gelu", hidden_dropout_prob=0.0,
+                attention_probs_dropout_prob=0.0, pad_token_id=1)
+
+
+def _make(kind, tok, vocab, path):
+    import transformers as T
+    torch.manual_seed(hash(kind) % 1000)
+    kw = _base_kwargs(vocab)
+    if kind == "bert64":
+        m = T.BertModel(T.BertConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256, **kw))
+    elif kind == "bert32":
+        m = T.BertModel(T.BertConfig(hidden_size=128, num_attention_heads=4, intermediate_size=256, **kw))
+    elif kind == "distilbert":
+        m = T.DistilBertModel(T.DistilBertConfig(vocab_size=vocab, dim=128, n_heads=2, n_layers=2, hidden_dim=256, activation="gelu",
+                                                 max_position_embeddings=66, dropout=0.0, attention_dropout=0.0, pad_token_id=1))
+    elif kind == "xlmr":
+        m = T.XLMRobertaModel(T.XLMRobertaConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256, type_vocab_size=1,
+                                                 layer_norm_eps=1e-5, **kw))
+    elif kind == "bert_mlm":
+        m = T.BertForMaskedLM(T.BertConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256, **kw))
+    elif kind == "bert_cls":
+        m = T.BertForSequenceClassification(T.BertConfig(hidden_size=128, num_attention_heads=4, intermediate_size=256, num_labels=1, **kw))
+    elif kind == "xlmr_cls":
+        m = T.XLMRobertaForSequenceClassification(T.XLMRobertaConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                                                                     type_vocab_size=1, layer_norm_eps=1e-5, num_labels=1, **kw))
+    else:
+        raise KeyError(kind)
+    return _save(m, tok, str(path))
+
+
+def _close(got, want, what):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    for r in range(got.shape[0]):
+        cos = float(got[r] @ want[r] / (np.linalg.norm(got[r]) * np.linalg.norm(want[r]) + 1e-30))
+        assert cos >= 0.999, f"{what} row {r}: cosine {cos}"
+        assert np.abs(got[r] - want[r]).max() <= 3e-2 * np.abs(want[r]).max() + 1e-3, f"{what} row {r}"
+
+
+@pytest.mark.parametrize("kind", ["bert64", "bert32", "distilbert", "xlmr"])
+@pytest.mark.parametrize("pooler", ["cls", "mean"])
+def test_dense_from_a_checkpoint_directory_runs_on_the_hip_path(kind, pooler, toy_tokenizer_files, tmp_path):
+    import transformers as T
+    import bergen_amd
+    tok, vocab = toy_tokenizer_files
+    path = _make(kind, tok, vocab, tmp_path / kind)
+    pool = bergen_amd.ClsPooler() if pooler == "cls" else bergen_amd.MeanPooler()
+    dense = bergen_amd.Dense(model_name=path, max_len=32, pooler=pool, similarity=bergen_amd.DotProduct(), prompt_q="what ")
+    assert dense.backend == "hip", "the checkpoint did not resolve to the hand-written forward pass"
+    docs = [{"content": t} for t in TEXTS]
+    batch = dense.collate_fn(docs, "doc")
+    got = dense("doc", batch)["embedding"]
+    assert got.is_cuda and got.dtype == torch.float16 and got.shape == (len(TEXTS), 128)
+    ref_model = T.AutoModel.from_pretrained(path, torch_dtype=torch.float32).eval()
+    with torch.no_grad():
+        hidden = ref_model(**{k: v for k, v in batch.items() if k != "token_type_ids" or kind in ("bert64", "bert32")})[0]
+    want = pool.pool(hidden, batch["attention_mask"])
+    _close(got.float().cpu().numpy(), want.numpy(), f"{kind}/{pooler}")
+    # queries go through the prompt + the same encoder
+    qb = dense.collate_fn([{"generated_query": "is the capital"}], "query")
+    assert dense.tokenizer.decode(qb["input_ids"][0], skip_special_tokens=True).startswith("what is the capital")
+    assert dense("query", qb)["embedding"].shape == (1, 128)
+
+
+def test_splade_from_a_checkpoint_directory_runs_on_the_hip_path(toy_tokenizer_files, tmp_path):
+    import transformers as T
+    import bergen_amd
+    tok, vocab = toy_tokenizer_files
+    path = _make("bert_mlm", tok, vocab, tmp_path / "mlm")
+    sp = bergen_amd.Splade(model_name=path, max_len=32)
+    assert sp.backend == "hip"
+    batch = sp.collate_fn([{"content": t} for t in TEXTS], "doc")
+    got = sp("doc", batch)["embedding"].float().cpu().numpy()
+    ref_model = T.AutoModelForMaskedLM.from_pretrained(path, torch_dtype=torch.float32).eval()
+    with torch.no_grad():
+        logits = ref_model(**batch).logits
+    want, _ = torch.max(torch.log(1 + torch.relu(logits)) * batch["attention_mask"].unsqueeze(-1), dim=1)  # splade.py:42-43
+    want = want.numpy()
+    assert got.shape == want.shape == (len(TEXTS), vocab)
+    assert np.abs(got - want).max() <= 3e-2
+    assert ((want > 0.05) <= (got > 0)).all() and ((want < -0.05) <= (got == 0)).all()
+
+
+@pytest.mark.parametrize("kind", ["bert_cls", "xlmr_cls"])
+def test_cross_encoder_from_a_checkpoint_directory_runs_on_the_hip_path(kind, toy_tokenizer_files, tmp_path):
+    import transformers as T
+    import bergen_amd
+    tok, vocab = toy_tokenizer_files
+    path = _make(kind, tok, vocab, tmp_path / kind)
+    ce = bergen_amd.CrossEncoder(model_name=path, max_len=40)
+    assert ce.backend == "hip"
+    rows = [{"query": TEXTS[i % 3], "doc": TEXTS[(i + 2) % len(TEXTS)], "q_id": f"q{i % 3}", "d_id": f"d{i}"} for i in range(6)]
+    batch = ce.collate_fn(rows)
+    feed = {k: v for k, v in batch.items() if k not in ("q_id", "d_id")}
+    if kind == "xlmr_cls":
+        feed.pop("token_type_ids", None)  # XLM-R has a single token type (its tokenizer returns none)
+    got = ce(feed)["score"].float().cpu().numpy()
+    ref_model = T.AutoModelForSequenceClassification.from_pretrained(path, torch_dtype=torch.float32).eval()
+    with torch.no_grad():
+        want = ref_model(**feed).logits.numpy()
+    assert got.shape == want.shape == (6, 1)
+    assert np.abs(got - want).max() <= 3e-2 * max(1.0, np.abs(want).max())

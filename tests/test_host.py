@@ -194,3 +194,202 @@ def test_multi_process_encoding_writes_one_valid_index(tmp_path):
         rr.encode_and_save(DS(n), str(many), "doc", chunk_size=160)
     got = bergen_amd.utils.load_embeddings(str(many))
     assert torch.equal(got, want)
+
+
+# ---- round 2: advisor findings ---------------------------------------------------------------------------------
+
+def test_retrieve_instantiates_any_mapping_config():
+    """rag.py builds Retrieve(**retriever_config) from hydra: init_args arrives as an OmegaConf DictConfig, which is a
+    Mapping but not a dict.  It must be instantiated (not stored as the model), nested targets included."""
+    from collections.abc import Mapping
+
+    class FakeDictConfig(Mapping):  # what a DictConfig looks like to isinstance() when omegaconf is not importable
+        def __init__(self, d):
+            self._d = {k: FakeDictConfig(v) if isinstance(v, dict) else v for k, v in d.items()}
+
+        def __getitem__(self, k):
+            return self._d[k]
+
+        def __iter__(self):
+            return iter(self._d)
+
+        def __len__(self):
+            return len(self._d)
+
+    cfg = FakeDictConfig({"_target_": "tests.test_host._Plugin", "model_name": "x/y",
+                          "pooler": {"_target_": "models.retrievers.dense.MeanPooler"},
+                          "similarity": {"_target_": "models.retrievers.dense.CosineSim"}})
+    r = Retrieve(init_args=cfg)
+    assert type(r.model).__name__ == "_Plugin" and r.model.model_name == "x/y"  # (the module may be imported under two names)
+    assert isinstance(r.model.pooler, bergen_amd.MeanPooler) and isinstance(r.model.similarity, bergen_amd.CosineSim)
+    assert r.get_clean_model_name() == "x_y"
+    built = _Plugin("a", None, None)
+    assert Retrieve(init_args=built).model is built  # an already-built plug-in passes through
+
+
+class _Plugin:
+    def __init__(self, model_name, pooler, similarity):
+        self.model_name, self.pooler, self.similarity = model_name, pooler, similarity
+
+
+def test_multi_rank_index_route_encodes_every_range_and_waits(tmp_path):
+    """Retrieve.index() from several ranks into one folder: the folder's existence must not make a later rank skip its
+    range, a finished rank must not encode twice, and wait_for_index() returns only when every range is there."""
+    import datasets
+    n, bs = 203, 8
+    ds = {"doc": datasets.Dataset.from_dict({"id": [f"d{i}" for i in range(n)], "content": [str(i) for i in range(n)]})}
+    folder = str(tmp_path / "shared")
+    ranks = [Retrieve(init_args=_FakeDense(), batch_size=bs, num_workers=0, encode_rank=r, encode_world=3) for r in range(3)]
+    ranks[1].index(ds, folder, "doc")                       # creates the folder first
+    with pytest.raises(TimeoutError):
+        ranks[1].wait_for_index(folder, n, timeout_s=0.2, poll_s=0.05)   # ranks 0 and 2 have not written yet
+    ranks[0].index(ds, folder, "doc")                       # must NOT be skipped although the folder exists
+    ranks[2].index(ds, folder, "doc")
+    before = {f: os.path.getmtime(os.path.join(folder, f)) for f in os.listdir(folder)}
+    ranks[0].index(ds, folder, "doc")                       # done marker present: no second encode
+    assert before == {f: os.path.getmtime(os.path.join(folder, f)) for f in os.listdir(folder)}
+    ranks[2].wait_for_index(folder, n, timeout_s=1.0)
+    single = str(tmp_path / "single")
+    Retrieve(init_args=_FakeDense(), batch_size=bs, num_workers=0).index(ds, single, "doc")
+    assert torch.equal(utils.load_embeddings(folder), utils.load_embeddings(single))
+    assert not [f for f in os.listdir(folder) if f.endswith(".tmp")]
+
+
+def test_dense_call_only_falls_back_for_an_unknown_pooler():
+    """Errors of the native forward pass (BH_EINVAL -> ValueError) must propagate; only a pooler the kernels have no mode
+    for goes through the unpooled path."""
+    calls = []
+
+    class Enc:
+        def encode_pooled(self, kwargs, pooler):
+            calls.append("pooled")
+            raise ValueError("seq_len 9999 > max_position 512")
+
+        def __call__(self, **kw):
+            calls.append("unpooled")
+            return (torch.zeros(2, 3, 4),)
+
+        def eval(self):
+            return self
+
+    class OddPooler:
+        @staticmethod
+        def pool(hidden, mask):
+            return hidden[:, -1]
+
+    batch = {"input_ids": torch.zeros(2, 3, dtype=torch.long), "attention_mask": torch.ones(2, 3, dtype=torch.long)}
+    d = bergen_amd.Dense("m", 8, bergen_amd.ClsPooler(), bergen_amd.DotProduct(), model=Enc(), tokenizer=object())
+    with pytest.raises(ValueError, match="max_position"):
+        d("doc", batch)
+    assert calls == ["pooled"]
+    calls.clear()
+    d2 = bergen_amd.Dense("m", 8, OddPooler(), bergen_amd.DotProduct(), model=Enc(), tokenizer=object())
+    assert d2("doc", batch)["embedding"].shape == (2, 4) and calls == ["unpooled"]
+    assert d.backend == "hf"
+
+
+def test_unsupported_encoders_are_reported_not_silent(caplog):
+    """A model the HIP forward pass does not cover stays on HF torch with ONE warning naming the reason."""
+    import logging
+    from types import SimpleNamespace
+    from bergen_amd.dense import _native_encoder, _warned
+    from bergen_amd.encoder import BertEncoder
+    cfg = SimpleNamespace(model_type="deberta-v2", _name_or_path="naver/trecdl22-crossencoder-debertav3")
+    model = SimpleNamespace(config=cfg)
+    assert BertEncoder.unsupported_reason(model).startswith("model_type 'deberta-v2'")
+    relu = SimpleNamespace(config=SimpleNamespace(model_type="bert", hidden_act="relu", hidden_size=768, num_attention_heads=12,
+                                                  num_hidden_layers=2, intermediate_size=3072, vocab_size=100,
+                                                  max_position_embeddings=64, type_vocab_size=2))
+    assert "hidden_act 'relu'" in BertEncoder.unsupported_reason(relu)
+    _warned.clear()
+    with caplog.at_level(logging.WARNING, logger="bergen_amd"):
+        assert _native_encoder(model) is model
+        assert _native_encoder(model) is model
+    msgs = [r.getMessage() for r in caplog.records if "stays on the HF torch implementation" in r.getMessage()]
+    assert len(msgs) == 1 and "crossencoder-debertav3" in msgs[0]
+
+
+def test_reference_model_families_resolve_to_the_hip_forward_pass():
+    """Architectures of the reference's shipped retriever / reranker configs that the kernels cover: BERT with 64- and
+    32-dim heads (e5-small-v2.yaml:3, bge-small-en-v1.5.yaml:3, reranker/minilm6.yaml:3), DistilBERT (tasb.yaml:3),
+    XLM-R (bge-m3.yaml:3).  DeBERTa-v3 (reranker/debertav3.yaml:3) is not one of them."""
+    from types import SimpleNamespace as NS
+    from bergen_amd.encoder import BertEncoder, canonical_config
+    bert = dict(hidden_act="gelu", num_hidden_layers=2, intermediate_size=1536, vocab_size=100, max_position_embeddings=64, type_vocab_size=2)
+    assert BertEncoder.supports(NS(config=NS(model_type="bert", hidden_size=768, num_attention_heads=12, **bert)))
+    small = canonical_config(NS(model_type="bert", hidden_size=384, num_attention_heads=12, **bert))
+    assert small["head_dim"] == 32 and small["position_offset"] == 0
+    distil = canonical_config(NS(model_type="distilbert", dim=768, n_heads=12, n_layers=6, hidden_dim=3072, activation="gelu",
+                                 vocab_size=30522, max_position_embeddings=512))
+    assert (distil["hidden_size"], distil["num_hidden_layers"], distil["type_vocab_size"], distil["head_dim"]) == (768, 6, 1, 64)
+    xlmr = canonical_config(NS(model_type="xlm-roberta", hidden_size=1024, num_attention_heads=16, num_hidden_layers=24,
+                               intermediate_size=4096, hidden_act="gelu", vocab_size=250002, max_position_embeddings=8194,
+                               type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5))
+    assert xlmr["position_offset"] == 2 and xlmr["layer_norm_eps"] == 1e-5
+    assert not BertEncoder.supports(NS(config=NS(model_type="deberta-v2")))
+
+
+def test_head_padding_keeps_the_attention_arithmetic():
+    """Heads narrower than 64 dims are stored zero-padded to 64 with the query scaled by sqrt(64 / head_dim): the kernel's
+    softmax(q k^T / sqrt(64)) v and output projection must equal the original softmax(q k^T / sqrt(head_dim)) v."""
+    from bergen_amd.encoder import canonical_state_dict
+    torch.manual_seed(0)
+    d, nh, hd, T = 128, 4, 32, 9
+    pre = "encoder.layer.0.attention."
+    sd = {pre + f"self.{n}.weight": torch.randn(d, d) * 0.1 for n in ("query", "key", "value")}
+    sd.update({pre + f"self.{n}.bias": torch.randn(d) * 0.1 for n in ("query", "key", "value")})
+    sd[pre + "output.dense.weight"] = torch.randn(d, d) * 0.1
+    cfg = dict(model_type="bert", hidden_size=d, num_attention_heads=nh, head_dim=hd, type_vocab_size=2)
+    sd["embeddings.token_type_embeddings.weight"] = torch.zeros(2, d)
+    pad = canonical_state_dict(cfg, sd)
+    assert pad[pre + "self.query.weight"].shape == (nh * 64, d) and pad[pre + "output.dense.weight"].shape == (d, nh * 64)
+    x = torch.randn(T, d)
+
+    def attend(w, width, scale):
+        q = (x @ w[pre + "self.query.weight"].T + w[pre + "self.query.bias"]).view(T, nh, width).transpose(0, 1)
+        k = (x @ w[pre + "self.key.weight"].T + w[pre + "self.key.bias"]).view(T, nh, width).transpose(0, 1)
+        v = (x @ w[pre + "self.value.weight"].T + w[pre + "self.value.bias"]).view(T, nh, width).transpose(0, 1)
+        ctx = torch.softmax(q @ k.transpose(1, 2) * scale, dim=-1) @ v
+        return ctx.transpose(0, 1).reshape(T, nh * width) @ w[pre + "output.dense.weight"].T
+
+    assert torch.allclose(attend(sd, hd, hd ** -0.5), attend(pad, 64, 64 ** -0.5), atol=1e-5)
+
+
+def test_distilbert_and_roberta_state_dicts_get_bert_names():
+    from bergen_amd.encoder import canonical_state_dict
+    d = 64
+    cfg = dict(model_type="distilbert", hidden_size=d, num_attention_heads=1, head_dim=64, type_vocab_size=1)
+    z = torch.zeros(1)
+    src = {"distilbert.embeddings.word_embeddings.weight": z, "distilbert.embeddings.position_embeddings.weight": z,
+           "distilbert.embeddings.LayerNorm.weight": z, "distilbert.embeddings.LayerNorm.bias": z}
+    for part in ("attention.q_lin", "attention.k_lin", "attention.v_lin", "attention.out_lin", "sa_layer_norm", "ffn.lin1",
+                 "ffn.lin2", "output_layer_norm"):
+        src[f"distilbert.transformer.layer.0.{part}.weight"] = z
+        src[f"distilbert.transformer.layer.0.{part}.bias"] = z
+    got = set(canonical_state_dict(cfg, src))
+    want = {"embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.token_type_embeddings.weight",
+            "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"}
+    for part in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense",
+                 "attention.output.LayerNorm", "intermediate.dense", "output.dense", "output.LayerNorm"):
+        want |= {f"encoder.layer.0.{part}.weight", f"encoder.layer.0.{part}.bias"}
+    assert got == want
+    rob = canonical_state_dict(dict(model_type="xlm-roberta", hidden_size=d, num_attention_heads=1, head_dim=64, type_vocab_size=1),
+                               {"roberta.embeddings.word_embeddings.weight": z, "classifier.dense.weight": z,
+                                "classifier.out_proj.weight": z, "lm_head.dense.weight": z,
+                                "roberta.embeddings.token_type_embeddings.weight": z})
+    assert set(rob) == {"embeddings.word_embeddings.weight", "pooler.dense.weight", "classifier.weight",
+                        "embeddings.token_type_embeddings.weight"}
+
+
+def test_k_is_validated_before_the_index_is_built(tmp_path):
+    import datasets
+    n = 40
+    ds = {"doc": datasets.Dataset.from_dict({"id": [f"d{i}" for i in range(n)], "content": [str(i) for i in range(n)]}),
+          "query": datasets.Dataset.from_dict({"id": ["q0"], "generated_query": ["3"]})}
+    r = Retrieve(init_args=_FakeDense(), batch_size=8, num_workers=0)
+    built = []
+    r._resident_index = lambda *a, **k: built.append(1)
+    with pytest.raises(ValueError, match=r"top_k_documents=300 outside 1\.\.248"):
+        r.retrieve(ds, str(tmp_path / "q"), str(tmp_path / "d"), 300)
+    assert not built
+    assert bergen_amd.FlatIndex.MAX_K == 248 and bergen_amd.SparseIndex.MAX_K == 120
