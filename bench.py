@@ -351,6 +351,7 @@ def main():
     for _ in range(args.warmup):
         res, res_host = step()
     scan_ms = merge_ms = kernel_total_ms = 0.0
+    uncertified = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -359,6 +360,7 @@ def main():
         scan_ms += c["scan_ms"]
         merge_ms += c["merge_ms"]
         kernel_total_ms += c["total_ms"]
+        uncertified += c.get("uncertified_queries", 0)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -430,6 +432,9 @@ def main():
             "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,
                                    "stream_total": kernel_total_ms / args.steps},
             "index_build_seconds": build_s,
+            # queries (summed over the timed steps) whose exactness the certificate could not prove from the scan's
+            # candidate lists and that took the exact fall-back scan (bergen_amd/csrc/certify.hip); inside the timed region
+            "uncertified_queries": uncertified,
             "parity_check": parity,
         }
         if world == 1 and args.query_split is None and not args.no_other_kernels:

@@ -40,6 +40,8 @@ class bh_counters(ctypes.Structure):
         ("total_ms", ctypes.c_double),
         ("algorithmic_bytes", ctypes.c_double),
         ("shader_mhz", ctypes.c_double),
+        ("uncertified_queries", ctypes.c_int64),
+        ("exact_ms", ctypes.c_double),
     ]
 
 

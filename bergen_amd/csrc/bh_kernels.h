@@ -52,6 +52,11 @@ struct BhMergeArgs {
     long long id_offset;
     float* out_scores;       // [nq_total][k] (already offset to this tile's first query)
     long long* out_ids;      // [nq_total][k]
+    // exactness certificate (certify.hip): a row the scan did not keep has an MFMA score <= the KP-th kept one, hence a
+    // canonical score <= that + err_coef * |q|; the query is certified when this stays below its k-th canonical score
+    float err_coef;          // 2 d 2^-24 max|x| (bound of |MFMA fp32 score - canonical score| per unit |q|), 0 = no certificate
+    unsigned* uncert;        // [nq_tile] out: 1 = not certified (already offset to this tile's first query), or null
+    bh_u64* kth_key;         // [nq_tile] out: canonical key (score, row) of the k-th result, or null
 };
 // merge_rescore.hip: one workgroup per query of the tile
 hipError_t bh_launch_merge_rescore(const BhMergeArgs& a, int kp, int nq_tile, hipStream_t stream);
@@ -59,6 +64,22 @@ hipError_t bh_launch_merge_rescore(const BhMergeArgs& a, int kp, int nq_tile, hi
 // merge_topk.hip: merge [n_lists][nq][k] (score, id) lists in canonical order
 hipError_t bh_launch_merge_lists(const float* scores, const long long* ids, int n_lists, int nq, int k,
                                  float* out_scores, long long* out_ids, hipStream_t stream);
+
+// certify.hip: largest row norm of the corpus (for the certificate's error bound) and the exact fall-back scan
+hipError_t bh_launch_row_norm_max(const _Float16* rows, long long n, int dim_padded, unsigned* out_max_bits, hipStream_t stream);
+#define BH_EXACT_BATCH 8        /* queries per exact-scan launch (their fp64 images share 64 KiB of LDS at d = 1024) */
+#define BH_EXACT_CAP 65536      /* qualifying rows kept per query */
+struct BhExactArgs {
+    const _Float16* corpus;   // [n_rows][D]
+    long long n_rows;
+    int dim_padded;
+    const _Float16* q;        // [nqf][D] the uncertified queries, gathered
+    int nqf;                  // <= BH_EXACT_BATCH
+    const bh_u64* kth_key;    // [nqf] a row qualifies iff its canonical key >= this one
+    bh_u64* out_keys;         // [nqf][BH_EXACT_CAP]
+    unsigned* out_cnt;        // [nqf] zeroed by the caller; may exceed the cap (overflow)
+};
+hipError_t bh_launch_exact_scan(const BhExactArgs& a, hipStream_t stream);
 
 // convert.hip: dtype conversion / padding / normalisation
 hipError_t bh_launch_convert_rows(const void* src, int src_dtype /*0=f16,1=f32*/, long long n, int dim,

@@ -56,6 +56,7 @@ struct Options {
     // 3 = scan_topk256.hip (8 waves, 256-query tile) where it applies (d in {384, 512, 768}), else scan_topk.hip;
     // 2 = scan_topk192.hip where it applies (d = 768, k <= 56); 0 = scan_topk.hip (4 waves, 128-query tile)
     int scan_kernel = 3;
+    int certify = 1;  // exactness certificate + exact fall-back scan for the queries it cannot prove (certify.hip)
 } g_opt;
 
 int pad_dim(int dim) {
@@ -92,6 +93,12 @@ struct bh_index {
     DevBuf<bh_u64> cand, partial;
     DevBuf<unsigned> gthr;
     DevBuf<bh_u64> clk;  // [grid][2] shader cycles / 100 MHz ticks of the last scan launch (diagnostics)
+    float max_norm = 0.f;        // largest row norm (after normalisation for cosine), set by bh_index_finalize
+    DevBuf<unsigned> uncert;     // [nq] certificate flags of the last search
+    DevBuf<bh_u64> kth;          // [nq] canonical key of each query's k-th result
+    DevBuf<_Float16> exact_q;    // [BH_EXACT_BATCH][D] uncertified queries gathered for the exact scan
+    DevBuf<bh_u64> exact_keys;   // [BH_EXACT_BATCH][BH_EXACT_CAP] + [BH_EXACT_BATCH] thresholds
+    DevBuf<unsigned> exact_cnt;  // [BH_EXACT_BATCH]
     DevBuf<_Float16> qbuf;
     DevBuf<unsigned char> staging;
     std::vector<hipEvent_t> events;
@@ -217,6 +224,9 @@ int bh_set_option(const char* name, int64_t value) {
         if (value != 0 && value != 2 && value != 3)
             return fail(BH_EINVAL, "scan_kernel must be 0 (128-query tile), 2 (192-query tile) or 3 (256-query tile, two waves per SIMD)");
         g_opt.scan_kernel = (int)value;
+    } else if (s == "certify") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "certify must be 0 or 1");
+        g_opt.certify = (int)value;
     } else if (s == "pair_window") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
         g_opt.pair_window = (int)value;
@@ -306,6 +316,11 @@ void bh_index_destroy(bh_index* ix) {
     ix->partial.release();
     ix->gthr.release();
     ix->clk.release();
+    ix->uncert.release();
+    ix->kth.release();
+    ix->exact_q.release();
+    ix->exact_keys.release();
+    ix->exact_cnt.release();
     ix->qbuf.release();
     ix->staging.release();
     if (ix->rows) (void)hipFree(ix->rows);
@@ -333,6 +348,20 @@ int bh_index_finalize(bh_index* ix) {
     if (ix->metric == BH_METRIC_COS) {
         HIP_TRY(bh_launch_l2_normalize_rows(ix->rows, ix->n_rows, ix->dim, ix->dim_padded, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    // largest row norm: the scale of the exactness certificate's error bound (certify.hip); one pass over the corpus
+    ix->max_norm = 0.f;
+    if (ix->n_rows > 0) {
+        int rc = ix->exact_cnt.ensure(BH_EXACT_BATCH);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(ix->exact_cnt.p, 0, sizeof(unsigned), ix->stream));
+        HIP_TRY(bh_launch_row_norm_max(ix->rows, ix->n_rows, ix->dim_padded, ix->exact_cnt.p, ix->stream));
+        unsigned bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, ix->exact_cnt.p, sizeof(unsigned), hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        float n2;
+        memcpy(&n2, &bits, sizeof n2);
+        ix->max_norm = std::sqrt(n2);
     }
     ix->finalized = true;
     return BH_OK;
@@ -383,6 +412,10 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: pass p is merged while pass p + 1 is scanned
     if ((rc = ix->gthr.ensure((size_t)bq * qs_max * 64 + grid))) return rc;
     if ((rc = ix->clk.ensure((size_t)grid * 2 + BH_TL_WORDS, true, ix->stream))) return rc;
+    if ((rc = ix->uncert.ensure((size_t)nq_pad))) return rc;
+    if ((rc = ix->kth.ensure((size_t)nq_pad))) return rc;
+    // |mfma - canonical| <= 2 d 2^-24 |q| |x| for any summation order of d exact products in fp32
+    const float err_coef = g_opt.certify ? 2.0f * (float)dp * 5.9604645e-8f * ix->max_norm : 0.f;
 
     hipStream_t st = ix->stream;
     if (!ix->merge_stream) HIP_TRY(hipStreamCreateWithFlags(&ix->merge_stream, hipStreamNonBlocking));
@@ -447,6 +480,9 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         ma.id_offset = id_offset;
         ma.out_scores = out_scores_dev + (size_t)q0 * k;
         ma.out_ids = reinterpret_cast<long long*>(out_ids_dev) + (size_t)q0 * k;
+        ma.err_coef = err_coef;
+        ma.uncert = g_opt.certify ? ix->uncert.p + q0 : nullptr;
+        ma.kth_key = g_opt.certify ? ix->kth.p + q0 : nullptr;
         HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 2), ms));
         HIP_TRY(bh_launch_merge_rescore(ma, kp, nq_tile, ms));
         HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 3), ms));
@@ -455,6 +491,80 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     }
     // the search ends when the last merges have: bring the side stream back into the main one
     for (int p = std::max(0, n_pass - 2); p < n_pass; ++p) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * p + 3), 0));
+    // ---- exactness: queries the certificate could not prove go through the exact scan (certify.hip)
+    int64_t n_uncert = 0;
+    double exact_ms = 0;
+    if (g_opt.certify) {
+        std::vector<unsigned> flags((size_t)nq);
+        HIP_TRY(hipMemcpyAsync(flags.data(), ix->uncert.p, (size_t)nq * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int> todo;
+        for (int q = 0; q < nq; ++q)
+            if (flags[(size_t)q]) todo.push_back(q);
+        n_uncert = (int64_t)todo.size();
+        if (!todo.empty()) {
+            hipEvent_t x0 = ix->event(2 + 4 * (size_t)n_pass), x1 = ix->event(3 + 4 * (size_t)n_pass);
+            if (!x0 || !x1) return fail(BH_EHIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(x0, st));
+            if ((rc = ix->exact_q.ensure((size_t)BH_EXACT_BATCH * dp))) return rc;
+            if ((rc = ix->exact_keys.ensure((size_t)BH_EXACT_BATCH * BH_EXACT_CAP + BH_EXACT_BATCH))) return rc;
+            if ((rc = ix->exact_cnt.ensure(BH_EXACT_BATCH))) return rc;
+            bh_u64* thr_dev = ix->exact_keys.p + (size_t)BH_EXACT_BATCH * BH_EXACT_CAP;
+            std::vector<bh_u64> keys;
+            std::vector<float> row_s((size_t)k);
+            std::vector<long long> row_i((size_t)k);
+            for (size_t b0 = 0; b0 < todo.size(); b0 += BH_EXACT_BATCH) {
+                const int nb = (int)std::min<size_t>(BH_EXACT_BATCH, todo.size() - b0);
+                for (int j = 0; j < nb; ++j) {
+                    const int q = todo[b0 + j];
+                    HIP_TRY(hipMemcpyAsync(ix->exact_q.p + (size_t)j * dp, ix->qbuf.p + (size_t)q * dp, (size_t)dp * 2, hipMemcpyDeviceToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(thr_dev + j, ix->kth.p + q, sizeof(bh_u64), hipMemcpyDeviceToDevice, st));
+                }
+                HIP_TRY(hipMemsetAsync(ix->exact_cnt.p, 0, BH_EXACT_BATCH * sizeof(unsigned), st));
+                BhExactArgs ea;
+                ea.corpus = ix->rows;
+                ea.n_rows = ix->n_rows;
+                ea.dim_padded = dp;
+                ea.q = ix->exact_q.p;
+                ea.nqf = nb;
+                ea.kth_key = thr_dev;
+                ea.out_keys = ix->exact_keys.p;
+                ea.out_cnt = ix->exact_cnt.p;
+                HIP_TRY(bh_launch_exact_scan(ea, st));
+                unsigned cnt[BH_EXACT_BATCH];
+                HIP_TRY(hipMemcpyAsync(cnt, ix->exact_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                for (int j = 0; j < nb; ++j) {
+                    const int q = todo[b0 + j];
+                    if (cnt[j] > BH_EXACT_CAP)
+                        return fail(BH_EUNSUPPORTED, "query %d: more than %d rows reach its k-th score within rounding error "
+                                    "(%u): exact fall-back list overflow", q, BH_EXACT_CAP, cnt[j]);
+                    keys.resize(cnt[j]);
+                    HIP_TRY(hipMemcpy(keys.data(), ix->exact_keys.p + (size_t)j * BH_EXACT_CAP, (size_t)cnt[j] * sizeof(bh_u64), hipMemcpyDeviceToHost));
+                    std::sort(keys.begin(), keys.end(), std::greater<bh_u64>());  // canonical order: score desc, row asc
+                    for (int t = 0; t < k; ++t) {
+                        if ((size_t)t < keys.size()) {
+                            const unsigned o = (unsigned)(keys[(size_t)t] >> 32);
+                            const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+                            memcpy(&row_s[(size_t)t], &u, 4);
+                            row_i[(size_t)t] = id_offset + (long long)(unsigned)~(unsigned)keys[(size_t)t];
+                        } else {
+                            row_s[(size_t)t] = -INFINITY;
+                            row_i[(size_t)t] = -1;
+                        }
+                    }
+                    HIP_TRY(hipMemcpy(out_scores_dev + (size_t)q * k, row_s.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(reinterpret_cast<long long*>(out_ids_dev) + (size_t)q * k, row_i.data(), (size_t)k * sizeof(long long),
+                                      hipMemcpyHostToDevice));
+                }
+            }
+            HIP_TRY(hipEventRecord(x1, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            float xm = 0;
+            HIP_TRY(hipEventElapsedTime(&xm, x0, x1));
+            exact_ms = xm;
+        }
+    }
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipStreamSynchronize(st));
 
@@ -479,6 +589,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
     c.total_ms = tot;
     c.algorithmic_bytes = alg_bytes;
+    c.uncertified_queries = n_uncert;
+    c.exact_ms = exact_ms;
     c.shader_mhz = 0;
     if (use256) {  // effective shader clock of the last scan launch: cycles per 100 MHz tick, averaged over the workgroups
         std::vector<bh_u64> h((size_t)grid * 2);

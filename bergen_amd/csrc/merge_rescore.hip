@@ -22,6 +22,7 @@ template <int KP>
 __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
     constexpr int EPL = KP / 64;
     __shared__ u64 lds_keys[4 * KP];
+    __shared__ float lds_qn[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x;  // query inside the tile
@@ -58,6 +59,19 @@ __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
         for (int r = 0; r < EPL; ++r) lds_keys[r * 64 + lane] = acc[r];
     }
     __syncthreads();
+    // (certificate) |q|^2 in fp32, slightly over-estimated below: every thread takes a strided part of the query
+    {
+        const _Float16* qv = a.qtile + (size_t)q * a.dim_padded;
+        float s2 = 0.f;
+        for (int j = tid; j < a.dim_padded; j += 256) {
+            const float v = (float)qv[j];
+            s2 += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        if (lane == 0) lds_qn[wave] = s2;
+    }
+    const u64 approx_kp_key = lds_keys[KP - 1];  // KP-th best by MFMA score (0: the lists were not full, nothing was dropped)
     // ---- 3. canonical re-scoring, one candidate per thread
     if (tid < KP) {
         const u64 key = lds_keys[tid];
@@ -92,6 +106,26 @@ __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
                 const bool valid = e[r] != 0ull;
                 a.out_scores[(size_t)q * a.k + i] = valid ? bh_key_score(e[r]) : -__builtin_inff();
                 a.out_ids[(size_t)q * a.k + i] = valid ? a.id_offset + (long long)bh_key_row(e[r]) : -1ll;
+            }
+        }
+        if (a.uncert != nullptr) {
+            // k-th canonical key (element k - 1 of the sorted list)
+            u64 kth = 0ull;
+#pragma unroll
+            for (int r = 0; r < EPL; ++r) {
+                const u64 v = bh_shfl64(e[r], (a.k - 1) & 63);
+                if (r == ((a.k - 1) >> 6)) kth = v;
+            }
+            if (lane == 0) {
+                bool certified = true;
+                if (approx_kp_key != 0ull && a.err_coef > 0.f) {
+                    const float qn = sqrtf(lds_qn[0] + lds_qn[1] + lds_qn[2] + lds_qn[3]) * 1.0001f;
+                    // everything the scan dropped has an MFMA score <= the KP-th kept one (exclusive thresholds drop ties too)
+                    const float limit = bh_key_score(approx_kp_key) + a.err_coef * qn;
+                    certified = kth != 0ull && bh_key_score(kth) > limit;
+                }
+                a.uncert[q] = certified ? 0u : 1u;
+                a.kth_key[q] = kth;
             }
         }
     }

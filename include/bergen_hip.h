@@ -59,6 +59,10 @@ typedef struct bh_counters {
     double total_ms;          /* first launch -> last kernel done (HIP events), excludes H2D/D2H */
     double algorithmic_bytes; /* sum over passes of N*d*2 + Bq*d*2 + Bq*k*12 */
     double shader_mhz;        /* effective shader clock during the last scan launch (s_memtime per 100 MHz tick); 0 = not measured */
+    int64_t uncertified_queries; /* queries whose top-k the exactness certificate could not prove from the scan's candidate
+                                    lists (more than KP - k rows within MFMA rounding error of the k-th score); they were
+                                    answered by the exact fall-back scan (one more corpus pass per 8 such queries) */
+    double exact_ms;          /* time spent in that fall-back (wall, included in total_ms) */
 } bh_counters;
 
 /* Library / device lifecycle ------------------------------------------------------- */

@@ -377,6 +377,52 @@ def test_tile256_kernel_dims_and_list_lengths(amd, n, d, nq, k):
     compare.assert_bit_exact(s, i, ws, wi, f"256-query kernel n={n} d={d} nq={nq} k={k}")
 
 
+@pytest.mark.parametrize("k", [50, 56, 120])
+@pytest.mark.parametrize("d", [768, 1024])
+def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
+    """More rows than the candidate margin (KP - k = 14 / 8 / 8) whose canonical scores TIE the k-th one exactly while
+    their fp32 MFMA scores differ in the last bits (same products, summed in another order): the scan's top-KP by MFMA
+    score then holds an arbitrary subset of the tied rows, the canonical order wants the lowest row indices.  The
+    certificate must flag the query and the exact fall-back scan must return the oracle's list bit for bit."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(1000 + k + d)
+    n, cluster, better = 4000, 40, k - 15
+    s = rng.choice(np.array([-1.0, 1.0]), size=d)
+    v = (rng.standard_normal(d) * 0.5).astype(np.float16).astype(np.float64)
+    q0 = (0.5 * s).astype(np.float16)                                   # |q_i| constant: q . (s * perm(v)) = 0.5 sum(v) for every perm
+    x = np.empty((n, d), np.float16)
+    for r in range(n):                                                    # the crowd: clearly lower scores
+        x[r] = (s * (rng.permutation(v) - 0.25 * rng.random(d))).astype(np.float16)
+    special = rng.choice(n, size=cluster + better, replace=False)
+    for r in special[:cluster]:                                           # the tie cluster: the same multiset of products
+        x[r] = (s * rng.permutation(v)).astype(np.float16)
+    for r in special[cluster:]:                                           # clearly better rows
+        x[r] = (s * (rng.permutation(v) + 0.25)).astype(np.float16)
+    q = np.concatenate([q0[None, :], rng.standard_normal((6, d)).astype(np.float16)])
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    tied = set(int(r) for r in special[:cluster])
+    assert len(tied & set(wi[0].tolist())) == 15 and len(set(np.float32(ws[0, -15:]).tolist())) == 1   # the construction works
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    try:
+        got_s, got_i = ix.search(q, k)
+        c = ix.counters()
+        compare.assert_bit_exact(got_s, got_i, ws, wi, f"near-tie cluster k={k} d={d}")
+        assert c["uncertified_queries"] >= 1 and c["exact_ms"] > 0
+        # an ordinary workload is certified from the candidate lists alone
+        got_s, got_i = ix.search(q[1:], k)
+        assert ix.counters()["uncertified_queries"] == 0
+        compare.assert_bit_exact(got_s, got_i, ws[1:], wi[1:], "ordinary queries")
+        # without the certificate the library still answers (results for the adversarial query are not guaranteed)
+        _lib.set_option("certify", 0)
+        ix.search(q, k)
+        assert ix.counters()["uncertified_queries"] == 0
+    finally:
+        _lib.set_option("certify", 1)
+        ix.close()
+
+
 def test_tile192_kernel_exact_ties(amd):
     from bergen_amd import _lib
     rng = np.random.default_rng(78)
