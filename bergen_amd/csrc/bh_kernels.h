@@ -39,6 +39,7 @@ bool bh_scan192_supports(int dim_padded, int kp);
 // scan_topk256.hip (8 waves, two per SIMD, 256 queries per pass; d in {384, 512, 768})
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan256_supports(int dim_padded, int kp);
+int bh_scan256_tile(int dim_padded);  // queries per pass: 256, or 128 at d = 1024
 
 struct BhMergeArgs {
     const bh_u64* partial;   // [G][BQ][KP]

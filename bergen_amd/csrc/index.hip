@@ -391,7 +391,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     const bool use256 = g_opt.scan_kernel == 3 && bh_scan256_supports(dp, kp);
     const bool use192 = g_opt.scan_kernel == 2 && bh_scan192_supports(dp, kp);
     if (use192 || use256) qw = 1;
-    const int bq = use256 ? 256 : use192 ? 192 : 128 * qw;
+    const int bq = use256 ? bh_scan256_tile(dp) : use192 ? 192 : 128 * qw;
     const int grid = ix->n_cu * g_opt.workgroups_per_cu;
     // passes: a launch scans for qs * bq queries (qs = 2: paired workgroups share the corpus stream through L2,
     // scan_topk.hip); the last queries run unsplit when no more than bq are left

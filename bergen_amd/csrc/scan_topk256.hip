@@ -92,7 +92,7 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // priority; 2 = waves 4-7 only, at raised priority; 3 = waves 0-3, no priority change.
 // SCHED: 0 = rendezvous at the top of a stage, refill spread over the stage; 1 = rendezvous in the middle of the stage,
 // refill in one block right behind it; 2 = rendezvous in the middle, refill spread over the second half.
-template <int NK32, int KP, int LS, int R, int PD, bool NT, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD>
+template <int NK32, int KP, int LS, int R, int PD, bool NT, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD, int NB = 2>
 __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NK32 * 32;
@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     constexpr int CAP = 2 * KP;
     constexpr int EPLC = CAP / 64;
     constexpr int EPLK = KP / 64;
-    constexpr int NB = 2;    // 16-query blocks per wave
-    constexpr int BQ = 256;  // 8 waves x 32 queries
+    // NB = 16-query blocks per wave: 2 (256 queries per workgroup) wherever their fragments fit, 1 at d = 1024
+    constexpr int BQ = 8 * 16 * NB;
     constexpr int ROW_BYTES = D * 2;
     constexpr int RB = KP / 64;
     // fragments in the accumulator half of the register file (all 128 of its registers; the MFMA accumulators are VGPRs)
@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             // stream does not depend on the back-to-back forwarding of a single chain (any instruction between two
             // dependent MFMAs costs ~60 cycles: measured 48 instead of 32 cycles per 32x32x16 MFMA in this loop shape)
             floatx4 acc[2][NB];  // (every element is first written by the tile's first MFMA on it, with C = 0)
+            static_assert(NB == 1 || NB == 2, "one or two query blocks per wave");
 
 #pragma unroll
             for (int part = 0; part < S; ++part) {
@@ -330,7 +331,12 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             // accumulators (a bare asm nop is not ordered against plain register reads: hipcc sank it behind them and the
             // filter saw the last block's scores one k-step short)
             if constexpr (!(ABL & 4))
-                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            {
+                if constexpr (NB == 2)
+                    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+                else
+                    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0]));
+            }
             else {
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
@@ -509,16 +515,16 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 
-template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD>
+template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD, int NB = 2>
 static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t smem = (size_t)R * 32 * LS * 128;
     constexpr bool kProduction = ABL == 0 && LM == 1 && SCHED == 1 && NBUF == PD;
     // the bench-only instantiations exist with the non-temporal stream policy only (compile time)
     const bool nt = a.nontemporal != 0 || !kProduction;
     static bool attr_done[2] = {false, false};
-    void (*kern)(BhScanArgs) = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, true, ABL, LM, SCHED, NBUF>;
+    void (*kern)(BhScanArgs) = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, true, ABL, LM, SCHED, NBUF, NB>;
     if constexpr (kProduction) {
-        if (!nt) kern = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, false, ABL, LM, SCHED, NBUF>;
+        if (!nt) kern = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, false, ABL, LM, SCHED, NBUF, NB>;
     }
     if (!attr_done[nt ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -529,26 +535,29 @@ static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t strea
     return hipGetLastError();
 }
 
-template <int NK32, int LS, int R, int PD>
+template <int NK32, int LS, int R, int PD, int NB = 2>
 static hipError_t launch256_kp(const BhScanArgs& a, int kp, int grid, hipStream_t stream) {
     switch (kp) {
-        case 64: return launch256_one<NK32, 64, LS, R, PD>(a, grid, stream);
-        case 128: return launch256_one<NK32, 128, LS, R, PD>(a, grid, stream);
-        case 256: return launch256_one<NK32, 256, LS, R, PD>(a, grid, stream);
+        case 64: return launch256_one<NK32, 64, LS, R, PD, 0, 1, 1, PD, NB>(a, grid, stream);
+        case 128: return launch256_one<NK32, 128, LS, R, PD, 0, 1, 1, PD, NB>(a, grid, stream);
+        case 256: return launch256_one<NK32, 256, LS, R, PD, 0, 1, 1, PD, NB>(a, grid, stream);
     }
     return hipErrorInvalidValue;
 }
 
-// dims whose 32-query fragments fit two waves per SIMD: d <= 768 (192 registers); d = 1024 needs 256
+// Two waves per SIMD need the fragments of a wave's queries in 192 registers: 32 queries up to d = 768 (256 queries per
+// workgroup), 16 queries at d = 1024 (128 registers; 128 queries per workgroup)
 bool bh_scan256_supports(int dim_padded, int kp) {
-    return (dim_padded == 768 || dim_padded == 512 || dim_padded == 384) && (kp == 64 || kp == 128 || kp == 256);
+    return (dim_padded == 1024 || dim_padded == 768 || dim_padded == 512 || dim_padded == 384) && (kp == 64 || kp == 128 || kp == 256);
 }
+int bh_scan256_tile(int dim_padded) { return dim_padded == 1024 ? 128 : 256; }
 
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream) {
     if (!bh_scan256_supports(dim_padded, kp) || a.qsplit != 1) return hipErrorInvalidValue;
     switch (dim_padded) {
         case 384: return launch256_kp<12, 6, 6, 4>(a, kp, grid, stream);
         case 512: return launch256_kp<16, 4, 9, 4>(a, kp, grid, stream);
+        case 1024: return launch256_kp<32, 4, 10, 4, 1>(a, kp, grid, stream);  // 16 KiB stages x 10 = all 160 KiB of LDS
         case 768:
             if (kp == 64) {
                 // bench-only: ablations (bit flags, see the kernel) and schedule variants of the headline geometry

@@ -423,6 +423,32 @@ def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
         ix.close()
 
 
+@pytest.mark.parametrize("kern", [3, 0])
+@pytest.mark.parametrize("nq", [127, 128, 129, 191, 192, 193, 600])
+def test_config5_geometry_matches_oracle(amd, kern, nq):
+    """BASELINE configs[4] geometry (e5-large-v2: d = 1024, top-200; reference config/retriever/e5-large-v2.yaml:5-10) on both
+    kernels that serve it — the two-waves-per-SIMD kernel with one 16-query block per wave (128 queries per pass) and the
+    4-wave kernel — across their pass boundaries."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(5000 + nq)
+    n, d, k = 30011, 1024, 200
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    try:
+        _lib.set_option("scan_kernel", kern)
+        ix = amd.FlatIndex(n, d, metric="ip")
+        ix.upload(x)
+        ix.finalize()
+        s, i = ix.search(q, k)
+        c = ix.counters()
+        ix.close()
+        assert c["query_tile"] == 128 and c["k_padded"] == 256 and c["n_passes"] == (nq + 127) // 128
+        compare.assert_bit_exact(s, i, ws, wi, f"config5 geometry, kernel {kern}, nq={nq}")
+    finally:
+        _lib.set_option("scan_kernel", KERNEL_DEFAULT)
+
+
 def test_tile192_kernel_exact_ties(amd):
     from bergen_amd import _lib
     rng = np.random.default_rng(78)

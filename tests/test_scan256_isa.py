@@ -63,11 +63,11 @@ def _code(lines):
 
 
 def production(name):
-    # template arguments: NK32, KP, LS, R, PD, NT, ABL, LM, SCHED, NBUF; production = ABL 0, LM 1, SCHED 1
-    m = re.search(r"kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+    # template arguments: NK32, KP, LS, R, PD, NT, ABL, LM, SCHED, NBUF, NB; production = ABL 0, LM 1, SCHED 1, NBUF = PD
+    m = re.search(r"kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     assert m, name
-    nk32, kp, ls, r, pd, nt, abl, lm, sched, nbuf = (int(x) for x in m.groups())
-    return abl == 0 and lm == 1 and sched == 1, nk32, kp, ls
+    nk32, kp, ls, r, pd, nt, abl, lm, sched, nbuf, nb = (int(x) for x in m.groups())
+    return abl == 0 and lm == 1 and sched == 1 and nbuf == pd, nk32, kp, ls, nb
 
 
 def test_no_instruction_touches_a_fragment_register_in_flight(kernels):
@@ -94,7 +94,7 @@ def test_no_instruction_touches_a_fragment_register_in_flight(kernels):
 def test_tile_loop_of_the_production_kernels(kernels):
     seen = 0
     for name, lines in kernels.items():
-        prod, nk32, kp, ls = production(name)
+        prod, nk32, kp, ls, nb = production(name)
         if not prod:
             continue
         seen += 1
@@ -104,14 +104,14 @@ def test_tile_loop_of_the_production_kernels(kernels):
         hot = [c for i, c in _code(lines[start:end])]
         assert not any("scratch_" in c for c in hot), f"{name}: scratch traffic inside the tile loop"
         n_mfma = sum(1 for c in hot if c.startswith("v_mfma_f32_16x16x32_f16"))
-        assert n_mfma == 4 * nk32, f"{name}: {n_mfma} MFMAs per tile, expected {4 * nk32}"   # 2 row blocks x 2 query blocks x k-steps
+        assert n_mfma == 2 * nb * nk32, f"{name}: {n_mfma} MFMAs per tile, expected {2 * nb * nk32}"   # 2 row blocks x NB query blocks x k-steps
         n_read = sum(1 for c in hot if c.startswith("ds_read_b128"))
         assert n_read == 2 * nk32, f"{name}: {n_read} fragment reads per tile"
         # the wait states must precede the first VALU instruction that reads an accumulator
         tail = [c for i, c in _code(lines[end:end + 12])]
         assert tail[0].startswith("s_nop 15") and tail[1].startswith("s_nop 7"), f"{name}: {tail[:3]}"
         assert not any(c.startswith("v_") for c in hot[-2:] if not c.startswith("v_mfma")), name
-    assert seen >= 6  # dims 384 / 512 / 768 x candidate lists 64 / 128 / 256 x nt / default policy
+    assert seen >= 24  # dims 384 / 512 / 768 / 1024 x candidate lists 64 / 128 / 256 x nt / default policy
 
 
 def test_headline_kernel_uses_the_whole_register_file_without_scratch(kernels):
@@ -125,7 +125,7 @@ def test_headline_kernel_uses_the_whole_register_file_without_scratch(kernels):
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
         if m and cur:
             usage[cur][m.group(1).strip()] = int(m.group(2))
-    head = [u for n, u in usage.items() if re.search(r"kernelILi24ELi64ELi6ELi6ELi4ELb[01]ELi0ELi1ELi1ELi4E", n)]
+    head = [u for n, u in usage.items() if re.search(r"kernelILi24ELi64ELi6ELi6ELi4ELb[01]ELi0ELi1ELi1ELi4ELi2E", n)]
     assert len(head) == 2
     for u in head:
         assert u["ScratchSize"] == 0 and u["Occupancy"] == 2 and u["VGPRs"] <= 128 and u["AGPRs"] <= 128, u
