@@ -36,6 +36,10 @@ bool bh_scan192_supports(int dim_padded, int kp);
 #define BH_TL_TILE0 1200
 #define BH_TL_TILES 6
 #define BH_TL_WORDS (8 * BH_TL_TILES * 2 * 5)
+#define BH_BOOT_TILES 8  /* tiles a workgroup of scan_topk256.hip scans twice to seed the shared score bounds */
+// scan_topk256: threshold slots per query (one per workgroup; the bound of a query is the 64th largest) and, behind the
+// slot tables of a pass, one refined bound per query
+#define BH_SLOTS256 256
 // scan_topk256.hip (8 waves, two per SIMD, 256 queries per pass; d in {384, 512, 768})
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan256_supports(int dim_padded, int kp);

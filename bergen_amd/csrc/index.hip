@@ -410,8 +410,11 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     if ((rc = ix->cand.ensure((size_t)grid * bq * 2 * kp))) return rc;
     const size_t partial_elems = (size_t)grid * bq * kp;
     if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: pass p is merged while pass p + 1 is scanned
-    if ((rc = ix->gthr.ensure((size_t)bq * qs_max * 64 + grid))) return rc;
-    if ((rc = ix->clk.ensure((size_t)grid * 2 + BH_TL_WORDS, true, ix->stream))) return rc;
+    // one threshold slot table per pass (64 KiB at 256 queries): all of them are reset by ONE launch up front instead of one
+    // small launch in front of every scan; the paired-workgroup progress words sit behind the tables
+    const size_t gthr_pass = use256 ? (size_t)bq * (BH_SLOTS256 + 1) : (size_t)bq * qs_max * 64;
+    if ((rc = ix->gthr.ensure(gthr_pass * (size_t)n_pass + grid))) return rc;
+    if ((rc = ix->clk.ensure((size_t)grid * 10 + BH_TL_WORDS, true, ix->stream))) return rc;
     if ((rc = ix->uncert.ensure((size_t)nq_pad))) return rc;
     if ((rc = ix->kth.ensure((size_t)nq_pad))) return rc;
     // |mfma - canonical| <= 2 d 2^-24 |q| |x| for any summation order of d exact products in fp32
@@ -431,12 +434,12 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         if (!ix->event(2 + 4 * p + 3)) return fail(BH_EHIP, "hipEventCreate failed");
 
     HIP_TRY(hipEventRecord(ev_begin, st));
+    HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)(gthr_pass * (size_t)n_pass), 0x007fffffu, st));
     double alg_bytes = 0;
     for (int p = 0; p < n_pass; ++p) {
         const int q0 = passes[p].first, qs = passes[p].second;
         const int tile = bq * qs;
         const int nq_tile = std::min(tile, nq - q0);
-        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)tile * 64, 0x007fffffu, st));
         BhScanArgs sa;
         sa.corpus = ix->rows;
         sa.n_rows = ix->n_rows;
@@ -445,7 +448,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.cand = ix->cand.p;
         bh_u64* partial_p = ix->partial.p + (size_t)(p & 1) * partial_elems;
         sa.partial = partial_p;
-        sa.gthr = ix->gthr.p;
+        sa.gthr = ix->gthr.p + gthr_pass * (size_t)p;
         sa.share = g_opt.share_threshold;
         sa.nontemporal = g_opt.nontemporal;
         sa.ablate = g_opt.ablate;
@@ -454,7 +457,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.dma_interleave = g_opt.dma_interleave;
         sa.pair_window = g_opt.pair_window;
         sa.clk = use256 ? ix->clk.p : nullptr;
-        sa.progress = ix->gthr.p + (size_t)bq * qs_max * 64;  // [grid] words behind the slot table
+        sa.progress = ix->gthr.p + gthr_pass * (size_t)n_pass;  // [grid] words behind the slot tables
         if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
         // this pass overwrites the partial set that pass p - 2 left for its merge: wait for that merge
         if (p >= 2) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * (p - 2) + 3), 0));

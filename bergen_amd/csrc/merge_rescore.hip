@@ -6,8 +6,11 @@
 //
 // One 256-thread workgroup per query:
 //   1. each of the 4 waves folds every 4th workgroup list (sorted, KP keys) into a running
-//      best-KP with a bitonic merge held in registers (lists whose best key cannot enter the
-//      running list are skipped after one 8-byte load);
+//      best-KP with a bitonic merge held in registers: the list heads are loaded 64 at a time (one
+//      per lane), the lists whose head can still enter are fetched four at a time, and the waves
+//      share their running KP-th best through LDS (a scan workgroup fills the whole register file
+//      of its CU, so this kernel cannot run beside the next pass's scan: its duration is per-pass
+//      fixed cost, and the dependent-load chain of a list-by-list fold was most of it);
 //   2. the 4 running lists are combined through LDS by wave 0;
 //   3. thread i re-scores candidate i: canonical score = fp32(sum_{j=0..d-1} q[j]*x[j]) with
 //      the sum taken sequentially in fp64 (products of fp16 values are exact in fp64, so the
@@ -23,25 +26,57 @@ __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
     constexpr int EPL = KP / 64;
     __shared__ u64 lds_keys[4 * KP];
     __shared__ float lds_qn[4];
+    __shared__ u64 lds_worst;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x;  // query inside the tile
     const size_t list_stride = (size_t)a.bq * KP;
     const u64* base = a.partial + (size_t)q * KP;
 
-    // ---- 1. fold lists wave, wave+4, ...
+    // ---- 1. fold lists wave, wave+4, ...: the heads of 64 lists sit one per lane; the lists whose head can still enter the
+    // running best-KP are fetched PF at a time (their latencies overlap) and merged; the running KP-th best of every wave
+    // is a lower bound of the query's KP-th best, so the four waves share the largest one through LDS
+    constexpr int PF = 4;
     u64 acc[EPL];
 #pragma unroll
     for (int r = 0; r < EPL; ++r) acc[r] = 0ull;
-    for (int g = wave; g < a.n_lists; g += 4) {
-        const u64* lst = base + (size_t)g * list_stride;
-        const u64 best = lst[0];                            // uniform load
-        const u64 worst = bh_shfl64(acc[EPL - 1], 63);      // running KP-th best
-        if (best <= worst) continue;                        // cannot contribute (covers empty lists)
-        u64 b[EPL];
+    if (tid == 0) lds_worst = 0ull;
+    __syncthreads();
+    for (int c0 = 0; c0 < a.n_lists; c0 += 256) {
+        const int g_lane = c0 + 4 * lane + wave;
+        const u64 head = g_lane < a.n_lists ? base[(size_t)g_lane * list_stride] : 0ull;
+        u64 todo = __ballot(head != 0ull);
+        while (todo) {
+            u64 worst = bh_shfl64(acc[EPL - 1], 63);
+            const u64 shared = *(volatile u64*)&lds_worst;
+            worst = worst > shared ? worst : shared;
+            u64 mask = __ballot(head > worst) & todo;
+            todo = mask;  // (bounds only rise: a list that fails now fails later too)
+            if (!mask) break;
+            int pick[PF];
+            u64 b[PF][EPL];
 #pragma unroll
-        for (int r = 0; r < EPL; ++r) b[r] = lst[r * 64 + lane];
-        bh_wave_merge_top<EPL>(acc, b, lane);
+            for (int p = 0; p < PF; ++p) {
+                pick[p] = -1;
+                if (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    todo &= ~(1ull << l);
+                    pick[p] = l;
+                    const u64* lst = base + (size_t)(c0 + 4 * l + wave) * list_stride;
+#pragma unroll
+                    for (int r = 0; r < EPL; ++r) b[p][r] = lst[r * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                if (pick[p] < 0) continue;
+                const u64 cur = bh_shfl64(acc[EPL - 1], 63);
+                if (bh_shfl64(b[p][0], 0) <= cur) continue;
+                bh_wave_merge_top<EPL>(acc, b[p], lane);
+                if (lane == 63 && acc[EPL - 1] != 0ull) atomicMax((unsigned long long*)&lds_worst, (unsigned long long)acc[EPL - 1]);
+            }
+        }
     }
     // ---- 2. combine the 4 waves
 #pragma unroll
@@ -82,11 +117,17 @@ __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
             const half8* qv = reinterpret_cast<const half8*>(a.qtile + (size_t)q * a.dim_padded);
             double s = 0.0;
             const int n8 = a.dim_padded >> 3;
-            for (int j = 0; j < n8; ++j) {
-                const half8 xv = x[j];
-                const half8 qq = qv[j];
+            for (int j = 0; j < n8; j += 4) {  // (dim_padded is a multiple of 32) four 16-byte loads in flight per candidate
+                half8 xv[4], qq[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s = __builtin_fma((double)qq[e], (double)xv[e], s);
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = x[j + u];
+                    qq[u] = qv[j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s = __builtin_fma((double)qq[u][e], (double)xv[u][e], s);
             }
             out = bh_make_key((float)s, row);
         }

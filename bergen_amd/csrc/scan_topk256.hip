@@ -94,6 +94,8 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // refill in one block right behind it; 2 = rendezvous in the middle, refill spread over the second half.
 template <int NK32, int KP, int LS, int R, int PD, bool NT, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD, int NB = 2>
 __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
+    const unsigned long long t_entry = wall_clock64();
+    unsigned st_hits = 0, st_compact = 0, st_poll = 0;  // diagnostics (wave 0 reports)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NK32 * 32;
     constexpr int LINES = D / 64;
@@ -158,7 +160,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     float thr[NB];       // candidate iff score > thr (per lane and block = per query)
     unsigned cnt[NB];    // entries in the query's candidate buffer (identical in the four lanes of a query)
     float best[NB][RB];  // this lane's RB best appended scores, descending
-    int next_poll = 0;
+    int next_poll = 0, npoll = 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         thr[nb] = -__builtin_inff();
@@ -209,13 +211,22 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     };
 
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    // Bootstrap of the thresholds.  Without a bound every score of a workgroup's first tiles is a candidate: the buffers
+    // of all its queries fill and are sorted several times before the shared bounds take hold (~0.25 ms per pass, a third
+    // of a pass over one of eight shards).  So the workgroup first runs its LAST nboot tiles for their per-query maxima
+    // only (published to the slot table, no candidates), exchanges bounds once, and then scans all its tiles — those nboot
+    // a second time (0.3 % more corpus bytes at 21 M rows).  A slot's value is still the score of a row of the corpus,
+    // distinct slots hold distinct rows: the bound stays valid, and rows that reach it are appended when they come by again.
+    const int nboot = a.share ? (my_tiles < BH_BOOT_TILES ? my_tiles : BH_BOOT_TILES) : 0;
+    const int total = nboot + my_tiles;  // tile ordinals: [0, nboot) bootstrap over tiles my_tiles - nboot .., then all tiles
     if (my_tiles > 0) {
         const unsigned char* corpus = reinterpret_cast<const unsigned char*>(a.corpus);
         int it = 0;  // issue cursor: tile ordinal, stage of the tile, ring slot
         int ip = 0;
         int islot = 0;
         auto issue_line = [&](int j) {
-            const int itc = it < my_tiles ? it : my_tiles - 1;  // past the end: harmless re-fetch, uniform vmcnt arithmetic
+            const int oc = it < total ? it : total - 1;  // past the end: harmless re-fetch, uniform vmcnt arithmetic
+            const int itc = oc < nboot ? my_tiles - nboot + oc : oc - nboot;
             const long long tile = b + (long long)itc * G;
             const unsigned char* src = corpus + (size_t)tile * 32 * ROW_BYTES + (size_t)ip * LS * 128 + ld_off;
             unsigned char* dst = smem + islot * STAGE_BYTES + line0 * 4096 + wr * 1024;
@@ -247,7 +258,9 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             for (int f = 0; f < NBUF; ++f) ag[f] = qf[0][f];
         }
 
-        for (int i = 0; i < my_tiles; ++i) {
+        for (int o = 0; o < total; ++o) {
+            const bool boot = o < nboot;
+            const int i = boot ? my_tiles - nboot + o : o - nboot;  // tile ordinal of this workgroup
             // four independent accumulator chains (row block x query block): consecutive MFMAs never share one, so the
             // stream does not depend on the back-to-back forwarding of a single chain (any instruction between two
             // dependent MFMAs costs ~60 cycles: measured 48 instead of 32 cycles per 32x32x16 MFMA in this loop shape)
@@ -346,6 +359,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                         for (int v = 0; v < 4; ++v) acc[rb][nb][v] = 0.f;
             }
             bool over = false;
+            float tile_max[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 float m = max3_raw(acc[0][nb][0], acc[0][nb][1], acc[0][nb][2]);
@@ -356,6 +370,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     asm volatile("" ::"v"(m));
                     m = -__builtin_inff();
                 }
+                tile_max[nb] = m;
                 over = over || (m > thr[nb]);
             }
             // ---- cold paths.  The fragment reads of the next tile's first k-steps are in flight and the compiler does not
@@ -364,9 +379,11 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             // between two rendezvous absorbs; the rare heavy parts (compaction of a full candidate buffer, the threshold
             // exchange) run with the fragments DEAD and read them again at the end (they are still in the ring): 16
             // registers more for that code.
-            const bool any_hit = __builtin_amdgcn_ballot_w64(over) != 0ull;
-            const bool do_poll = a.share && i >= next_poll;
-            if (__builtin_expect(any_hit || do_poll, 0)) {
+            const bool any_hit = !boot && __builtin_amdgcn_ballot_w64(over) != 0ull;
+            // (bootstrap: two exchanges, two tiles apart — the first publishes this wave's refinement, the second reads what the
+            // other workgroups refined meanwhile, so that the first scanned tile already meets a bound)
+            const bool do_poll = a.share && (boot ? (o == nboot - 1 || o == nboot - 3) : i >= next_poll);
+            if (__builtin_expect(any_hit || do_poll || boot, 0)) {
                 if constexpr (!(ABL & 2)) {
                     asm volatile("s_waitcnt lgkmcnt(0)");
 #pragma unroll
@@ -374,7 +391,37 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 }
                 const int lane_c = opaque_lane();
                 const int q16 = lane_c & 15, lg = lane_c >> 4;
+                if (boot && row0 + 32u <= n_rows32 && !(ABL & 1)) {
+                    // bootstrap tile: this lane's best score of its 8 rows goes to the slot table, nothing else happens
+                    // (a tile holding padding rows is skipped: their zero scores are no rows of the corpus)
+                    // (candidate lists of 64 * RB entries: the slot needs a score that RB rows of this lane reach)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        float pubv = tile_max[nb];
+                        if constexpr (RB > 1) {
+                            float top[RB];
+#pragma unroll
+                            for (int r = 0; r < RB; ++r) top[r] = -__builtin_inff();
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    float x = acc[rb][nb][v];
+#pragma unroll
+                                    for (int r = 0; r < RB; ++r) {
+                                        const float hi = fmaxf(top[r], x);
+                                        x = fminf(top[r], x);
+                                        top[r] = hi;
+                                    }
+                                }
+                            pubv = top[RB - 1];
+                        }
+                        __hip_atomic_fetch_max(a.gthr + (size_t)((wave * NB + nb) * 16 + q16) * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(pubv),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (any_hit) {
+                    ++st_hits;
                     // (1) append survivors (room for 32 entries per query is guaranteed by (2) of the previous visit);
                     //     slot = count + hits of the same query in the lower lane groups.  Hits are rare: the per-row test is
                     //     a fall-through branch, the work sits out of line.
@@ -399,7 +446,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                                             // lists of 64: the slot holds the best score of its workgroups; published right
                                             // here (fire and forget) instead of tracked in a register
                                             if (a.share)
-                                                __hip_atomic_fetch_max(a.gthr + (size_t)((wave * NB + nb) * 16 + q16) * 64 + (b & 63), bh_ordf(sv),
+                                                __hip_atomic_fetch_max(a.gthr + (size_t)((wave * NB + nb) * 16 + q16) * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(sv),
                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         } else {
                                             float x = sv;
@@ -431,49 +478,65 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                         while (need[nb] != 0ull) {
                             const int qq = __builtin_ctzll(need[nb]);
                             need[nb] &= need[nb] - 1;
+                            ++st_compact;
                             compact(nb, qq);
                         }
                     }
                 // ---- threshold exchange through the slot table (filter hint only), geometric schedule (scan_topk.hip)
                 if (do_poll) {
-                    next_poll = i + 1 + (i >> 1);
+                    if (!boot) next_poll = i + 1 + (i >> 1);
                     if constexpr (RB > 1) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const int q = (wave * NB + nb) * 16 + q16;
                             const float mine = best[nb][RB - 1];
                             if (mine > -__builtin_inff()) {  // (re-published at every exchange: ~20 atomics per lane and pass)
-                                __hip_atomic_fetch_max(a.gthr + (size_t)q * 64 + (b & 63), bh_ordf(mine), __ATOMIC_RELAXED,
+                                __hip_atomic_fetch_max(a.gthr + (size_t)q * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(mine), __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
                     }
-                    // poll: 16 lanes x 4 slots cover one query, 4 queries per 16-byte agent-scope load (the per-XCD L2s are
-                    // not coherent: sc1), uniform base + 32-bit lane offset; one batch of four loads per query block
-                    const unsigned loff = (unsigned)lane_c * 16u;
+                    // (a) refine the bound of ONE of this wave's queries (they rotate; the 256 workgroups refine all of them
+                    //     at every exchange): the 256 slots of the query are one 16-byte agent-scope load per lane (the
+                    //     per-XCD L2s are not coherent: sc1), and the largest T that 64 slots reach is built bit by bit
+                    //     (bits 31..8: a bound a little low is still a bound).  64 slots = 64 workgroups = 64 * RB distinct
+                    //     rows at or above T.  (b) the bounds the other workgroups refined: one word per query.
+                    const int sel = (b + npoll) & (16 * NB - 1);
+                    ++npoll;
+                    ++st_poll;
+                    const int qsel = wave * (16 * NB) + sel;
+                    unsigned* gbound = a.gthr + (size_t)(128 * NB) * BH_SLOTS256;
+                    uintx4 sl;
+                    unsigned gb[NB];
+                    asm volatile("global_load_dwordx4 %0, %1, %2 sc1"
+                                 : "=v"(sl)
+                                 : "v"((unsigned)lane_c * 16u), "s"(a.gthr + (size_t)qsel * BH_SLOTS256)
+                                 : "memory");
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        asm volatile("global_load_dword %0, %1, %2 sc1"
+                                     : "=v"(gb[nb])
+                                     : "v"((unsigned)q16 * 4u), "s"(gbound + (wave * NB + nb) * 16)
+                                     : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("" : "+v"(sl));
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(gb[nb]));
+                    unsigned T = 0u;
+                    for (int bit = 31; bit >= 8; --bit) {
+                        const unsigned c = T | (1u << bit);
+                        const int n = __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.x >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.y >= c)) +
+                                      __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.z >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.w >= c));
+                        if (n >= 64) T = c;
+                    }
+                    if (T > BH_ORD_NEG_INF && lane_c == 0)
+                        __hip_atomic_fetch_max(gbound + qsel, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        const unsigned* tab = a.gthr + (size_t)(wave * NB + nb) * 16 * 64;
-                        uintx4 sl[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1"
-                                         : "=v"(sl[t])
-                                         : "v"(loff), "s"(tab), "n"(t * 1024)
-                                         : "memory");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(sl[t]));
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            unsigned mn = min(min(sl[t].x, sl[t].y), min(sl[t].z, sl[t].w));
-#pragma unroll
-                            for (int o = 8; o >= 1; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
-                            // lanes 16g..16g+15 now hold the minimum of query 4 t + g of this block
-                            const unsigned got = (unsigned)__shfl((int)mn, (q16 & 3) * 16, 64);
-                            // a row that TIES the bound may still win on row index: inclusive compare
-                            if ((q16 >> 2) == t && got > BH_ORD_NEG_INF) thr[nb] = fmaxf(thr[nb], bh_unordf(got - 1u));
-                        }
+                        unsigned got = gb[nb];
+                        if (sel == nb * 16 + q16) got = max(got, T);
+                        // a row that TIES the bound may still win on row index: inclusive compare
+                        if (got > BH_ORD_NEG_INF) thr[nb] = fmaxf(thr[nb], bh_unordf(got - 1u));
                     }
                 }
                     // read the next tile's first fragments again (the read cursor already stands behind them)
@@ -497,18 +560,60 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         a.clk[2 * b] = __builtin_readcyclecounter() - clk0;
         a.clk[2 * b + 1] = wall_clock64() - rt0;
     }
+    const unsigned long long t_loop_end = wall_clock64();
 
-    // ---- final: every wave sorts its queries' buffers and publishes the best KP
+    // ---- final: every wave sorts its queries' buffers and publishes the best KP.  Once the bounds work a buffer holds a
+    // handful of candidates: eight buffers of up to 64 entries are loaded together and sorted side by side (the 21 stages
+    // of a 64-key sort are a chain of LDS-crossbar shuffles; eight independent chains hide each other's latency)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        for (int qq = 0; qq < 16; ++qq) {
-            const int qi = (wave * NB + nb) * 16 + qq;
-            const unsigned n = __builtin_amdgcn_readlane(cnt[nb], qq);
-            u64 e[EPLC];
-            sort_candidates256<KP>(e, cand_wg + (size_t)qi * CAP, n, lane);
+        for (int q0 = 0; q0 < 16; q0 += 8) {  // (rolled: one copy of the sort per query block)
+            u64 e8[8];
+            bool big = false;
 #pragma unroll
-            for (int r = 0; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = e[r];
+            for (int t = 0; t < 8; ++t) {
+                const unsigned n = __builtin_amdgcn_readlane(cnt[nb], q0 + t);
+                big = big || n > 64u;
+                const unsigned nn = n > 64u ? 0u : n;
+                load_list256<1>(*reinterpret_cast<u64(*)[1]>(&e8[t]), cand_wg + (size_t)((wave * NB + nb) * 16 + q0 + t) * CAP, nn, lane);
+            }
+#pragma unroll
+            for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) bh_bitonic_stage<8>(e8, lane, j, (k == 64) ? 0 : k);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int qi = (wave * NB + nb) * 16 + q0 + t;
+                part_wg[(size_t)qi * KP + lane] = e8[t];
+#pragma unroll
+                for (int r = 1; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = 0ull;
+            }
+            if (__builtin_expect(big, 0)) {
+                for (int t = 0; t < 8; ++t) {
+                    const int qi = (wave * NB + nb) * 16 + q0 + t;
+                    const unsigned n = __builtin_amdgcn_readlane(cnt[nb], q0 + t);
+                    if (n <= 64u) continue;
+                    u64 e[EPLC];
+                    sort_candidates256<KP>(e, cand_wg + (size_t)qi * CAP, n, lane);
+#pragma unroll
+                    for (int r = 0; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = e[r];
+                }
+            }
         }
+    }
+    if (a.clk != nullptr && tid == 0) {  // diagnostics: 100 MHz stamps of this workgroup's phases + wave 0's cold-path counts
+        unsigned long long* st = a.clk + 2 * G + BH_TL_WORDS + 8 * b;
+        st[0] = t_entry;
+        st[1] = rt0;
+        st[2] = t_loop_end;
+        st[3] = wall_clock64();
+        st[4] = st_hits;
+        st[5] = st_compact;
+        st[6] = st_poll;
+        unsigned tot = 0;
+        for (int nb = 0; nb < NB; ++nb)
+            for (int qq = 0; qq < 16; ++qq) tot += __builtin_amdgcn_readlane(cnt[nb], qq);
+        st[7] = tot;
     }
 }
 

@@ -1,0 +1,56 @@
+"""What bounds the 8-GPU strong-scaling case, measured on ONE GPU: the headline search on a shard of N / g rows for
+g = 1, 2, 4, 8 (one rank's work when the corpus is row-sharded over g GPUs), with the per-search fixed costs broken out.
+Run on the GPU box:  python profiles/shard_sweep.py > profiles/r02_shard_sweep.json"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import bergen_amd  # noqa: E402
+from bergen_amd import _lib  # noqa: E402
+
+
+def main():
+    _lib.init(0)
+    dim, k, nq, n_total = 768, 50, 2837, 21_000_000
+    dev = torch.device("cuda", 0)
+    q = bench.make_queries(nq, dim, dev)
+    out = {"workload": f"{nq} queries x (21 M / g) x {dim} fp16, top-{k}, one GPU", "shards": []}
+    for g in (1, 2, 4, 8):
+        lo, hi = bergen_amd.shard_range(n_total, 0, g)
+        ix = bergen_amd.FlatIndex(hi - lo, dim, metric="ip", device=0)
+        bench.fill_shard(ix, lo, hi, dim, q, n_total, dev)
+        ix.finalize()
+        ix.search(q, k)
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        scan = merge = total = 0.0
+        for _ in range(reps):
+            s, i = ix.search(q, k)
+            host = (s.cpu(), i.cpu())
+            c = ix.counters()
+            scan += c["scan_ms"]
+            merge += c["merge_ms"]
+            total += c["total_ms"]
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        out["shards"].append({"g": g, "rows": hi - lo, "queries_per_s": nq / (wall * 1e-3), "wall_ms": wall,
+                              "stream_total_ms": total / reps, "scan_ms": scan / reps, "merge_ms_side_stream": merge / reps,
+                              "passes": c["n_passes"], "scan_ms_per_pass": scan / reps / c["n_passes"],
+                              "non_scan_ms": wall - scan / reps, "query_tile": c["query_tile"]})
+        print(out["shards"][-1], file=sys.stderr, flush=True)
+        ix.close()
+    base = out["shards"][0]["queries_per_s"]
+    for sh in out["shards"]:
+        sh["speedup_vs_full_corpus"] = sh["queries_per_s"] / base
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
