@@ -21,7 +21,8 @@ struct BhScanArgs {
     unsigned* progress;      // [grid] qsplit = 2: tiles started per workgroup (zeroed by the host), pacing hint only
     int dma_interleave;      // 1: LDS-DMA refills issued one per line between the MFMAs instead of all after the barrier
     int pair_window;         // qsplit = 2: a workgroup may run at most this many tiles ahead of its partner (0 = free-running)
-    bh_u64* clk;             // optional diagnostics [grid][2]: shader cycles and 100 MHz ticks of the scan loop (scan_topk256.hip)
+    int dyn_tiles;           // scan_topk256: tiles handed out in chunks by a claim counter instead of round robin
+    bh_u64* clk;             // optional diagnostics [grid][8] phase stamps + BH_TL_WORDS timeline words (scan_topk256.hip)
 };
 
 // scan_topk.hip
@@ -32,7 +33,7 @@ hipError_t bh_launch_scan192(const BhScanArgs& a, int dim_padded, int kp, int gr
 bool bh_scan192_supports(int dim_padded, int kp);
 // timeline diagnostics of scan_topk256.hip (ablate 5): workgroup 0 records, for BH_TL_TILES tiles from ordinal BH_TL_TILE0,
 // per wave and stage five s_memtime values (before the vmcnt wait, after it, after the barrier, stage end, cycles spent in
-// LDS-DMA issue) behind the [grid][2] clock words of BhScanArgs::clk
+// LDS-DMA issue) behind the [grid][8] phase stamps of BhScanArgs::clk
 #define BH_TL_TILE0 1200
 #define BH_TL_TILES 6
 #define BH_TL_WORDS (8 * BH_TL_TILES * 2 * 5)
@@ -40,6 +41,20 @@ bool bh_scan192_supports(int dim_padded, int kp);
 // scan_topk256: threshold slots per query (one per workgroup; the bound of a query is the 64th largest) and, behind the
 // slot tables of a pass, one refined bound per query
 #define BH_SLOTS256 256
+// scan_topk256, dynamic tile distribution: smallest run of consecutive tiles a claim hands out (the LDS ring holds 2.5 tiles
+// in flight at d = 768, 4 at d = 512, 5 at d = 384: a run must outlast the look-ahead by two tiles); the pass's claim counter
+// sits behind its bounds
+__host__ __device__ constexpr int bh_scan256_chunk_tiles(int /*dim_padded*/) { return 8; }
+// tiles per workgroup that go round robin before the claimed part of the corpus starts (0: all of it is claimed in chunks,
+// chunk b first: the counter starts at tile grid * chunk); shared by the kernel and the host
+__host__ __device__ inline int bh_scan256_round_robin_tiles(int n_tiles, int grid, int dim_padded) {
+    const int rr = (int)(((long long)n_tiles * 7 / 8) / grid);
+    return rr >= 4 * bh_scan256_chunk_tiles(dim_padded) ? rr : 0;
+}
+__host__ __device__ inline unsigned bh_scan256_first_claimed_tile(int n_tiles, int grid, int dim_padded) {
+    const int rr = bh_scan256_round_robin_tiles(n_tiles, grid, dim_padded);
+    return rr > 0 ? (unsigned)rr * (unsigned)grid : (unsigned)grid * (unsigned)bh_scan256_chunk_tiles(dim_padded);
+}
 // scan_topk256.hip (8 waves, two per SIMD, 256 queries per pass; d in {384, 512, 768})
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan256_supports(int dim_padded, int kp);
@@ -90,7 +105,8 @@ hipError_t bh_launch_exact_scan(const BhExactArgs& a, hipStream_t stream);
 hipError_t bh_launch_convert_rows(const void* src, int src_dtype /*0=f16,1=f32*/, long long n, int dim,
                                   _Float16* dst, int dim_padded, hipStream_t stream);
 hipError_t bh_launch_l2_normalize_rows(_Float16* rows, long long n, int dim, int dim_padded, hipStream_t stream);
-hipError_t bh_launch_fill_u32(unsigned* p, long long n, unsigned v, hipStream_t stream);
+hipError_t bh_launch_fill_u32(unsigned* p, long long n, unsigned v, hipStream_t stream, long long period = 0, long long special_at = 0,
+                              unsigned v_special = 0);
 
 // ---------------------------------------------------------------------------------------------
 // bi-encoder forward pass (gemm_f16.hip, attention.hip, encoder_ops.hip; orchestrated by encoder.hip)

@@ -79,16 +79,18 @@ hipError_t bh_launch_l2_normalize_rows(_Float16* rows, long long n, int dim, int
     return hipGetLastError();
 }
 
-__global__ void bh_fill_u32_kernel(unsigned* p, long long n, unsigned v) {
+// p[i] = v, except the word at offset `special_at` of every block of `period` words (period > 0), which gets v_special
+__global__ void bh_fill_u32_kernel(unsigned* p, long long n, unsigned v, long long period, long long special_at, unsigned v_special) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
-        p[i] = v;
+        p[i] = (period > 0 && i % period == special_at) ? v_special : v;
 }
 
-hipError_t bh_launch_fill_u32(unsigned* p, long long n, unsigned v, hipStream_t stream) {
+hipError_t bh_launch_fill_u32(unsigned* p, long long n, unsigned v, hipStream_t stream, long long period, long long special_at,
+                              unsigned v_special) {
     if (n <= 0) return hipSuccess;
     long long blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(bh_fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n, v);
+    hipLaunchKernelGGL(bh_fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n, v, period, special_at, v_special);
     return hipGetLastError();
 }

@@ -53,6 +53,7 @@ struct Options {
     int query_split = 1;
     int pair_window = 0;
     int dma_interleave = 1;
+    int dyn_tiles = 1;  // scan_topk256: the last eighth of the corpus in chunks by claim counter (0: everything round robin)
     // 3 = scan_topk256.hip (8 waves, 256-query tile) where it applies (d in {384, 512, 768}), else scan_topk.hip;
     // 2 = scan_topk192.hip where it applies (d = 768, k <= 56); 0 = scan_topk.hip (4 waves, 128-query tile)
     int scan_kernel = 3;
@@ -92,7 +93,7 @@ struct bh_index {
     hipStream_t merge_stream = nullptr;  // merge / re-score of pass p runs beside the scan of pass p + 1
     DevBuf<bh_u64> cand, partial;
     DevBuf<unsigned> gthr;
-    DevBuf<bh_u64> clk;  // [grid][2] shader cycles / 100 MHz ticks of the last scan launch (diagnostics)
+    DevBuf<bh_u64> clk;  // [grid][8] phase stamps of the last scan launch + the timeline words (diagnostics, scan_topk256.hip)
     float max_norm = 0.f;        // largest row norm (after normalisation for cosine), set by bh_index_finalize
     DevBuf<unsigned> uncert;     // [nq] certificate flags of the last search
     DevBuf<bh_u64> kth;          // [nq] canonical key of each query's k-th result
@@ -227,6 +228,9 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "certify") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "certify must be 0 or 1");
         g_opt.certify = (int)value;
+    } else if (s == "dyn_tiles") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "dyn_tiles must be 0 or 1");
+        g_opt.dyn_tiles = (int)value;
     } else if (s == "pair_window") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
         g_opt.pair_window = (int)value;
@@ -412,9 +416,9 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: pass p is merged while pass p + 1 is scanned
     // one threshold slot table per pass (64 KiB at 256 queries): all of them are reset by ONE launch up front instead of one
     // small launch in front of every scan; the paired-workgroup progress words sit behind the tables
-    const size_t gthr_pass = use256 ? (size_t)bq * (BH_SLOTS256 + 1) : (size_t)bq * qs_max * 64;
+    const size_t gthr_pass = use256 ? (size_t)bq * (BH_SLOTS256 + 1) + 4 : (size_t)bq * qs_max * 64;  // (+ the claim counter)
     if ((rc = ix->gthr.ensure(gthr_pass * (size_t)n_pass + grid))) return rc;
-    if ((rc = ix->clk.ensure((size_t)grid * 10 + BH_TL_WORDS, true, ix->stream))) return rc;
+    if ((rc = ix->clk.ensure((size_t)grid * 8 + BH_TL_WORDS, true, ix->stream))) return rc;
     if ((rc = ix->uncert.ensure((size_t)nq_pad))) return rc;
     if ((rc = ix->kth.ensure((size_t)nq_pad))) return rc;
     // |mfma - canonical| <= 2 d 2^-24 |q| |x| for any summation order of d exact products in fp32
@@ -434,7 +438,10 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         if (!ix->event(2 + 4 * p + 3)) return fail(BH_EHIP, "hipEventCreate failed");
 
     HIP_TRY(hipEventRecord(ev_begin, st));
-    HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)(gthr_pass * (size_t)n_pass), 0x007fffffu, st));
+    // every pass's slot tables and bounds start at ordf(-inf); its claim counter (scan_topk256 dynamic tile distribution)
+    // starts at the first tile that is not handed out by workgroup index
+    HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)(gthr_pass * (size_t)n_pass), 0x007fffffu, st, use256 ? (long long)gthr_pass : 0,
+                               (long long)bq * (BH_SLOTS256 + 1), use256 ? bh_scan256_first_claimed_tile((int)ix->n_tiles, grid, dp) : 0u));
     double alg_bytes = 0;
     for (int p = 0; p < n_pass; ++p) {
         const int q0 = passes[p].first, qs = passes[p].second;
@@ -456,6 +463,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.qsplit = qs;
         sa.dma_interleave = g_opt.dma_interleave;
         sa.pair_window = g_opt.pair_window;
+        sa.dyn_tiles = g_opt.dyn_tiles;
         sa.clk = use256 ? ix->clk.p : nullptr;
         sa.progress = ix->gthr.p + gthr_pass * (size_t)n_pass;  // [grid] words behind the slot tables
         if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
@@ -596,12 +604,12 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     c.exact_ms = exact_ms;
     c.shader_mhz = 0;
     if (use256) {  // effective shader clock of the last scan launch: cycles per 100 MHz tick, averaged over the workgroups
-        std::vector<bh_u64> h((size_t)grid * 2);
+        std::vector<bh_u64> h((size_t)grid * 8);
         HIP_TRY(hipMemcpy(h.data(), ix->clk.p, h.size() * sizeof(bh_u64), hipMemcpyDeviceToHost));
         double cyc = 0, ticks = 0;
-        for (int g = 0; g < grid; ++g) {
-            cyc += (double)h[2 * g];
-            ticks += (double)h[2 * g + 1];
+        for (int g = 0; g < grid; ++g) {  // (tile loop: words 4 -> 5 in cycles, 1 -> 2 in ticks)
+            cyc += (double)(h[8 * g + 5] - h[8 * g + 4]);
+            ticks += (double)(h[8 * g + 2] - h[8 * g + 1]);
         }
         if (ticks > 0) c.shader_mhz = 100.0 * cyc / ticks;
     }

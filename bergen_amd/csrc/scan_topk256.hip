@@ -94,8 +94,9 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // refill in one block right behind it; 2 = rendezvous in the middle, refill spread over the second half.
 template <int NK32, int KP, int LS, int R, int PD, bool NT, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD, int NB = 2>
 __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
-    const unsigned long long t_entry = wall_clock64();
-    unsigned st_hits = 0, st_compact = 0, st_poll = 0;  // diagnostics (wave 0 reports)
+    // diagnostics block of this workgroup (a.clk, 8 words: 100 MHz ticks at entry / loop start / loop end / exit, shader
+    // cycles at loop start / end, candidates wave 0 holds at the end); every stamp is stored where it is taken
+    if (a.clk != nullptr && threadIdx.x == 0) a.clk[8 * blockIdx.x + 0] = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NK32 * 32;
     constexpr int LINES = D / 64;
@@ -108,6 +109,12 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     constexpr int DPW = SPLIT ? LS / 2 : LS;  // LDS-DMA instructions per (loading) wave and stage
     static_assert(PD <= NF / 2 && NF % NBUF == 0 && NBUF >= PD, "fragment pipeline depth divides the stage; reads of the next stage start behind the rendezvous");
     constexpr int STAGE_BYTES = 32 * LS * 128;
+    // dynamic tile distribution needs one word of LDS behind the ring (the d = 1024 ring takes all 160 KiB: static there)
+    constexpr bool DYN = R * STAGE_BYTES + 16 <= 160 * 1024;
+    // the LDS-DMA issue cursor runs LEAD tiles ahead of the MFMAs: the run after the current one must be known by then
+    constexpr int LEAD = (R - 1 + S - 1) / S;
+    constexpr int CH = bh_scan256_chunk_tiles(D);
+    static_assert(!DYN || CH >= LEAD + 3, "a run is claimed LEAD + 2 tiles before the current one ends");
     constexpr int CAP = 2 * KP;
     constexpr int EPLC = CAP / 64;
     constexpr int EPLK = KP / 64;
@@ -133,7 +140,31 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     const int G = (int)gridDim.x, b = (int)blockIdx.x;
     const int q16 = lane & 15, lg = lane >> 4;
 
-    const int my_tiles = (a.n_tiles > b) ? (int)((a.n_tiles - b + G - 1) / G) : 0;  // < 2^27 (n_rows < 2^32)
+    const int n_tiles = (int)a.n_tiles;  // < 2^27 (n_rows < 2^32)
+    // The workgroup's tiles, one RUN at a time: tile j of a run is run_base + j * run_stride.
+    //   static  : one run, tiles b, b + G, b + 2 G, ... (round robin)
+    //   dynamic : the first 7/8 of the corpus round robin (one long run), the rest in runs of consecutive tiles handed out
+    //             by the pass's claim counter (an atomic add of the run length; the lengths halve from half a workgroup's
+    //             share of the tail down to CH tiles).  Workgroups do not run at one speed (the XCDs clock differently
+    //             under the power limit: 3-4 % between them, plus the luck of the candidate path: +-5 % over an eighth
+    //             of the corpus), and a launch ends with its slowest workgroup.  A corpus too small for a round-robin
+    //             run of 4 CH tiles is all chunks of CH: chunk b first, the counter hands out the tiles from G * CH on.
+    const bool dyn = DYN && a.dyn_tiles != 0;
+    int run_base = b, run_stride = G, run_len = n_tiles > b ? (n_tiles - b + G - 1) / G : 0;
+    int nxt_base = 0, nxt_len = 0;
+    int claim_len = CH;  // tiles the next claim asks for
+    if (dyn) {
+        const int rr = bh_scan256_round_robin_tiles(n_tiles, G, D);  // (the host starts the claim counter behind them)
+        if (rr > 0) {
+            run_len = rr;
+            claim_len = (n_tiles - rr * G) / (2 * G);
+            if (claim_len < CH) claim_len = CH;
+        } else {
+            run_base = b * CH;
+            run_stride = 1;
+            run_len = run_base < n_tiles ? (n_tiles - run_base < CH ? n_tiles - run_base : CH) : 0;
+        }
+    }
     const unsigned n_rows32 = (unsigned)a.n_rows;
     u64* cand_wg = a.cand + (size_t)b * BQ * CAP;
     u64* part_wg = a.partial + (size_t)b * BQ * KP;
@@ -160,7 +191,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     float thr[NB];       // candidate iff score > thr (per lane and block = per query)
     unsigned cnt[NB];    // entries in the query's candidate buffer (identical in the four lanes of a query)
     float best[NB][RB];  // this lane's RB best appended scores, descending
-    int next_poll = 0, npoll = 0;
+    int next_poll = 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         thr[nb] = -__builtin_inff();
@@ -190,8 +221,24 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         asm volatile("" : "+v"(l));
         return l;
     };
+    // (same for the wave index: the per-wave base addresses of the candidate buffers, slot tables and bounds would
+    // otherwise sit in ~20 scalar registers across the hot path — past the 102 there are, into lanes of a vector register)
+    auto opaque_wave = [&]() {
+        int w = wave;
+        asm volatile("" : "+s"(w));
+        return w;
+    };
+    // a pointer for an "s" operand of inline asm: uniform by construction, made uniform for the compiler too.  The
+    // v_readfirstlane pair may sit right in front of the asm: a VMEM instruction that reads an SGPR a VALU instruction wrote
+    // needs 5 wait states, and the hazard recognizer does not look into inline asm — such asm starts with s_nop 4
+    auto sgpr_ptr = [](const unsigned* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const unsigned*)(((unsigned long long)hi << 32) | lo);
+    };
     auto compact = [&](int nb, int qq) {
         const int lane = opaque_lane();
+        const int wave = opaque_wave();
         const int q16 = lane & 15;
         const int qi = (wave * NB + nb) * 16 + qq;
         const unsigned n = __builtin_amdgcn_readlane(cnt[nb], qq);
@@ -210,31 +257,63 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         }
     };
 
-    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    if (a.clk != nullptr && tid == 0) {
+        a.clk[8 * b + 1] = wall_clock64();
+        a.clk[8 * b + 4] = __builtin_readcyclecounter();
+    }
     // Bootstrap of the thresholds.  Without a bound every score of a workgroup's first tiles is a candidate: the buffers
     // of all its queries fill and are sorted several times before the shared bounds take hold (~0.25 ms per pass, a third
-    // of a pass over one of eight shards).  So the workgroup first runs its LAST nboot tiles for their per-query maxima
-    // only (published to the slot table, no candidates), exchanges bounds once, and then scans all its tiles — those nboot
-    // a second time (0.3 % more corpus bytes at 21 M rows).  A slot's value is still the score of a row of the corpus,
-    // distinct slots hold distinct rows: the bound stays valid, and rows that reach it are appended when they come by again.
-    const int nboot = a.share ? (my_tiles < BH_BOOT_TILES ? my_tiles : BH_BOOT_TILES) : 0;
-    const int total = nboot + my_tiles;  // tile ordinals: [0, nboot) bootstrap over tiles my_tiles - nboot .., then all tiles
-    if (my_tiles > 0) {
+    // of a pass over one of eight shards).  So the workgroup first runs nboot tiles for their per-query maxima only
+    // (published to the slot table, no candidates), exchanges bounds, and then scans its tiles.  The bootstrap tiles are
+    // tiles of the workgroup's OWN first run, spread evenly over it (0.3 % more corpus bytes at 21 M rows): a slot's value
+    // is the score of a row that this workgroup — and no other — appends when the scan proper comes by, so distinct slots
+    // still stand for distinct rows and the bound stays valid.
+    const int nboot = !a.share ? 0 : run_len < BH_BOOT_TILES ? run_len : BH_BOOT_TILES;
+    const int boot_step = (run_len / BH_BOOT_TILES > 1 ? run_len / BH_BOOT_TILES : 1) * run_stride;  // in tiles
+    unsigned* lds_claim = reinterpret_cast<unsigned*>(smem + R * STAGE_BYTES);
+    if (run_len > 0) {
         const unsigned char* corpus = reinterpret_cast<const unsigned char*>(a.corpus);
-        int it = 0;  // issue cursor: tile ordinal, stage of the tile, ring slot
+        // issue cursor: the tile it stands on, the tile step and the tiles left of ITS run (phase 0: the bootstrap tiles;
+        // 1: the run the MFMAs are in; 2: the run after it, known by then), stage of the tile, ring slot.  Past the last
+        // run it stays on the last tile: harmless re-fetches, uniform vmcnt arithmetic.
+        int it_phase, it_tile, it_step, it_left;
+        if (nboot > 0) {
+            it_phase = 0;
+            it_tile = run_base;
+            it_step = boot_step;
+            it_left = nboot;
+        } else {
+            it_phase = 1;
+            it_tile = run_base;
+            it_step = run_stride;
+            it_left = run_len;
+        }
         int ip = 0;
         int islot = 0;
         auto issue_line = [&](int j) {
-            const int oc = it < total ? it : total - 1;  // past the end: harmless re-fetch, uniform vmcnt arithmetic
-            const int itc = oc < nboot ? my_tiles - nboot + oc : oc - nboot;
-            const long long tile = b + (long long)itc * G;
-            const unsigned char* src = corpus + (size_t)tile * 32 * ROW_BYTES + (size_t)ip * LS * 128 + ld_off;
+            const unsigned char* src = corpus + (size_t)(unsigned)it_tile * (size_t)(32 * ROW_BYTES) + (size_t)(ip * LS * 128) + ld_off;
             unsigned char* dst = smem + islot * STAGE_BYTES + line0 * 4096 + wr * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 128),
                                              (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, NT ? 2 : 0);
         };
         auto advance_cursor = [&]() {
-            if (++ip == S) { ip = 0; ++it; }
+            if (++ip == S) {
+                ip = 0;
+                if (it_left > 1) {
+                    --it_left;
+                    it_tile += it_step;
+                } else if (it_phase == 0) {  // bootstrap done: the workgroup's first run
+                    it_phase = 1;
+                    it_tile = run_base;
+                    it_step = run_stride;
+                    it_left = run_len;
+                } else if (it_phase == 1 && nxt_len > 0) {
+                    it_phase = 2;
+                    it_tile = nxt_base;
+                    it_step = 1;
+                    it_left = nxt_len;
+                }
+            }
             if (++islot == R) islot = 0;
         };
 #pragma unroll
@@ -258,9 +337,11 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             for (int f = 0; f < NBUF; ++f) ag[f] = qf[0][f];
         }
 
-        for (int o = 0; o < total; ++o) {
-            const bool boot = o < nboot;
-            const int i = boot ? my_tiles - nboot + o : o - nboot;  // tile ordinal of this workgroup
+        bool boot = nboot > 0;
+        int tj = 0;  // tile of the bootstrap / of the current run
+        int i = 0;   // tiles scanned so far (threshold exchange schedule)
+        for (;;) {
+            const int tile_id = run_base + tj * (boot ? boot_step : run_stride);
             // four independent accumulator chains (row block x query block): consecutive MFMAs never share one, so the
             // stream does not depend on the back-to-back forwarding of a single chain (any instruction between two
             // dependent MFMAs costs ~60 cycles: measured 48 instead of 32 cycles per 32x32x16 MFMA in this loop shape)
@@ -329,7 +410,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 advance_cursor();
                 cslot = nslot;
                 if (tl_on && lane == 0) {
-                    bh_u64* rec = a.clk + 2 * G + ((size_t)(wave * BH_TL_TILES + (i - BH_TL_TILE0)) * S + part) * 5;
+                    bh_u64* rec = a.clk + 8 * G + ((size_t)(wave * BH_TL_TILES + (i - BH_TL_TILE0)) * S + part) * 5;
                     rec[0] = tl0;
                     rec[1] = tl1;
                     rec[2] = tl2;
@@ -339,7 +420,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             }
 
             // ---- threshold filter: lane (q16, lg) holds rows 16 rb + 4 lg + v of queries 16 nb + q16
-            const unsigned row0 = ((unsigned)b + (unsigned)i * (unsigned)G) * 32u;  // n_rows < 2^32 (bh_index_create)
+            const unsigned row0 = (unsigned)tile_id * 32u;  // n_rows < 2^32 (bh_index_create)
             // last MFMAs -> VALU reads of their results: the hardware does not interlock these, and the wait must be TIED to the
             // accumulators (a bare asm nop is not ordered against plain register reads: hipcc sank it behind them and the
             // filter saw the last block's scores one k-step short)
@@ -382,7 +463,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             const bool any_hit = !boot && __builtin_amdgcn_ballot_w64(over) != 0ull;
             // (bootstrap: two exchanges, two tiles apart — the first publishes this wave's refinement, the second reads what the
             // other workgroups refined meanwhile, so that the first scanned tile already meets a bound)
-            const bool do_poll = a.share && (boot ? (o == nboot - 1 || o == nboot - 3) : i >= next_poll);
+            const bool do_poll = a.share && (boot ? (tj == nboot - 1 || tj == nboot - 3) : i >= next_poll);
             if (__builtin_expect(any_hit || do_poll || boot, 0)) {
                 if constexpr (!(ABL & 2)) {
                     asm volatile("s_waitcnt lgkmcnt(0)");
@@ -390,6 +471,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     for (int f = 0; f < NBUF; ++f) asm volatile("" : "+v"(ag[f]));
                 }
                 const int lane_c = opaque_lane();
+                const int wave = opaque_wave();  // (shadows the kernel's: cold-path addresses are not hoisted)
                 const int q16 = lane_c & 15, lg = lane_c >> 4;
                 if (boot && row0 + 32u <= n_rows32 && !(ABL & 1)) {
                     // bootstrap tile: this lane's best score of its 8 rows goes to the slot table, nothing else happens
@@ -421,7 +503,6 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     }
                 }
                 if (any_hit) {
-                    ++st_hits;
                     // (1) append survivors (room for 32 entries per query is guaranteed by (2) of the previous visit);
                     //     slot = count + hits of the same query in the lower lane groups.  Hits are rare: the per-row test is
                     //     a fall-through branch, the work sits out of line.
@@ -478,7 +559,6 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                         while (need[nb] != 0ull) {
                             const int qq = __builtin_ctzll(need[nb]);
                             need[nb] &= need[nb] - 1;
-                            ++st_compact;
                             compact(nb, qq);
                         }
                     }
@@ -501,22 +581,20 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     //     per-XCD L2s are not coherent: sc1), and the largest T that 64 slots reach is built bit by bit
                     //     (bits 31..8: a bound a little low is still a bound).  64 slots = 64 workgroups = 64 * RB distinct
                     //     rows at or above T.  (b) the bounds the other workgroups refined: one word per query.
-                    const int sel = (b + npoll) & (16 * NB - 1);
-                    ++npoll;
-                    ++st_poll;
+                    const int sel = (b + i + tj) & (16 * NB - 1);
                     const int qsel = wave * (16 * NB) + sel;
                     unsigned* gbound = a.gthr + (size_t)(128 * NB) * BH_SLOTS256;
                     uintx4 sl;
                     unsigned gb[NB];
-                    asm volatile("global_load_dwordx4 %0, %1, %2 sc1"
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1"
                                  : "=v"(sl)
-                                 : "v"((unsigned)lane_c * 16u), "s"(a.gthr + (size_t)qsel * BH_SLOTS256)
+                                 : "v"((unsigned)lane_c * 16u), "s"(sgpr_ptr(a.gthr + (size_t)qsel * BH_SLOTS256))
                                  : "memory");
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        asm volatile("global_load_dword %0, %1, %2 sc1"
+                        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1"
                                      : "=v"(gb[nb])
-                                     : "v"((unsigned)q16 * 4u), "s"(gbound + (wave * NB + nb) * 16)
+                                     : "v"((unsigned)q16 * 4u), "s"(sgpr_ptr(gbound + (wave * NB + nb) * 16))
                                      : "memory");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("" : "+v"(sl));
@@ -549,6 +627,56 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     }
                 }
             }
+            // ---- next tile
+            ++tj;
+            if (boot) {
+                if (tj == nboot) {
+                    boot = false;
+                    tj = 0;
+                }
+                continue;
+            }
+            ++i;
+            if (i > n_tiles) break;  // (cannot happen: a workgroup never scans more tiles than there are; keeps a logic error from hanging the GPU)
+            if constexpr (DYN) {
+                // The run after the current one: claimed LEAD + 2 tiles before the current run's end by wave 7 (it does not
+                // issue LDS-DMA, its vmcnt is its own; it waits for the answer on the spot — an answer on its way into a
+                // register the compiler allocates is not safe — which holds the workgroup up for ~1.5 us, a handful of
+                // times per launch), parked in LDS, read by every wave one tile later (the rendezvous between make it
+                // visible) — a tile before the issue cursor, up to LEAD tiles ahead, leaves the run.
+                if (dyn && run_len >= CH) {  // (a shorter run is the corpus's last, clipped: nothing follows)
+                    const int left = run_len - tj;
+                    if (left == LEAD + 2 && wave == 7) {
+                        unsigned* ctr = a.gthr + (size_t)BQ * (BH_SLOTS256 + 1);
+                        unsigned got = (unsigned)claim_len;
+                        const unsigned off = 0u;
+                        if (opaque_lane() == 0) {
+                            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %0, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "+v"(got) : "v"(off), "s"(sgpr_ptr(ctr)) : "memory");
+                            *(volatile unsigned*)lds_claim = got;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else if (left == LEAD + 1) {
+                        const unsigned got = *(volatile unsigned*)lds_claim;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragment reads in flight land too: no register moves)
+                        // (the host starts the counter at the first tile of the claimed part of the corpus)
+                        const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane(got);
+                        if (t0 < (unsigned)n_tiles) {
+                            nxt_base = (int)t0;
+                            nxt_len = n_tiles - nxt_base < claim_len ? n_tiles - nxt_base : claim_len;
+                        }
+                        claim_len = claim_len >= 2 * CH ? claim_len >> 1 : CH;
+                    }
+                }
+            }
+            if (tj == run_len) {
+                if (nxt_len == 0) break;
+                run_base = nxt_base;
+                run_stride = 1;
+                run_len = nxt_len;
+                nxt_len = 0;
+                tj = 0;
+                if (it_phase == 2) it_phase = 1;  // (the issue cursor is ahead of the tile just finished: it stands in the new run)
+            }
         }
         // drain: tail re-fetches and the fragment reads still in flight (their registers are dead to the compiler)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -556,11 +684,10 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         for (int f = 0; f < NBUF; ++f) asm volatile("" : "+v"(ag[f]));
     }
 
-    if (a.clk != nullptr && tid == 0) {  // diagnostics: shader cycles and 100 MHz ticks this workgroup's scan loop took
-        a.clk[2 * b] = __builtin_readcyclecounter() - clk0;
-        a.clk[2 * b + 1] = wall_clock64() - rt0;
+    if (a.clk != nullptr && tid == 0) {
+        a.clk[8 * b + 2] = wall_clock64();
+        a.clk[8 * b + 5] = __builtin_readcyclecounter();
     }
-    const unsigned long long t_loop_end = wall_clock64();
 
     // ---- final: every wave sorts its queries' buffers and publishes the best KP.  Once the bounds work a buffer holds a
     // handful of candidates: eight buffers of up to 64 entries are loaded together and sorted side by side (the 21 stages
@@ -601,19 +728,12 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             }
         }
     }
-    if (a.clk != nullptr && tid == 0) {  // diagnostics: 100 MHz stamps of this workgroup's phases + wave 0's cold-path counts
-        unsigned long long* st = a.clk + 2 * G + BH_TL_WORDS + 8 * b;
-        st[0] = t_entry;
-        st[1] = rt0;
-        st[2] = t_loop_end;
-        st[3] = wall_clock64();
-        st[4] = st_hits;
-        st[5] = st_compact;
-        st[6] = st_poll;
+    if (a.clk != nullptr && tid == 0) {
         unsigned tot = 0;
         for (int nb = 0; nb < NB; ++nb)
             for (int qq = 0; qq < 16; ++qq) tot += __builtin_amdgcn_readlane(cnt[nb], qq);
-        st[7] = tot;
+        a.clk[8 * b + 6] = tot;
+        a.clk[8 * b + 3] = wall_clock64();
     }
 }
 
@@ -622,7 +742,8 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
 
 template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int SCHED = 1, int NBUF = PD, int NB = 2>
 static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t stream) {
-    constexpr size_t smem = (size_t)R * 32 * LS * 128;
+    constexpr size_t ring = (size_t)R * 32 * LS * 128;
+    constexpr size_t smem = ring + 16 <= 160 * 1024 ? ring + 16 : ring;  // + the chunk claim word (dynamic tile distribution)
     constexpr bool kProduction = ABL == 0 && LM == 1 && SCHED == 1 && NBUF == PD;
     // the bench-only instantiations exist with the non-temporal stream policy only (compile time)
     const bool nt = a.nontemporal != 0 || !kProduction;

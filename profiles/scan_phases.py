@@ -20,6 +20,10 @@ def main():
     g = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     nq = int(sys.argv[2]) if len(sys.argv) > 2 else 2816
     _lib.init(0)
+    for kv in sys.argv[3:]:
+        k_, v_ = kv.split('=')
+        _lib.set_option(k_, int(v_))
+        print('option', k_, v_)
     dim, k, n_total = 768, 50, 21_000_000
     dev = torch.device("cuda", 0)
     q = bench.make_queries(nq, dim, dev)
@@ -31,10 +35,12 @@ def main():
         ix.search(q, k)
     c = ix.counters()
     grid = c["n_workgroups"]
-    buf = (ctypes.c_uint64 * (grid * 10 + TL_WORDS))()
+    buf = (ctypes.c_uint64 * (grid * 8))()
     n = _lib.lib().bh_debug_scan_timeline(ix._h, buf, len(buf))
     a = np.frombuffer(buf, dtype=np.uint64)[:n].astype(np.int64)
-    st = a[grid * 2 + TL_WORDS:].reshape(grid, 8)
+    w = a[:grid * 8].reshape(grid, 8)
+    # entry, loop start, loop end, exit (100 MHz ticks); candidates wave 0 holds
+    st = np.stack([w[:, 0], w[:, 1], w[:, 2], w[:, 3], w[:, 6]], axis=1)
     t0 = st[:, 0].min()
     us = lambda x: x * 0.01
     print(f"g={g} scan_ms_per_pass={c['scan_ms'] / c['n_passes']:.4f} mhz={c['shader_mhz']:.0f}")
@@ -47,10 +53,9 @@ def main():
     print("tile loop by XCD (b % 8): " + " ".join(f"{loop[x::8].mean():7.1f}" for x in range(8)))
     print("   spread inside an XCD : " + " ".join(f"{loop[x::8].max() - loop[x::8].min():7.1f}" for x in range(8)))
     order = np.argsort(loop)
-    print("slowest workgroups:", [(int(b), round(float(loop[b]), 1), int(st[b, 4])) for b in order[-6:]])
-    print("fastest workgroups:", [(int(b), round(float(loop[b]), 1), int(st[b, 4])) for b in order[:6]])
-    print(f"corr(loop, wave-0 hit tiles) = {np.corrcoef(loop, st[:, 4])[0, 1]:.2f}")
-    print(f"wave 0: hit tiles mean {st[:, 4].mean():.1f}, compactions {st[:, 5].mean():.2f}, polls {st[:, 6].mean():.1f}, candidates held at the end (32 queries) {st[:, 7].mean():.1f}")
+    print("slowest workgroups:", [(int(b), round(float(loop[b]), 1)) for b in order[-6:]])
+    print("fastest workgroups:", [(int(b), round(float(loop[b]), 1)) for b in order[:6]])
+    print(f"wave 0: candidates held at the end (32 queries) {st[:, 4].mean():.1f}")
 
 
 if __name__ == "__main__":

@@ -34,12 +34,12 @@ def main():
     ix.search(q, k)
     c = ix.counters()
     grid = c["n_workgroups"]
-    words = grid * 2 + 8 * TL_TILES * S * 5
+    words = grid * 8 + 8 * TL_TILES * S * 5
     buf = (ctypes.c_uint64 * words)()
     got = _lib.lib().bh_debug_scan_timeline(ix._h, buf, words)
     assert got == words, got
     a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
-    tl = a[grid * 2:].reshape(8, TL_TILES * S, 5)
+    tl = a[grid * 8:].reshape(8, TL_TILES * S, 5)
     t_ref = tl[:, 0, 0].min()
     out = {"ring_variant": rv, "ablate": abl, "scan_ms": c["scan_ms"], "shader_mhz": c["shader_mhz"], "waves": []}
     print(f"scan {c['scan_ms']:.3f} ms, {c['shader_mhz']:.0f} MHz; per wave and stage: start | vmcnt wait | barrier wait | body | dma issue",

@@ -377,6 +377,32 @@ def test_tile256_kernel_dims_and_list_lengths(amd, n, d, nq, k):
     compare.assert_bit_exact(s, i, ws, wi, f"256-query kernel n={n} d={d} nq={nq} k={k}")
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(300001, 768, 40, 50), (300001, 384, 40, 50), (300001, 512, 40, 120), (70001, 384, 300, 50),
+                                      (70001, 512, 100, 200), (100003, 768, 257, 56), (2049 * 32, 768, 64, 50)])
+def test_dynamic_tile_distribution_matches_oracle(amd, n, d, nq, k):
+    """scan_topk256's dynamic tile distribution (option dyn_tiles, default on): the first 7/8 of the corpus round robin and
+    the tail in runs claimed from the pass's counter (>= 300 k rows on 256 workgroups), or — smaller corpora — all of it in
+    claimed chunks of 8 tiles.  Every tile must be scanned exactly once whatever the claim order: bit-exact against the
+    oracle with the option on and off, at every ring geometry that has it (d = 384 / 512 / 768: the LDS-DMA look-ahead is
+    5 / 4 / 2.5 tiles) and with 64 / 128 / 256-entry candidate lists."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(n + d + k)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    try:
+        for dyn in (1, 0, 1):
+            _lib.set_option("dyn_tiles", dyn)
+            s, i = ix.search(q, k)
+            compare.assert_bit_exact(s, i, ws, wi, f"dyn_tiles={dyn} n={n} d={d} nq={nq} k={k}")
+    finally:
+        _lib.set_option("dyn_tiles", 1)
+        ix.close()
+
+
 @pytest.mark.parametrize("k", [50, 56, 120])
 @pytest.mark.parametrize("d", [768, 1024])
 def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
