@@ -344,47 +344,76 @@ def pmc_traffic(path, kernel, n_rows, dim):
     return None
 
 
+class HipEnv:
+    """Where the bench runs: one MI355X per rank, RCCL between the ranks, the HIP library underneath.  bench.py itself only
+    ever builds this one (there is no CPU mode); tests/bench_standin.py drives run() with an oracle-backed stand-in so that
+    the multi-rank control flow (sharding, gather, merge, barrier / max-over-ranks timing) is exercised without GPUs."""
+    backend = "nccl"
+    merge = None  # ShardedSearcher's default: the HIP merge kernel
+    results_to_host = True
+
+    def __init__(self, local_rank):
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.device = torch.device("cuda", local_rank)
+
+    def init_dist(self, rank, world):
+        import torch.distributed as dist
+        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=self.device)
+
+    def init_library(self, args):
+        from bergen_amd import _lib
+        _lib.init(self.local_rank)
+        for name in ("query_tile", "query_split", "pair_window", "share_threshold", "nontemporal"):
+            if getattr(args, name) is not None:
+                _lib.set_option(name, getattr(args, name))
+
+    def make_index(self, n_rows, dim):
+        import bergen_amd
+        return bergen_amd.FlatIndex(n_rows, dim, metric="ip", device=self.local_rank)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
 def main():
     args = parse_args()
+    run(args, HipEnv(int(os.environ.get("LOCAL_RANK", "0"))))
+
+
+def run(args, env):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = env.device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        env.init_dist(rank, world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import bergen_amd
-    from bergen_amd import _lib
-    _lib.init(local_rank)
-    if args.query_tile is not None:
-        _lib.set_option("query_tile", args.query_tile)
-    if args.query_split is not None:
-        _lib.set_option("query_split", args.query_split)
-    if args.pair_window is not None:
-        _lib.set_option("pair_window", args.pair_window)
-    if args.share_threshold is not None:
-        _lib.set_option("share_threshold", args.share_threshold)
-    if args.nontemporal is not None:
-        _lib.set_option("nontemporal", args.nontemporal)
+    env.init_library(args)
+    if world == 1:
+        from bergen_amd import _lib  # (the single-GPU secondary legs switch library options)
 
     dim, k, nq, n_total = args.dim, args.k, args.queries, args.n_rows
     lo, hi = bergen_amd.shard_range(n_total, rank, world)
     queries = make_queries(nq, dim, device)
     t0 = time.perf_counter()
-    ix = bergen_amd.FlatIndex(hi - lo, dim, metric="ip", device=local_rank)
+    ix = env.make_index(hi - lo, dim)
     planted, plant_rows = fill_shard(ix, lo, hi, dim, queries, n_total, device)
     ix.finalize()
-    torch.cuda.synchronize()
+    env.sync()
     build_s = time.perf_counter() - t0
-    searcher = bergen_amd.ShardedSearcher(ix, lo, rank=rank, world_size=world) if world > 1 else None
+    searcher = bergen_amd.ShardedSearcher(ix, lo, rank=rank, world_size=world, merge=env.merge) if world > 1 else None
 
     def step():
         # search_seconds includes the D2H of the result lists (SURVEY §8d): [Q, k] fp32 + int64, 1.7 MB at Q = 2 837
+        if searcher is None and env.results_to_host:
+            r = ix.search(queries, k, host=True)  # the merge kernel writes the lists into pinned host memory
+            return r, r
         r = searcher.search(queries, k) if searcher is not None else ix.search(queries, k)
         if r is not None and r[0] is not None:
             host = (torch.as_tensor(r[0]).cpu(), torch.as_tensor(r[1]).cpu())
@@ -393,10 +422,10 @@ def main():
         return r, host
 
     def barrier():
-        torch.cuda.synchronize()
+        env.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        env.sync()
 
     for _ in range(args.warmup):
         res, res_host = step()
@@ -507,8 +536,8 @@ def main():
                         "avg_launch_ms": cb["scan_ms"] / cb["n_passes"],
                         "roofline_frac": cb["algorithmic_bytes"] / cb["n_passes"] / (cb["scan_ms"] / cb["n_passes"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                         "traffic": pmc_traffic(args.traffic_json, scan_kernel_name(cb["query_tile"]), hi - lo, dim),
-                        "same_results_as_headline": bool(torch.equal(torch.as_tensor(s_alt), torch.as_tensor(res[0])) and
-                                                         torch.equal(torch.as_tensor(i_alt), torch.as_tensor(res[1])))})
+                        "same_results_as_headline": bool(torch.equal(torch.as_tensor(s_alt).cpu(), torch.as_tensor(res[0]).cpu()) and
+                                                         torch.equal(torch.as_tensor(i_alt).cpu(), torch.as_tensor(res[1]).cpu()))})
             except Exception as exc:  # a secondary figure must never cost the headline line
                 out["secondary_error"] = repr(exc)
             finally:

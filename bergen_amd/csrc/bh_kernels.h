@@ -61,7 +61,8 @@ bool bh_scan256_supports(int dim_padded, int kp);
 int bh_scan256_tile(int dim_padded);  // queries per pass: 256, or 128 at d = 1024
 
 struct BhMergeArgs {
-    const bh_u64* partial;   // [G][BQ][KP]
+    const bh_u64* partial;   // [G][BQ][KP] (x passes, pass_stride keys apart)
+    long long pass_stride;   // 0: the launch merges one pass; else keys between the list sets of consecutive passes
     int n_lists;             // G
     int bq;                  // BQ (stride between lists = BQ*KP)
     const _Float16* corpus;  // [*, D]
@@ -77,6 +78,7 @@ struct BhMergeArgs {
     float err_coef;          // 2 d 2^-24 max|x| (bound of |MFMA fp32 score - canonical score| per unit |q|), 0 = no certificate
     unsigned* uncert;        // [nq_tile] out: 1 = not certified (already offset to this tile's first query), or null
     bh_u64* kth_key;         // [nq_tile] out: canonical key (score, row) of the k-th result, or null
+    unsigned* n_uncert;      // host-mapped count of uncertified queries (system-scope atomic), or null
 };
 // merge_rescore.hip: one workgroup per query of the tile
 hipError_t bh_launch_merge_rescore(const BhMergeArgs& a, int kp, int nq_tile, hipStream_t stream);

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/bergen_hip.h"
@@ -96,6 +97,8 @@ struct bh_index {
     DevBuf<bh_u64> clk;  // [grid][8] phase stamps of the last scan launch + the timeline words (diagnostics, scan_topk256.hip)
     float max_norm = 0.f;        // largest row norm (after normalisation for cosine), set by bh_index_finalize
     DevBuf<unsigned> uncert;     // [nq] certificate flags of the last search
+    unsigned* n_uncert_host = nullptr;  // host-mapped count of uncertified queries of the running search
+    unsigned* n_uncert_dev = nullptr;
     DevBuf<bh_u64> kth;          // [nq] canonical key of each query's k-th result
     DevBuf<_Float16> exact_q;    // [BH_EXACT_BATCH][D] uncertified queries gathered for the exact scan
     DevBuf<bh_u64> exact_keys;   // [BH_EXACT_BATCH][BH_EXACT_CAP] + [BH_EXACT_BATCH] thresholds
@@ -116,6 +119,18 @@ struct bh_index {
 };
 
 namespace {
+
+// Wait for a stream by polling it.  hipStreamSynchronize parks the thread once the wait gets long (tens of milliseconds:
+// every search over a whole corpus) and the wake-up costs 1-2 ms, 2 % of the headline search; a search is a blocking call
+// on a thread that has nothing else to do, so it spins (and falls back to the blocking wait after 10 s).
+hipError_t spin_sync(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned n = 0;; ++n) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return hipStreamSynchronize(st);
+    }
+}
 
 void add_interval(std::vector<std::pair<int64_t, int64_t>>& v, int64_t b, int64_t e) {
     v.emplace_back(b, e);
@@ -321,6 +336,8 @@ void bh_index_destroy(bh_index* ix) {
     ix->gthr.release();
     ix->clk.release();
     ix->uncert.release();
+    if (ix->n_uncert_host) (void)hipHostFree(ix->n_uncert_host);
+    ix->n_uncert_host = ix->n_uncert_dev = nullptr;
     ix->kth.release();
     ix->exact_q.release();
     ix->exact_keys.release();
@@ -413,14 +430,26 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     if ((rc = ix->qbuf.ensure((size_t)nq_pad * dp))) return rc;
     if ((rc = ix->cand.ensure((size_t)grid * bq * 2 * kp))) return rc;
     const size_t partial_elems = (size_t)grid * bq * kp;
-    if ((rc = ix->partial.ensure(2 * partial_elems))) return rc;  // two sets: pass p is merged while pass p + 1 is scanned
-    // one threshold slot table per pass (64 KiB at 256 queries): all of them are reset by ONE launch up front instead of one
-    // small launch in front of every scan; the paired-workgroup progress words sit behind the tables
-    const size_t gthr_pass = use256 ? (size_t)bq * (BH_SLOTS256 + 1) + 4 : (size_t)bq * qs_max * 64;  // (+ the claim counter)
+    // Unsplit passes (every kernel but scan_topk.hip's paired workgroups) are merged in GROUPS: the scans of a group run
+    // back to back, then ONE merge launch takes all their queries.  A scan workgroup fills the register file of its CU, so
+    // a merge beside the next pass's scan only ran in the gaps (it delayed the scan's workgroups by its ~60 us, or ran
+    // after them and held up the pass that reuses its lists: 10 % of a pass over an eighth of the corpus), and one
+    // workgroup per query of ONE pass is latency-bound; thousands of them at once are not.  Up to 1 GiB of list sets.
+    const bool grouped = qs_max == 1;
+    const int group = grouped ? (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pass, ((size_t)1 << 30) / (partial_elems * sizeof(bh_u64)))) : 2;
+    if ((rc = ix->partial.ensure((size_t)group * partial_elems))) return rc;  // (paired: two sets, pass p is merged while p + 1 is scanned)
+    // one threshold block per pass (scan_topk256: [bq][256] slots + [bq] bounds + the claim counter; else [bq * qs][64] slots):
+    // all of them are reset by ONE launch up front; the paired-workgroup progress words sit behind the blocks
+    const size_t gthr_pass = use256 ? (size_t)bq * (BH_SLOTS256 + 1) + 4 : (size_t)bq * qs_max * 64;
     if ((rc = ix->gthr.ensure(gthr_pass * (size_t)n_pass + grid))) return rc;
     if ((rc = ix->clk.ensure((size_t)grid * 8 + BH_TL_WORDS, true, ix->stream))) return rc;
     if ((rc = ix->uncert.ensure((size_t)nq_pad))) return rc;
     if ((rc = ix->kth.ensure((size_t)nq_pad))) return rc;
+    if (!ix->n_uncert_host) {  // host-mapped: the merge kernel counts the queries it could not certify straight into host memory
+        HIP_TRY(hipHostMalloc((void**)&ix->n_uncert_host, sizeof(unsigned), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&ix->n_uncert_dev, ix->n_uncert_host, 0));
+    }
+    *ix->n_uncert_host = 0u;
     // |mfma - canonical| <= 2 d 2^-24 |q| |x| for any summation order of d exact products in fp32
     const float err_coef = g_opt.certify ? 2.0f * (float)dp * 5.9604645e-8f * ix->max_norm : 0.f;
 
@@ -434,7 +463,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
 
     hipEvent_t ev_begin = ix->event(0), ev_end = ix->event(1);
     if (!ev_begin || !ev_end) return fail(BH_EHIP, "hipEventCreate failed");
-    for (int p = 0; p < n_pass; ++p)
+    const int n_group = grouped ? (n_pass + group - 1) / group : n_pass;
+    for (int p = 0; p < n_group; ++p)
         if (!ix->event(2 + 4 * p + 3)) return fail(BH_EHIP, "hipEventCreate failed");
 
     HIP_TRY(hipEventRecord(ev_begin, st));
@@ -443,17 +473,14 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)(gthr_pass * (size_t)n_pass), 0x007fffffu, st, use256 ? (long long)gthr_pass : 0,
                                (long long)bq * (BH_SLOTS256 + 1), use256 ? bh_scan256_first_claimed_tile((int)ix->n_tiles, grid, dp) : 0u));
     double alg_bytes = 0;
-    for (int p = 0; p < n_pass; ++p) {
+    auto scan_args = [&](int p, bh_u64* partial_p) {
         const int q0 = passes[p].first, qs = passes[p].second;
-        const int tile = bq * qs;
-        const int nq_tile = std::min(tile, nq - q0);
         BhScanArgs sa;
         sa.corpus = ix->rows;
         sa.n_rows = ix->n_rows;
         sa.n_tiles = ix->n_tiles;
         sa.qtile = ix->qbuf.p + (size_t)q0 * dp;
         sa.cand = ix->cand.p;
-        bh_u64* partial_p = ix->partial.p + (size_t)(p & 1) * partial_elems;
         sa.partial = partial_p;
         sa.gthr = ix->gthr.p + gthr_pass * (size_t)p;
         sa.share = g_opt.share_threshold;
@@ -465,27 +492,18 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         sa.pair_window = g_opt.pair_window;
         sa.dyn_tiles = g_opt.dyn_tiles;
         sa.clk = use256 ? ix->clk.p : nullptr;
-        sa.progress = ix->gthr.p + gthr_pass * (size_t)n_pass;  // [grid] words behind the slot tables
-        if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
-        // this pass overwrites the partial set that pass p - 2 left for its merge: wait for that merge
-        if (p >= 2) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * (p - 2) + 3), 0));
-        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p), st));
-        if (use256)
-            HIP_TRY(bh_launch_scan256(sa, dp, kp, grid, st));
-        else if (use192)
-            HIP_TRY(bh_launch_scan192(sa, dp, kp, grid, st));
-        else
-            HIP_TRY(bh_launch_scan(sa, dp, kp, qw, grid, st));
-        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 1), st));
-        // merge + canonical re-score on the side stream, beside the next pass's scan
-        HIP_TRY(hipStreamWaitEvent(ms, ix->event(2 + 4 * p + 1), 0));
+        sa.progress = ix->gthr.p + gthr_pass * (size_t)n_pass;  // [grid] words behind the threshold blocks
+        return sa;
+    };
+    auto merge_args = [&](int q0, int tile, int n_lists, const bh_u64* partial_p, long long pass_stride) {
         BhMergeArgs ma;
         ma.partial = partial_p;
-        ma.n_lists = grid / qs;
+        ma.pass_stride = pass_stride;
+        ma.n_lists = n_lists;
         ma.bq = tile;
         ma.corpus = ix->rows;
         ma.n_rows = ix->n_rows;
-        ma.qtile = sa.qtile;
+        ma.qtile = ix->qbuf.p + (size_t)q0 * dp;
         ma.dim_padded = dp;
         ma.k = k;
         ma.id_offset = id_offset;
@@ -494,18 +512,58 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         ma.err_coef = err_coef;
         ma.uncert = g_opt.certify ? ix->uncert.p + q0 : nullptr;
         ma.kth_key = g_opt.certify ? ix->kth.p + q0 : nullptr;
-        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 2), ms));
-        HIP_TRY(bh_launch_merge_rescore(ma, kp, nq_tile, ms));
-        HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 3), ms));
-        // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
-        alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + (double)tile * ix->dim * 2.0 + (double)tile * k * 12.0;
+        ma.n_uncert = g_opt.certify ? ix->n_uncert_dev : nullptr;
+        return ma;
+    };
+    auto launch_scan = [&](const BhScanArgs& sa) {
+        if (use256) return bh_launch_scan256(sa, dp, kp, grid, st);
+        if (use192) return bh_launch_scan192(sa, dp, kp, grid, st);
+        return bh_launch_scan(sa, dp, kp, qw, grid, st);
+    };
+    if (grouped) {
+        for (int g0 = 0, gi = 0; g0 < n_pass; g0 += group, ++gi) {
+            const int g1 = std::min(n_pass, g0 + group);
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi), st));
+            for (int p = g0; p < g1; ++p) {
+                HIP_TRY(launch_scan(scan_args(p, ix->partial.p + (size_t)(p - g0) * partial_elems)));
+                // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
+                alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + (double)bq * ix->dim * 2.0 + (double)bq * k * 12.0;
+            }
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 1), st));
+            const int q0 = passes[g0].first;
+            const int nq_group = std::min(nq, passes[g1 - 1].first + bq) - q0;
+            HIP_TRY(bh_launch_merge_rescore(merge_args(q0, bq, grid, ix->partial.p, (long long)partial_elems), kp, nq_group, st));
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 3), st));
+        }
+    } else {
+        for (int p = 0; p < n_pass; ++p) {
+            const int q0 = passes[p].first, qs = passes[p].second;
+            const int tile = bq * qs;
+            const int nq_tile = std::min(tile, nq - q0);
+            bh_u64* partial_p = ix->partial.p + (size_t)(p & 1) * partial_elems;
+            const BhScanArgs sa = scan_args(p, partial_p);
+            if (qs > 1) HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
+            // this pass overwrites the partial set that pass p - 2 left for its merge: wait for that merge
+            if (p >= 2) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * (p - 2) + 3), 0));
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * p), st));
+            HIP_TRY(launch_scan(sa));
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 1), st));
+            // merge + canonical re-score on the side stream, beside the next pass's scan
+            HIP_TRY(hipStreamWaitEvent(ms, ix->event(2 + 4 * p + 1), 0));
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 2), ms));
+            HIP_TRY(bh_launch_merge_rescore(merge_args(q0, tile, grid / qs, partial_p, 0), kp, nq_tile, ms));
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * p + 3), ms));
+            alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + (double)tile * ix->dim * 2.0 + (double)tile * k * 12.0;
+        }
+        // the search ends when the last merges have: bring the side stream back into the main one
+        for (int p = std::max(0, n_pass - 2); p < n_pass; ++p) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * p + 3), 0));
     }
-    // the search ends when the last merges have: bring the side stream back into the main one
-    for (int p = std::max(0, n_pass - 2); p < n_pass; ++p) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * p + 3), 0));
+    HIP_TRY(hipEventRecord(ev_end, st));
+    HIP_TRY(spin_sync(st));
     // ---- exactness: queries the certificate could not prove go through the exact scan (certify.hip)
     int64_t n_uncert = 0;
     double exact_ms = 0;
-    if (g_opt.certify) {
+    if (g_opt.certify && *ix->n_uncert_host != 0u) {
         std::vector<unsigned> flags((size_t)nq);
         HIP_TRY(hipMemcpyAsync(flags.data(), ix->uncert.p, (size_t)nq * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -514,7 +572,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
             if (flags[(size_t)q]) todo.push_back(q);
         n_uncert = (int64_t)todo.size();
         if (!todo.empty()) {
-            hipEvent_t x0 = ix->event(2 + 4 * (size_t)n_pass), x1 = ix->event(3 + 4 * (size_t)n_pass);
+            hipEvent_t x0 = ix->event(2 + 4 * (size_t)n_group), x1 = ix->event(3 + 4 * (size_t)n_group);
             if (!x0 || !x1) return fail(BH_EHIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(x0, st));
             if ((rc = ix->exact_q.ensure((size_t)BH_EXACT_BATCH * dp))) return rc;
@@ -564,9 +622,9 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
                             row_i[(size_t)t] = -1;
                         }
                     }
-                    HIP_TRY(hipMemcpy(out_scores_dev + (size_t)q * k, row_s.data(), (size_t)k * sizeof(float), hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(out_scores_dev + (size_t)q * k, row_s.data(), (size_t)k * sizeof(float), hipMemcpyDefault));  // (the result buffers may be pinned host memory)
                     HIP_TRY(hipMemcpy(reinterpret_cast<long long*>(out_ids_dev) + (size_t)q * k, row_i.data(), (size_t)k * sizeof(long long),
-                                      hipMemcpyHostToDevice));
+                                      hipMemcpyDefault));
                 }
             }
             HIP_TRY(hipEventRecord(x1, st));
@@ -576,8 +634,6 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
             exact_ms = xm;
         }
     }
-    HIP_TRY(hipEventRecord(ev_end, st));
-    HIP_TRY(hipStreamSynchronize(st));
 
     bh_counters& c = ix->counters;
     c.n_rows = ix->n_rows;
@@ -589,16 +645,18 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     c.k_padded = kp;
     c.scan_ms = 0;
     c.merge_ms = 0;
-    for (int p = 0; p < n_pass; ++p) {
+    for (int p = 0; p < n_group; ++p) {
         float ms = 0;
+        // grouped: the group's scans back to back (launch gaps included), then its one merge; paired: per pass, the merge
+        // on the side stream (beside the next pass's scan: not additive with scan_ms)
         HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p), ix->event(2 + 4 * p + 1)));
         c.scan_ms += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p + 2), ix->event(2 + 4 * p + 3)));
-        c.merge_ms += ms;  // (runs beside the next pass's scan: not additive with scan_ms)
+        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p + (grouped ? 1 : 2)), ix->event(2 + 4 * p + 3)));
+        c.merge_ms += ms;
     }
     float tot = 0;
     HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
-    c.total_ms = tot;
+    c.total_ms = tot + exact_ms;
     c.algorithmic_bytes = alg_bytes;
     c.uncertified_queries = n_uncert;
     c.exact_ms = exact_ms;

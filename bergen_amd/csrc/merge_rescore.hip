@@ -29,9 +29,11 @@ __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
     __shared__ u64 lds_worst;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = blockIdx.x;  // query inside the tile
+    const int q = blockIdx.x;  // query of the launch: query q % bq of the launch's pass q / bq (a launch merges one pass, or
+                               // — pass_stride > 0 — a group of passes whose list sets lie pass_stride keys apart)
     const size_t list_stride = (size_t)a.bq * KP;
-    const u64* base = a.partial + (size_t)q * KP;
+    const int pass = a.pass_stride > 0 ? q / a.bq : 0;
+    const u64* base = a.partial + (size_t)pass * (size_t)a.pass_stride + (size_t)(q - pass * a.bq) * KP;
 
     // ---- 1. fold lists wave, wave+4, ...: the heads of 64 lists sit one per lane; the lists whose head can still enter the
     // running best-KP are fetched PF at a time (their latencies overlap) and merged; the running KP-th best of every wave
@@ -167,6 +169,8 @@ __global__ void __launch_bounds__(256) bh_merge_rescore_kernel(BhMergeArgs a) {
                 }
                 a.uncert[q] = certified ? 0u : 1u;
                 a.kth_key[q] = kth;
+                // (host-mapped counter: the host learns "nothing to re-do" from the search's one synchronisation)
+                if (!certified && a.n_uncert != nullptr) __hip_atomic_fetch_add(a.n_uncert, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

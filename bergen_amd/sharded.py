@@ -27,6 +27,14 @@ def shard_range(n_rows, rank, world_size):
     return lo, hi
 
 
+def _takes(fn, name):
+    import inspect
+    try:
+        return name in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class ShardedSearcher:
     """local_index: object with .search(queries, k, id_offset) -> (scores [Q,k] f32, ids [Q,k] i64)
     as torch tensors on `device` (a bergen_amd.FlatIndex fed device tensors does exactly that).
@@ -43,25 +51,61 @@ class ShardedSearcher:
         if merge is None:
             from .index import merge_topk as merge  # HIP kernel; no CPU fallback
         self.merge = merge
+        self._buf = {}
+        self._search_takes_out = _takes(local_index.search, "out")
+        self._merge_takes_out = _takes(merge, "out")
+
+    def _buffers(self, nq, k, device):
+        """Per (nq, k) buffers, allocated once: this rank's packed (scores | ids) lists — the local search writes straight
+        into them —, the gathered lists of all ranks, their dense [G, nq, k] forms for the merge and the merged result."""
+        key = (nq, k, str(device))
+        buf = self._buf.get(key)
+        if buf is None:
+            nbs = nq * k * 4
+            ids_at = (nbs + 7) // 8 * 8  # int64 view needs an 8-byte offset
+            per = ids_at + nq * k * 8
+            packed = torch.empty(per, dtype=torch.uint8, device=device)
+            buf = {
+                "per": per, "ids_at": ids_at, "packed": packed,
+                "scores": packed[:nbs].view(torch.float32).view(nq, k),
+                "ids": packed[ids_at:].view(torch.int64).view(nq, k),
+                "flat": torch.empty(self.world_size * per, dtype=torch.uint8, device=device),
+            }
+            if self.rank == self.dst:
+                buf["all_s"] = torch.empty((self.world_size, nq, k), dtype=torch.float32, device=device)
+                buf["all_i"] = torch.empty((self.world_size, nq, k), dtype=torch.int64, device=device)
+                buf["out"] = (torch.empty((nq, k), dtype=torch.float32, device=device),
+                              torch.empty((nq, k), dtype=torch.int64, device=device))
+            if len(self._buf) >= 4:  # a handful of query-set shapes at most
+                self._buf.pop(next(iter(self._buf)))
+            self._buf[key] = buf
+        return buf
 
     def search(self, queries, k):
-        """All ranks call this with the same queries.  Returns (scores, ids) on rank `dst`, None elsewhere."""
-        scores, ids = self.local_index.search(queries, k, id_offset=self.row_lo)
-        scores = torch.as_tensor(scores)
-        ids = torch.as_tensor(ids)
-        nq = scores.shape[0]
+        """All ranks call this with the same queries.  Returns (scores, ids) on rank `dst`, None elsewhere.  The result
+        tensors are reused by the next search of the same shape: copy them if they must outlive it."""
         if self.world_size == 1:
-            return scores, ids
-        # pack (score, id) into one byte buffer -> a single collective per search
-        packed = torch.cat([scores.contiguous().view(torch.uint8).reshape(-1),
-                            ids.contiguous().view(torch.uint8).reshape(-1)])
-        flat = torch.empty(self.world_size * packed.numel(), dtype=torch.uint8, device=packed.device)
-        dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D in/out: valid for RCCL and gloo
-        gathered = flat.view(self.world_size, packed.numel())
+            scores, ids = self.local_index.search(queries, k, id_offset=self.row_lo)
+            return torch.as_tensor(scores), torch.as_tensor(ids)
+        nq = int(queries.shape[0])
+        device = queries.device if isinstance(queries, torch.Tensor) else torch.device("cpu")
+        buf = self._buffers(nq, k, device)
+        if self._search_takes_out:
+            self.local_index.search(queries, k, id_offset=self.row_lo, out=(buf["scores"], buf["ids"]))
+        else:
+            scores, ids = self.local_index.search(queries, k, id_offset=self.row_lo)
+            buf["scores"].copy_(torch.as_tensor(scores))
+            buf["ids"].copy_(torch.as_tensor(ids))
+        # (score, id) lists in one byte buffer -> a single collective per search
+        dist.all_gather_into_tensor(buf["flat"], buf["packed"], group=self.group)  # 1-D in/out: valid for RCCL and gloo
         if self.rank != self.dst:
             return None
+        gathered = buf["flat"].view(self.world_size, buf["per"])
         nbs = nq * k * 4
-        all_s = gathered[:, :nbs].contiguous().view(torch.float32).reshape(self.world_size, nq, k)
-        all_i = gathered[:, nbs:].contiguous().view(torch.int64).reshape(self.world_size, nq, k)
-        out_s, out_i = self.merge(all_s, all_i)
+        buf["all_s"].view(self.world_size, nq * k).copy_(gathered[:, :nbs].view(torch.float32))
+        buf["all_i"].view(self.world_size, nq * k).copy_(gathered[:, buf["ids_at"]:].view(torch.int64))
+        if self._merge_takes_out:
+            out_s, out_i = self.merge(buf["all_s"], buf["all_i"], out=buf["out"])
+        else:
+            out_s, out_i = self.merge(buf["all_s"], buf["all_i"])
         return torch.as_tensor(out_s), torch.as_tensor(out_i)

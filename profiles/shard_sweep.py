@@ -30,10 +30,14 @@ def main():
         torch.cuda.synchronize()
         reps = 5
         t0 = time.perf_counter()
-        scan = merge = total = 0.0
+        scan = merge = total = t_search = t_d2h = 0.0
         for _ in range(reps):
+            ta = time.perf_counter()
             s, i = ix.search(q, k)
+            tb = time.perf_counter()
             host = (s.cpu(), i.cpu())
+            t_d2h += time.perf_counter() - tb
+            t_search += tb - ta
             c = ix.counters()
             scan += c["scan_ms"]
             merge += c["merge_ms"]
@@ -43,7 +47,8 @@ def main():
         out["shards"].append({"g": g, "rows": hi - lo, "queries_per_s": nq / (wall * 1e-3), "wall_ms": wall,
                               "stream_total_ms": total / reps, "scan_ms": scan / reps, "merge_ms_side_stream": merge / reps,
                               "passes": c["n_passes"], "scan_ms_per_pass": scan / reps / c["n_passes"],
-                              "non_scan_ms": wall - scan / reps, "query_tile": c["query_tile"]})
+                              "non_scan_ms": wall - scan / reps, "search_call_ms": t_search / reps * 1e3, "result_d2h_ms": t_d2h / reps * 1e3,
+                              "query_tile": c["query_tile"]})
         print(out["shards"][-1], file=sys.stderr, flush=True)
         ix.close()
     base = out["shards"][0]["queries_per_s"]

@@ -1,0 +1,55 @@
+"""CPU: bench.py's multi-rank path (`--gpus 2`, launched exactly as the driver launches it, but through
+tests/bench_standin.py: gloo instead of RCCL, an oracle-backed index instead of the HIP one).  Checks the contract of the
+JSON line and that the sharded search reproduces the single-rank result bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra):
+    flags = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-rows", "30011", "--queries", "37", "--no-encoder",
+             "--no-cpu-baseline", "--no-other-kernels", "--no-config5"] + extra
+    script = os.path.join(ROOT, "tests", "bench_standin.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if world == 1:
+        cmd = [sys.executable, script] + flags
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), script] + flags
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_line_of_a_multi_rank_run(world):
+    r = _run(world, [])
+    assert r["n_gpus"] == world and r["steps"] == 2 and r["warmup"] == 1
+    assert r["unit"] == "queries/s" and r["higher_is_better"] is True and r["scaling"] == "strong"
+    assert r["value"] > 0 and abs(r["value"] - 37 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert r["parity_check"] == "pass"          # planted positives on top of the merged lists, sorted scores
+    assert r["config"]["rows_per_gpu"] == -(-30011 // world)
+    assert f"row-shard x{world}" in r["config"]["parallelism"]
+    for key in ("roofline", "kernel_ms_per_step", "uncertified_queries", "vs_baseline", "dtype", "data", "metric"):
+        assert key in r
+
+
+def test_single_rank_standin_agrees():
+    r = _run(1, [])
+    assert r["n_gpus"] == 1 and r["parity_check"] == "pass"

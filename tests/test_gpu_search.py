@@ -490,3 +490,24 @@ def test_tile192_kernel_exact_ties(amd):
                 compare.assert_bit_exact(s, i, ws, wi, f"ties, kernel {kern}, share {share}")
     finally:
         _lib.set_option("scan_kernel", KERNEL_DEFAULT)
+
+
+def test_results_written_to_pinned_host_memory(amd):
+    """search(host=True): the merge kernel (and the exact fall-back) write the lists straight into pinned host memory."""
+    import torch
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((20011, 768)).astype(np.float16)
+    q = rng.standard_normal((300, 768)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, 50)
+    ix = amd.FlatIndex(20011, 768, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    qd = torch.from_numpy(q).cuda()
+    s, i = ix.search(qd, 50, host=True)
+    assert not s.is_cuda and s.is_pinned() and i.is_pinned()
+    compare.assert_bit_exact(s.numpy(), i.numpy(), ws, wi, "host=True")
+    s2, i2 = ix.search(qd[:40], 50, host=True, id_offset=1000)
+    compare.assert_bit_exact(s2.numpy(), i2.numpy() - 1000, ws[:40], wi[:40], "host=True, second shape")
+    with pytest.raises(ValueError):
+        ix.search(q, 50, host=True)
+    ix.close()
