@@ -17,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/bergen_hip.h"
@@ -105,6 +106,9 @@ struct bh_index {
     DevBuf<unsigned> exact_cnt;  // [BH_EXACT_BATCH]
     DevBuf<_Float16> qbuf;
     DevBuf<unsigned char> staging;
+    unsigned char* pinned[2] = {nullptr, nullptr};  // host staging of the load path (upload_common)
+    size_t pinned_cap[2] = {0, 0};
+    hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> events;
     bh_counters counters{};
 
@@ -130,6 +134,23 @@ hipError_t spin_sync(hipStream_t st) {
         if (e != hipErrorNotReady) return e;
         if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return hipStreamSynchronize(st);
     }
+}
+
+// a host-to-host copy on a few threads (one thread moves ~10 GB/s; the PCIe link takes five times that)
+void parallel_memcpy(void* dst, const void* src, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = bytes < (8u << 20) ? 1 : (int)std::min<unsigned>(8u, std::max<unsigned>(1u, hw / 2));
+    if (nt == 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (int t = 0; t < nt; ++t) {
+        const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
+        if (hi > lo) th.emplace_back([=] { memcpy((unsigned char*)dst + lo, (const unsigned char*)src + lo, hi - lo); });
+    }
+    for (auto& t : th) t.join();
 }
 
 void add_interval(std::vector<std::pair<int64_t, int64_t>>& v, int64_t b, int64_t e) {
@@ -164,25 +185,52 @@ int upload_common(bh_index* ix, int64_t row0, const void* src, int64_t n, int32_
     HIP_TRY(hipSetDevice(ix->device));
     const size_t esz = src_dtype == BH_F16 ? 2 : 4;
     _Float16* dst = ix->rows + (size_t)row0 * ix->dim_padded;
-    if (src_dtype == BH_F16 && ix->dim == ix->dim_padded) {
-        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * ix->dim * 2,
-                               src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ix->stream));
-    } else if (src_on_device) {
-        HIP_TRY(bh_launch_convert_rows(src, src_dtype, n, ix->dim, dst, ix->dim_padded, ix->stream));
+    const bool direct = src_dtype == BH_F16 && ix->dim == ix->dim_padded;  // the bytes land as they are
+    if (src_on_device) {
+        if (direct)
+            HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * ix->dim * 2, hipMemcpyDeviceToDevice, ix->stream));
+        else
+            HIP_TRY(bh_launch_convert_rows(src, src_dtype, n, ix->dim, dst, ix->dim_padded, ix->stream));
     } else {
-        // host source needing conversion/padding: stage through HBM in <= 256 MiB pieces
+        // Host source (a chunk file torch.load-ed or mmap-ed into pageable memory: the index load path, reference
+        // modules/retrieve.py:153).  A pageable hipMemcpy stages through the runtime's own small pinned buffers at a few
+        // GB/s; here the block goes through TWO pinned buffers of this index: a few host threads copy piece i + 1 into
+        // one while the DMA engine moves piece i out of the other (and, for fp32 or padded rows, the conversion kernel
+        // reads it from a device staging area).
         const size_t row_bytes = (size_t)ix->dim * esz;
-        int64_t rows_per = std::max<int64_t>(1, (int64_t)((256ull << 20) / row_bytes));
-        rows_per = std::min<int64_t>(rows_per, n);
-        int rc = ix->staging.ensure((size_t)rows_per * row_bytes);
-        if (rc) return rc;
-        for (int64_t r = 0; r < n; r += rows_per) {
+        const size_t piece_bytes = 64ull << 20;
+        const int64_t rows_per = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(piece_bytes / row_bytes)));
+        for (int b = 0; b < 2; ++b) {
+            if (ix->pinned_cap[b] < (size_t)rows_per * row_bytes) {
+                if (ix->pinned[b]) (void)hipHostFree(ix->pinned[b]);
+                ix->pinned[b] = nullptr;
+                ix->pinned_cap[b] = 0;
+                HIP_TRY(hipHostMalloc((void**)&ix->pinned[b], (size_t)rows_per * row_bytes, hipHostMallocDefault));
+                ix->pinned_cap[b] = (size_t)rows_per * row_bytes;
+            }
+            if (!ix->pinned_ev[b]) HIP_TRY(hipEventCreateWithFlags(&ix->pinned_ev[b], hipEventDisableTiming));
+        }
+        if (!direct) {
+            int rc = ix->staging.ensure(2 * (size_t)rows_per * row_bytes);
+            if (rc) return rc;
+        }
+        bool used[2] = {false, false};
+        int64_t piece = 0;
+        for (int64_t r = 0; r < n; r += rows_per, ++piece) {
+            const int b = (int)(piece & 1);
             const int64_t m = std::min<int64_t>(rows_per, n - r);
-            HIP_TRY(hipMemcpyAsync(ix->staging.p, (const unsigned char*)src + (size_t)r * row_bytes,
-                                   (size_t)m * row_bytes, hipMemcpyHostToDevice, ix->stream));
-            HIP_TRY(bh_launch_convert_rows(ix->staging.p, src_dtype, m, ix->dim,
-                                           dst + (size_t)r * ix->dim_padded, ix->dim_padded, ix->stream));
-            HIP_TRY(hipStreamSynchronize(ix->stream));
+            const size_t bytes = (size_t)m * row_bytes;
+            if (used[b]) HIP_TRY(hipEventSynchronize(ix->pinned_ev[b]));  // the DMA out of this buffer has finished
+            parallel_memcpy(ix->pinned[b], (const unsigned char*)src + (size_t)r * row_bytes, bytes);
+            if (direct) {
+                HIP_TRY(hipMemcpyAsync(dst + (size_t)r * ix->dim_padded, ix->pinned[b], bytes, hipMemcpyHostToDevice, ix->stream));
+            } else {
+                unsigned char* stage = ix->staging.p + (size_t)b * (size_t)rows_per * row_bytes;
+                HIP_TRY(hipMemcpyAsync(stage, ix->pinned[b], bytes, hipMemcpyHostToDevice, ix->stream));
+                HIP_TRY(bh_launch_convert_rows(stage, src_dtype, m, ix->dim, dst + (size_t)r * ix->dim_padded, ix->dim_padded, ix->stream));
+            }
+            HIP_TRY(hipEventRecord(ix->pinned_ev[b], ix->stream));
+            used[b] = true;
         }
     }
     HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -344,6 +392,12 @@ void bh_index_destroy(bh_index* ix) {
     ix->exact_cnt.release();
     ix->qbuf.release();
     ix->staging.release();
+    for (int b = 0; b < 2; ++b) {
+        if (ix->pinned[b]) (void)hipHostFree(ix->pinned[b]);
+        if (ix->pinned_ev[b]) (void)hipEventDestroy(ix->pinned_ev[b]);
+        ix->pinned[b] = nullptr;
+        ix->pinned_ev[b] = nullptr;
+    }
     if (ix->rows) (void)hipFree(ix->rows);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;

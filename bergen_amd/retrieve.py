@@ -62,12 +62,18 @@ class Retrieve:
                  device=0,
                  num_workers=4,
                  encode_rank=0,
-                 encode_world=1):
+                 encode_world=1,
+                 resident_on_encode=False):
         # encode_rank / encode_world: multi-GPU encoding.  The reference's only multi-GPU mechanism is
         # torch.nn.DataParallel around the encoder (dense.py:32-35: scatter inputs, re-broadcast every weight and
         # gather [B, T, d] outputs to GPU 0 on every forward).  Here each of `encode_world` processes (one per GPU)
         # encodes a contiguous range of BATCHES of the dataset into the same index folder — no collective; the
         # union of the chunk files is a valid index (same naming, ordering by the integer in the file name).
+        # resident_on_encode (opt-in, single process, dense): while index() encodes the documents, every batch is ALSO
+        # copied device-to-device into the resident HBM index, so that retrieve() searches it without reading the folder
+        # back (the reference writes the chunk files and then loads them again, retrieve.py:110-144 -> 153).  The folder is
+        # written all the same: it is the cache the next run finds.
+        self.resident_on_encode = bool(resident_on_encode)
         self.encode_rank = int(encode_rank)
         self.encode_world = int(encode_world)
         self.continue_batch = continue_batch
@@ -134,13 +140,37 @@ class Retrieve:
         pieces = []
         progress = tqdm(enumerate(loader, start=b_lo), total=b_hi - b_lo, desc=f'Encoding: {self.model.model_name}',
                         file=sys.stderr)
-        for i, batch in progress:
-            if self.continue_batch is not None and i <= self.continue_batch:
-                continue  # resume: batches up to continue_batch were saved by an earlier run
-            pieces.append(self.model(query_or_doc, batch)['embedding'].detach().cpu())
-            if (i != 0 and i % cadence == 0) or i == b_hi - 1:
-                self._flush_chunk(save_path, i, pieces)
-                pieces = []
+        direct = (self.resident_on_encode and query_or_doc == 'doc' and self.encode_world == 1 and self.continue_batch is None
+                  and torch.cuda.is_available() and not getattr(self.model, 'sparse', False) and 'splade' not in self.model.model_name)
+        resident, row = None, 0
+        try:
+            for i, batch in progress:
+                if self.continue_batch is not None and i <= self.continue_batch:
+                    continue  # resume: batches up to continue_batch were saved by an earlier run
+                emb = self.model(query_or_doc, batch)['embedding'].detach()
+                if direct and emb.is_cuda and emb.ndim == 2:
+                    if resident is None:
+                        resident = FlatIndex(len(dataset), emb.shape[1], metric=_metric_of(self.model), device=self.device)
+                    resident.upload(emb.contiguous(), row0=row)  # device to device, no host round trip
+                    row += emb.shape[0]
+                pieces.append(emb.cpu())
+                if (i != 0 and i % cadence == 0) or i == b_hi - 1:
+                    self._flush_chunk(save_path, i, pieces)
+                    pieces = []
+            if resident is not None:
+                if row != len(dataset):
+                    raise IOError(_INCOMPLETE.format(len(dataset) - row))
+                resident.finalize()
+                files = utils.sorted_chunk_files(save_path)
+                signature = (tuple(files), tuple(os.path.getmtime(f) for f in files), len(dataset), _metric_of(self.model))
+                old = self._resident.pop(save_path, None)
+                if old is not None:
+                    old[0].close()
+                self._resident[save_path] = (resident, signature)
+                resident = None
+        finally:
+            if resident is not None:
+                resident.close()
         self.model.model = self.model.model.to('cpu')
 
     def _batch_range(self, n_batches, rank=None):
@@ -211,8 +241,10 @@ class Retrieve:
             raise IOError(_INCOMPLETE.format(dataset_size))
 
         def chunks():
-            for f in tqdm(files, total=len(files), desc='Load embeddings into HBM...'):
-                yield self._dense_chunk(utils.load_chunk(f))
+            # chunk i + 1 is read (mapped) on a worker thread while chunk i goes through the pinned staging buffers
+            loaded = utils.prefetched(files, lambda f: utils.load_chunk(f, mmap=True), depth=1)
+            for emb in tqdm(loaded, total=len(files), desc='Load embeddings into HBM...'):
+                yield self._dense_chunk(emb)
 
         first = utils.load_chunk(files[0])
         dim = first.shape[1]

@@ -24,9 +24,51 @@ def sorted_chunk_files(index_path):
     return sorted(glob.glob(f'{index_path}/*.pt'), key=chunk_sort_key)
 
 
-def load_chunk(path):
-    """torch.load of one embedding_chunk_*.pt (dense fp16 tensor, or sparse COO for SPLADE)."""
+def load_chunk(path, mmap=False):
+    """torch.load of one embedding_chunk_*.pt (dense fp16 tensor, or sparse COO for SPLADE).  mmap=True maps the file
+    instead of reading it into a fresh allocation (the load path copies the rows out of the mapping straight into its pinned
+    staging buffers); files written by an old torch (no zip container) fall back to a plain read."""
+    if mmap:
+        try:
+            return torch.load(path, map_location='cpu', weights_only=True, mmap=True)
+        except (RuntimeError, ValueError):
+            pass
     return torch.load(path, map_location='cpu', weights_only=True)
+
+
+def prefetched(items, load, depth=1):
+    """Yield load(item) for every item, in order, with up to `depth` loads running ahead on a worker thread: reading /
+    deserialising chunk i + 1 overlaps the upload of chunk i (torch.load and the upload both release the GIL)."""
+    import queue
+    import threading
+    items = list(items)
+    q = queue.Queue(maxsize=max(1, depth))
+    stop = threading.Event()
+
+    def work():
+        try:
+            for it in items:
+                if stop.is_set():
+                    return
+                q.put(("ok", load(it)))
+        except BaseException as exc:  # delivered to the consumer
+            q.put(("err", exc))
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    try:
+        for _ in items:
+            kind, val = q.get()
+            if kind == "err":
+                raise val
+            yield val
+    finally:
+        stop.set()
+        while t.is_alive():  # unblock a producer waiting on a full queue
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                t.join(0.01)
 
 
 def load_embeddings(index_path):

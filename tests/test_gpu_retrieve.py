@@ -93,3 +93,67 @@ def test_load_collection_and_retrieve_signature():
     assert e is None and s.dtype == torch.float32 and i.dtype == torch.int64
     with pytest.raises(IOError, match="Missing 5 documents"):
         r.load_collection_and_retrieve(q, [x], 7, dataset_size=705)
+
+
+class _DeviceTableDense(_TableDense):
+    """The same plug-in with its embeddings coming out of the 'encoder' on the GPU, as a real Dense model's do."""
+
+    def __call__(self, query_or_doc, batch):
+        return {"embedding": super().__call__(query_or_doc, batch)["embedding"].cuda()}
+
+
+def test_resident_on_encode_skips_the_read_back(tmp_path, monkeypatch):
+    """resident_on_encode=True: index() copies every encoded batch device-to-device into the resident index while it
+    writes the reference's chunk files; retrieve() then searches without loading the document folder (SURVEY H-4)."""
+    import datasets
+    import bergen_amd
+    from bergen_amd import utils
+    g = torch.Generator().manual_seed(22)
+    n, nq, d, k = 5000, 40, 768, 20
+    d_table = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).half()
+    q_table = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).half()
+    dataset = {
+        "doc": datasets.Dataset.from_dict({"id": [f"doc{i}" for i in range(n)], "content": [str(i) for i in range(n)]}),
+        "query": datasets.Dataset.from_dict({"id": [f"q{i}" for i in range(nq)], "generated_query": [str(i) for i in range(nq)],
+                                             "content": [str(i) for i in range(nq)]}),
+    }
+    q_path, d_path = str(tmp_path / "q_idx"), str(tmp_path / "d_idx")
+    r = bergen_amd.Retrieve(init_args=_DeviceTableDense(q_table, d_table, bergen_amd.DotProduct()), batch_size=256, num_workers=0,
+                            resident_on_encode=True)
+    loaded = []
+    real = utils.load_chunk
+    monkeypatch.setattr(utils, "load_chunk", lambda f, **kw: (loaded.append(f), real(f, **kw))[1])
+    out = r.retrieve(dataset, q_path, d_path, k)
+    assert not any(f.startswith(d_path) for f in loaded), loaded          # the document folder was not read back
+    assert sorted(os.listdir(d_path)) == ["embedding_chunk_19.pt"]        # ... but it was written, in the reference's layout
+    assert torch.equal(torch.load(os.path.join(d_path, "embedding_chunk_19.pt")), d_table)
+    ws, wi = c_oracle.canonical_search(q_table.numpy(), d_table.numpy(), k)
+    got_i = np.array([[int(s[3:]) for s in row] for row in out["doc_id"]])
+    compare.assert_bit_exact(out["score"].numpy(), got_i, ws, wi, "resident_on_encode")
+    r.close()
+    # a fresh Retrieve finds the folder and loads it (mmap + prefetch thread + pinned staging): same result
+    r2 = bergen_amd.Retrieve(init_args=_DeviceTableDense(q_table, d_table, bergen_amd.DotProduct()), batch_size=256, num_workers=0)
+    out2 = r2.retrieve(dataset, q_path, d_path, k)
+    assert any(f.startswith(d_path) for f in loaded)
+    assert torch.equal(out2["score"], out["score"]) and out2["doc_id"] == out["doc_id"]
+    r2.close()
+
+
+@pytest.mark.parametrize("dtype,dim", [(torch.float16, 768), (torch.float32, 768), (torch.float16, 100), (torch.float32, 129)])
+def test_host_upload_through_pinned_staging(dtype, dim):
+    """FlatIndex.upload of pageable host rows: double-buffered pinned staging (several 64 MiB pieces), with and without the
+    fp32 -> fp16 conversion / row padding; the rows must land exactly."""
+    import bergen_amd
+    n = 200_003 if dim >= 512 else 700_001      # > 2 pieces of 64 MiB either way
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(n, dim, generator=g).to(dtype)
+    ix = bergen_amd.FlatIndex(n, dim, metric="ip")
+    ix.upload(x[:1000], row0=0)
+    ix.upload(x[1000:], row0=1000)
+    ix.finalize()
+    q = x[[5, n // 2, n - 1]].half()
+    s, i = ix.search(q.numpy(), 3)
+    ix.close()
+    assert i[:, 0].tolist() == [5, n // 2, n - 1]
+    ws, wi = c_oracle.canonical_search(q.numpy(), x.half().numpy(), 3)
+    compare.assert_bit_exact(s, i, ws, wi, f"pinned staging {dtype} {dim}")

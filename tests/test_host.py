@@ -393,3 +393,34 @@ def test_k_is_validated_before_the_index_is_built(tmp_path):
         r.retrieve(ds, str(tmp_path / "q"), str(tmp_path / "d"), 300)
     assert not built
     assert bergen_amd.FlatIndex.MAX_K == 248 and bergen_amd.SparseIndex.MAX_K == 120
+
+
+def test_prefetched_keeps_order_and_forwards_errors():
+    from bergen_amd import utils
+    assert list(utils.prefetched(range(7), lambda i: i * i, depth=2)) == [i * i for i in range(7)]
+    assert list(utils.prefetched([], lambda i: i)) == []
+
+    def boom(i):
+        if i == 3:
+            raise IOError("chunk 3 is corrupt")
+        return i
+    got = []
+    with pytest.raises(IOError, match="chunk 3"):
+        for v in utils.prefetched(range(6), boom):
+            got.append(v)
+    assert got == [0, 1, 2]
+    # a consumer that stops early must not leave the worker blocked on a full queue
+    it = utils.prefetched(range(100), lambda i: i, depth=1)
+    assert next(it) == 0
+    it.close()
+
+
+def test_load_chunk_mmap_reads_the_same_tensor(tmp_path):
+    import torch
+    from bergen_amd import utils
+    x = torch.randn(100, 16).half()
+    f = str(tmp_path / "embedding_chunk_3.pt")
+    torch.save(x, f)
+    assert torch.equal(utils.load_chunk(f, mmap=True), x) and torch.equal(utils.load_chunk(f), x)
+    torch.save(x, f, _use_new_zipfile_serialization=False)  # legacy container: cannot be mapped, falls back to a read
+    assert torch.equal(utils.load_chunk(f, mmap=True), x)
