@@ -61,7 +61,7 @@ def parse_args():
     p.add_argument("--enc-batch", type=int, default=512, help="sequences per encoder step (retromae.yaml batch_size)")
     p.add_argument("--enc-steps", type=int, default=3)
     p.add_argument("--no-splade", action="store_true", help="skip the SPLADE legs (configs[3]: MLM-head encode, sparse search)")
-    p.add_argument("--splade-docs", type=int, default=4_000_000, help="documents of the synthetic SPLADE corpus (S4)")
+    p.add_argument("--splade-docs", type=int, default=21_000_000, help="documents of the synthetic SPLADE corpus (S4: 21 M, ~180 terms each)")
     p.add_argument("--sweep", action="store_true", help="also time kernel variants (written to gpurun_out/sweep.json)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                    help="optional PMC-derived HBM bytes per scan launch (written by profiles/collect_pmc.py)")
@@ -188,8 +188,9 @@ def splade_legs(args, device_index):
     """BASELINE configs[3] (SPLADE), both halves, as secondary figures beside the headline (N = 1 only):
     * encode: BERT-base + tied masked-LM head over 30 522 terms + max-over-tokens pooling on the encoder leg's batch
       (`BertEncoder.encode_splade`; the [B, T, vocab] logits are never materialised);
-    * search: SURVEY §8d S4 — synthetic CSR corpus (V = 30 522, ~110 terms per document kept, Zipf term ids), 64-query
-      tiles, top-k; roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per tile pass.
+    * search: SURVEY §8d S4 as stated — synthetic CSR corpus of 21 M documents (V = 30 522, Poisson(180) terms per document
+      clipped to [16, 400], Zipf(1.1) term ids drawn without replacement; a 1 M-document block repeated), 64-query tiles,
+      top-k; roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per tile pass.
     Self-check on a 200 k-document slice: both HIP kernels agree bit for bit, canonical order, scores recomputed in numpy."""
     from bergen_amd import BertEncoder, SparseIndex, synth
     out = {}
@@ -223,7 +224,7 @@ def splade_legs(args, device_index):
     del emb
     enc.close()
     V, block = 30522, 1_000_000
-    blk = synth.random_sparse_corpus_fast(min(block, args.splade_docs), V, seed=4)
+    blk = synth.random_sparse_corpus_device(min(block, args.splade_docs), V, seed=4, device=torch.device("cuda", device_index))
     ix = SparseIndex(args.splade_docs, V, device=device_index)
     done = 0
     while done < args.splade_docs:  # the corpus is the block repeated (timing depends on sizes only)

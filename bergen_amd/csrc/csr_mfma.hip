@@ -144,12 +144,27 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     };
     // one super-chunk = SC chunks of 64 entries (6 KiB in flight per wave); the very first one is loaded in a block
     constexpr int SC = 32;
+    constexpr int ST = 8;  // chunks per step: their term-set lookups (and their refills) are issued together
+    // Entries are fetched with BUFFER loads, 16 bytes per lane: the descriptor carries the group's extent, so an entry past
+    // its end reads as 0 without a compare, a branch or 64-bit address arithmetic per load (lane offset in a register that
+    // never changes, chunk offset in a scalar) — with one dword load per lane and chunk the refill was a third of the
+    // vector instructions of the entry loop.  Register j of quad c4 holds entry 256 c4 + 4 lane + j of the super-chunk.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto group_rsrc = [&](const unsigned* eb, unsigned total) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)eb, 0, (int)(total * 4u), 0x00020000);
+    };
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto load_quad = [&](unsigned (&buf)[SC], int c4, __amdgpu_buffer_rsrc_t rs, unsigned sc) {
+        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (sc * SC + c4 * 4) * 256u, 0);
+        buf[c4 * 4 + 0] = t4[0];
+        buf[c4 * 4 + 1] = t4[1];
+        buf[c4 * 4 + 2] = t4[2];
+        buf[c4 * 4 + 3] = t4[3];
+    };
     auto issue_sc = [&](unsigned (&buf)[SC], const unsigned* eb, unsigned total, unsigned sc) {
+        const __amdgpu_buffer_rsrc_t rs = group_rsrc(eb, total);
 #pragma unroll
-        for (int c = 0; c < SC; ++c) {
-            const unsigned idx = (sc * SC + c) * 64 + lane;
-            buf[c] = idx < total ? eb[idx] : 0u;
-        }
+        for (int c4 = 0; c4 < SC / 4; ++c4) load_quad(buf, c4, rs, sc);
     };
     // diagnostics (BH_SPARSE_STATS): cycle counts of the phases of a few sampled waves (s_memtime; perturbs little)
 #ifdef BH_CSR_TIMERS  // diagnostic build (make CXXFLAGS+=-DBH_CSR_TIMERS): the accumulators cost ~16 VGPRs
@@ -209,20 +224,28 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     // kernel was 95 KiB of instructions, more than the 64 KiB instruction cache two CUs share; it is inlined per step.
     auto process_and_refill = [&](unsigned (&buf)[SC], unsigned rel, unsigned total, unsigned sc, const unsigned* nb,
                                   unsigned ntot, unsigned nsc_i) {
+        const __amdgpu_buffer_rsrc_t nrs = group_rsrc(nb, ntot);
 #pragma unroll
-        for (int step = 0; step < SC / 4; ++step) {
-            const unsigned cbase = (sc * SC + step * 4) * 64;
+        for (int step = 0; step < SC / ST; ++step) {
+            const unsigned cbase = (sc * SC + step * ST) * 64;
             if (cbase < total) {        // wave-uniform
                 if (a.ablate & 1) {     // bench-only: stream the entries, no scatter
-                    asm volatile("" ::"v"(buf[step * 4]), "v"(buf[step * 4 + 1]), "v"(buf[step * 4 + 2]), "v"(buf[step * 4 + 3]));
+                    #pragma unroll
+                    for (int c = 0; c < ST; ++c) asm volatile("" ::"v"(buf[step * ST + c]));
                 } else {
+                    // the four term-set lookups of the step first (entries past the group's end are 0: term 0, any word
+                    // will do, the position test below drops them): their LDS latencies overlap instead of adding up —
+                    // looked up one chunk at a time, with two waves per SIMD to hide a ~100-cycle round trip each, this
+                    // test alone was 2.4 of the pass's 6.5 ms on the 21 M-document corpus
+                    unsigned word4[ST];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const unsigned p = cbase + c * 64 + lane;
-                        const unsigned ent = buf[step * 4 + c];
+                    for (int c = 0; c < ST; ++c) word4[c] = bitmap[(buf[step * ST + c] & 0xffffu) >> 5];
+#pragma unroll
+                    for (int c = 0; c < ST; ++c) {
+                        const unsigned p = cbase + (c >> 2) * 256 + 4 * lane + (c & 3);
+                        const unsigned ent = buf[step * ST + c];
                         const unsigned term = ent & 0xffffu;
-                        const unsigned word = bitmap[term >> 5];
-                        const bool hit = p < total && (word & (1u << (term & 31)));
+                        const bool hit = ((word4[c] >> (term & 31)) & 1u) != 0u && p < total;
                         // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them
                         // here would run the document search and the divergent slot lookup / pair walk once per chunk.
                         // They are queued instead (position in the group + entry, compacted by the ballot's prefix
@@ -240,10 +263,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned idx = (nsc_i * SC + step * 4 + c) * 64 + lane;
-                buf[step * 4 + c] = idx < ntot ? nb[idx] : 0u;
-            }
+            for (int c4 = 0; c4 < ST / 4; ++c4) load_quad(buf, step * (ST / 4) + c4, nrs, nsc_i);
         }
     };
 

@@ -140,3 +140,38 @@ def random_sparse_corpus_fast(n_docs, vocab, seed, mean_nnz=180, lo=16, hi=400, 
     w = np.log1p(rng.exponential(1.0, size=term.size)).astype(np.float16)
     w[w == 0] = np.float16(0.01)
     return indptr, term, w
+
+
+def random_sparse_corpus_device(n_docs, vocab, seed, device, mean_nnz=180, lo=16, hi=400, zipf_a=1.1, chunk=8192):
+    """SURVEY §8d S4 as stated, at benchmark size: document lengths ~ Poisson(mean_nnz) clipped to [lo, hi], term ids
+    Zipf(zipf_a) over a permuted vocabulary drawn WITHOUT replacement, weights log1p(Exp(1)) in fp16.  Sampling nnz terms
+    without replacement with probabilities p is taking the nnz smallest of E_i / p_i with E_i ~ Exp(1) (exponential
+    clocks): one [chunk, vocab] draw and a top-`hi` per chunk of documents on the device (`device`: a torch device).
+    Returns numpy CSR (indptr int64, terms int32 ascending inside a document, weights fp16) like random_sparse_corpus."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    nnz = np.clip(rng.poisson(mean_nnz, size=n_docs), lo, min(hi, vocab)).astype(np.int64)
+    p = 1.0 / np.arange(1, vocab + 1) ** zipf_a
+    perm = rng.permutation(vocab)
+    p_of_term = np.empty(vocab)
+    p_of_term[perm] = p / p.sum()
+    inv_p = torch.from_numpy(1.0 / p_of_term).to(device=device, dtype=torch.float32)
+    kmax = int(nnz.max())
+    col = torch.arange(kmax, device=device)
+    terms_out = []
+    for c0 in range(0, n_docs, chunk):
+        m = min(chunk, n_docs - c0)
+        clock = torch.empty((m, vocab), device=device, dtype=torch.float32).exponential_(1.0, generator=g) * inv_p
+        idx = clock.topk(kmax, dim=1, largest=False, sorted=True).indices  # the first nnz of a row: its sample, in draw order
+        keep = col[None, :] < torch.from_numpy(nnz[c0:c0 + m]).to(device)[:, None]
+        srt = idx.masked_fill(~keep, vocab).sort(dim=1).values              # ascending term ids, the dropped slots last
+        terms_out.append(srt[srt < vocab].to(torch.int32).cpu().numpy())
+        del clock, idx, keep, srt
+    terms = np.concatenate(terms_out) if terms_out else np.zeros(0, np.int32)
+    indptr = np.zeros(n_docs + 1, np.int64)
+    np.cumsum(nnz, out=indptr[1:])
+    assert terms.size == indptr[-1]
+    w = np.log1p(rng.exponential(1.0, size=terms.size)).astype(np.float16)
+    w[w == 0] = np.float16(0.01)
+    return indptr, terms, w

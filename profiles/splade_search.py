@@ -1,0 +1,60 @@
+"""SPLADE search (BASELINE configs[3]) on its own: python profiles/splade_search.py [docs] [option=value ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bergen_amd import SparseIndex, _lib, synth  # noqa: E402
+
+
+def main():
+    docs = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+    _lib.init(0)
+    sweep = ("", [None])
+    for kv in sys.argv[2:]:
+        k_, v_ = kv.split("=")
+        if "," in v_:
+            sweep = (k_, [int(x) for x in v_.split(",")])  # e.g. sparse_ablate=0,1,4,16 (bench-only kernel ablations)
+        else:
+            _lib.set_option(k_, int(v_))
+    V, block = 30522, 1_000_000
+    t0 = time.perf_counter()
+    blk = synth.random_sparse_corpus_device(min(block, docs), V, seed=4, device=torch.device("cuda", 0))
+    t_gen = time.perf_counter() - t0
+    ix = SparseIndex(docs, V, device=0)
+    done = 0
+    t0 = time.perf_counter()
+    while done < docs:
+        m = min(len(blk[0]) - 1, docs - done)
+        ix.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
+        done += m
+    ix.finalize()
+    t_up = time.perf_counter() - t0
+    qp, qt, qw = synth.random_sparse_corpus_fast(256, V, seed=5, mean_nnz=24, lo=4, hi=64)
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    for val in sweep[1]:
+        if val is not None:
+            _lib.set_option(sweep[0], val)
+            print(sweep[0], '=', val)
+        ix.search(q[:64], 50)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ix.search(q, 50)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, ix.counters())
+        dt, c = best
+        gbps = c["algorithmic_bytes"] / (c["scan_ms"] * 1e-3) / 1e9
+        print({"docs": docs, "nnz": int(ix.nnz), "gen_s": round(t_gen, 2), "upload_s": round(t_up, 2), "queries_per_s": round(256 / dt, 1),
+               "scan_ms_per_pass": round(c["scan_ms"] / c["n_passes"], 3), "passes": c["n_passes"], "GB_per_s": round(gbps, 1), "frac": round(gbps / 8000, 4),
+               "wall_ms": round(dt * 1e3, 2), "scan_ms": round(c["scan_ms"], 2), "merge_ms": round(c["merge_ms"], 2)})
+    ix.close()
+
+
+if __name__ == "__main__":
+    main()
