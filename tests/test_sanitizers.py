@@ -1,0 +1,128 @@
+"""Sanitizer builds of the library's HOST side (`make -C bergen_amd/csrc asan ubsan`; the C-ABI layer, device code unchanged).
+  * CPU: the no-device API surface (option parsing, argument validation, error strings and error returns) runs clean under
+    AddressSanitizer + UndefinedBehaviorSanitizer;
+  * GPU: index build, multi-pass search with the exact fall-back, sparse search and the encoder run clean end to end under
+    UndefinedBehaviorSanitizer (ROCm's ASan runtime intercepts the HSA allocator and cannot start torch's uninstrumented
+    HIP runtime: "out of memory" at the first device allocation).
+Each case is a subprocess with the sanitizer runtime preloaded and BERGEN_HIP_LIB pointing at the sanitized library; any
+report aborts it (halt_on_error, -fno-sanitize-recover)."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bergen_amd", "csrc")
+ASAN_LIB = os.path.join(ROOT, "bergen_amd", "lib", "asan", "libbergen_hip.so")
+UBSAN_LIB = os.path.join(ROOT, "bergen_amd", "lib", "ubsan", "libbergen_hip.so")
+
+
+def _runtime(name="asan"):
+    hits = glob.glob(f"/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.{name}-x86_64.so")
+    return hits[0] if hits else None
+
+
+def _build():
+    if not os.path.exists("/opt/rocm/bin/hipcc") or _runtime() is None:
+        pytest.skip("hipcc / ASan runtime not installed")
+    out = subprocess.run(["make", "-C", CSRC, f"-j{min(32, os.cpu_count() or 4)}", "asan", "ubsan"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert os.path.exists(ASAN_LIB) and os.path.exists(UBSAN_LIB)
+
+
+def _run(code, gpu=False):
+    env = dict(os.environ, BERGEN_HIP_LIB=UBSAN_LIB if gpu else ASAN_LIB, LD_PRELOAD=_runtime("ubsan_standalone" if gpu else "asan"),
+               PYTHONPATH=ROOT, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "SANITIZED-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr, out.stderr[-3000:]
+
+
+CPU_SURFACE = r'''
+import ctypes, numpy as np
+from bergen_amd import _lib
+lib = _lib.lib()
+assert "asan" in _lib.LIB_PATH and lib.bh_version() >= 130
+for name, good, bad in (("query_tile", 128, 77), ("scan_kernel", 3, 9), ("certify", 1, 5), ("dyn_tiles", 1, 2)):
+    assert lib.bh_set_option(name.encode(), bad) == _lib.BH_EINVAL and name.encode() in lib.bh_last_error()
+    assert lib.bh_set_option(name.encode(), good) == _lib.BH_OK
+assert lib.bh_set_option(b"no_such_option", 1) == _lib.BH_EINVAL
+assert lib.bh_set_option(b"x" * 4000, 1) == _lib.BH_EINVAL           # long names go through the error formatter
+for fn, args in (("bh_index_finalize", (None,)), ("bh_index_rows_uploaded", (None,)), ("bh_sparse_finalize", (None,)),
+                 ("bh_index_upload", (None, 0, None, 0, 0)), ("bh_search", (None, None, 0, 0, 1, 0, None, None)),
+                 ("bh_sparse_search", (None, None, 0, 0, 0, 0, None, None)), ("bh_bench_counters", (None, None))):
+    rc = getattr(lib, fn)(*args)
+    assert rc in (_lib.BH_EINVAL, -1, 0) or rc < 0, (fn, rc)
+lib.bh_index_destroy(None); lib.bh_sparse_destroy(None); lib.bh_encoder_destroy(None)
+# a compute entry point without a device: a clean error, no fallback (numpy buffers are real: the argument checks pass)
+rng = np.random.default_rng(0)
+s = -np.sort(-rng.standard_normal((5, 7, 9)).astype(np.float32), axis=2)
+i = rng.integers(0, 1 << 40, size=(5, 7, 9)).astype(np.int64)
+os_, oi = np.empty((7, 9), np.float32), np.empty((7, 9), np.int64)
+rc = lib.bh_merge_topk(ctypes.c_void_p(s.ctypes.data), ctypes.c_void_p(i.ctypes.data), 5, 7, 9,
+                       ctypes.c_void_p(os_.ctypes.data), ctypes.c_void_p(oi.ctypes.data))
+assert rc == (_lib.BH_OK if lib.bh_device_count() > 0 else _lib.BH_EHIP), (rc, lib.bh_last_error())
+assert lib.bh_device_count() >= 0
+print("SANITIZED-OK")
+'''
+
+GPU_END_TO_END = r'''
+import numpy as np, torch
+import bergen_amd
+from bergen_amd import _lib, synth
+assert "ubsan" in _lib.LIB_PATH
+rng = np.random.default_rng(1)
+# dense: pageable-host upload through the pinned staging (fp32 -> fp16, padded dim), three passes, a near-tie cluster that
+# the certificate must send through the exact fall-back (host-side sort + write-back), results into pinned host memory
+n, d, k = 70001, 500, 50
+x = rng.standard_normal((n, d)).astype(np.float32)
+x[1000:1040] = x[999]
+q = rng.standard_normal((600, d)).astype(np.float16)
+q[0] = x[999].astype(np.float16)
+ix = bergen_amd.FlatIndex(n, d, metric="cos")
+ix.upload(x[:30000], row0=0); ix.upload(torch.from_numpy(x[30000:]).cuda(), row0=30000)
+ix.finalize()
+s, i = ix.search(q, k)
+s2, i2 = ix.search(torch.from_numpy(q).cuda(), k, host=True)
+assert np.array_equal(i, i2.numpy()) and np.array_equal(s.view(np.uint32), s2.numpy().view(np.uint32))
+assert set(range(999, 1040)) >= set(i[0, :30].tolist())
+for kk in (1, 57, 248):
+    ix.search(q[:130], kk)
+try:
+    ix.search(q[:4], 249)
+    raise SystemExit("k = 249 accepted")
+except _lib.BergenHipError:
+    pass
+ix.close()
+# sparse
+ip, t, w = synth.random_sparse_corpus(3000, 30522, seed=2)
+sx = bergen_amd.SparseIndex(3000, 30522)
+sx.upload((ip, t, w)); sx.finalize()
+qp, qt, qw = synth.random_sparse_corpus(70, 30522, seed=3, mean_nnz=24, lo=4, hi=64)
+sx.search(synth.csr_to_dense(qp, qt, qw, 30522).astype(np.float16), 20)
+sx.close()
+# encoder
+cfg = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+           max_position_embeddings=64, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+enc = bergen_amd.BertEncoder(cfg, {a: torch.from_numpy(b) for a, b in synth.random_bert(cfg, seed=4).items()})
+ids = rng.integers(1, 1000, size=(5, 33)).astype(np.int64)
+out = enc.encode_pooled({"input_ids": torch.from_numpy(ids), "attention_mask": torch.ones(5, 33, dtype=torch.int64)}, "cls")
+assert torch.isfinite(torch.as_tensor(out).float()).all()
+enc.close()
+print("SANITIZED-OK")
+'''
+
+
+def test_no_device_api_surface_is_clean_under_asan_ubsan():
+    _build()
+    _run(CPU_SURFACE)
+
+
+@pytest.mark.gpu
+def test_gpu_paths_are_clean_under_asan_ubsan():
+    if not os.path.exists(UBSAN_LIB) or _runtime("ubsan_standalone") is None:
+        pytest.skip("sanitized library not built (make -C bergen_amd/csrc ubsan; it ships with the snapshot)")
+    _run(GPU_END_TO_END, gpu=True)
