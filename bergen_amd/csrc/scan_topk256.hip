@@ -1,31 +1,70 @@
 // scan_topk256.hip — fused inner-product + running top-k scan, 256 queries per corpus pass, two waves per SIMD
-// (option scan_kernel 3; the default wherever the fragments of 32 queries fit 128 + 64 registers: d <= 768).
+// (option scan_kernel 3; the default for d in {384, 512, 768, 1024} and candidate lists of 64 / 128 / 256 entries, i.e.
+// k <= 248; at d = 1024 a wave carries one 16-query block instead of two: 128 queries per pass).
 //
-// Same contract, candidate scheme and canonical re-score as scan_topk.hip (read that header first); same
-// reference lines replaced: torch.mm (models/retrievers/dense.py:81) + torch.topk (modules/retrieve.py:157).
+// Same contract, candidate keys and canonical re-score as scan_topk.hip (read that header first); same reference lines
+// replaced: torch.mm (models/retrievers/dense.py:81) + torch.topk (modules/retrieve.py:157).
 //
-// Why.  With ONE wave per SIMD (scan_topk.hip, scan_topk192.hip) everything a wave does besides MFMAs — the
-// LDS-DMA issue (the wave is blocked ~100 cycles per instruction while the memory pipeline is saturated), the LDS
-// latency after every stage barrier, the threshold filter — leaves the SIMD's matrix pipe idle: a pass costs the
-// SUM of the stream and the matrix work (round-1 finding: 3.0 us per 32-row tile where the stream needs 1.8 and
-// the MFMAs 1.2).  Here the workgroup has 8 waves, two per SIMD, each with the fragments of 32 queries and at
-// most 256 registers:
+// Why.  With ONE wave per SIMD (scan_topk.hip, scan_topk192.hip) everything a wave does besides MFMAs — the LDS-DMA
+// issue (the wave is blocked ~100 cycles per instruction while the memory pipeline is saturated), the LDS latency behind
+// every stage barrier, the threshold filter — leaves the SIMD's matrix pipe idle: a pass costs the SUM of the stream and
+// the matrix work.  Here the workgroup has 8 waves, two per SIMD, each with the query fragments of 32 queries and at most
+// 256 registers:
 //   * 256 queries ride on one pass of the corpus (HBM bytes per query: 1/2 of the 128-query kernel's, 3/4 of the
 //     192-query kernel's); every wave reads every stage from LDS against its own queries;
-//   * whatever blocks one wave (DMA issue, barrier, filter, compaction) is covered by its SIMD partner's MFMAs;
-//   * the LDS-DMA refill is spread over 8 waves (LS/2 instructions per wave and stage instead of LS);
-//   * fragment reads are a rolling pipeline PD fragments deep that never drains: the stage barrier is taken one
-//     stage EARLY (at the top of stage s every wave has waited for its pieces of stage s+1), so the first
-//     fragments of the next stage are requested while the last MFMAs of the current one run — no LDS-latency
-//     bubble behind the barrier.  The reads are inline asm with counted `s_waitcnt lgkmcnt(PD-1)` (hipcc waits
-//     lgkmcnt(0) for builtin loads in this loop shape).
+//   * whatever blocks one wave (DMA issue, rendezvous, filter, candidate code) is covered by its SIMD partner's MFMAs;
+//   * waves 0-3 issue the LDS-DMA refill of a stage in one block right behind the stage's rendezvous, at raised priority
+//     (the matrix pipe serves the two waves of a SIMD by priority, then age);
+//   * the rendezvous of stage s is taken in the MIDDLE of the stage (fragment NF / 2) and waits for the pieces of stage
+//     s + 1: a wave runs from one stage into the next without stopping, fragment reads are a rolling pipeline PD deep
+//     that never drains (inline-asm ds_read_b128 + counted `s_waitcnt lgkmcnt(PD - 1)`; hipcc waits lgkmcnt(0) for
+//     builtin loads in this loop shape).
 //
-// Register budget (launch bounds 512 x 2 -> 256 per lane; hipcc splits the file 128 VGPR + 128 AGPR as soon as an
-// AGPR is used): 48 fragments of 4 registers at d = 768 -> 32 pinned in AGPRs, 16 pinned in VGPRs; 16
-// accumulators, PD x 4 fragment-read registers, addresses and filter state in the remaining 64 VGPRs.
+// MFMA: v_mfma_f32_16x16x32_f16, accumulators updated in place by inline asm (the builtin lets hipcc put the result into
+// a fresh tuple).  A wave owns NB 16-query blocks x 2 row blocks of a 32-row tile = 2 NB independent accumulator chains:
+// two dependent MFMAs on one accumulator lose the back-to-back forwarding as soon as ANY instruction sits between them
+// (measured: 48 instead of 32 cycles per 32x32x16 in this loop shape), independent chains do not care.  The wait states
+// between the tile's last MFMAs and the first VALU read of their results are an asm statement TIED to the accumulators
+// (a bare `s_nop` asm is not ordered against plain register reads: hipcc sank it behind them).
 //
-// LDS image, MFMA shape (v_mfma_f32_32x32x16_f16: lane l = query l & 31, 16 rows), filter, candidate buffers,
-// threshold slot table and exactness argument: scan_topk.hip.
+// Register budget (launch bounds 512 x 2 -> 256 per lane; hipcc splits the file 128 VGPR + 128 AGPR as soon as an AGPR
+// is used): NB * NK32 query fragments of 4 registers (48 at d = 768): the first 32 pinned in the 128 AGPRs (MFMA reads
+// operand B from either file), the rest in VGPRs; 4 NB accumulator registers, PD x 4 fragment-read registers, addresses
+// and filter state in what is left of the 128 VGPRs.  The scalar file is as tight (102): cold-path addresses are derived
+// from OPAQUE copies of the lane / wave index so that hipcc does not hoist ~40 vector and ~20 scalar registers of
+// loop-invariant cold-path values across the tile loop.  tests/test_scan256_isa.py checks the generated code: no
+// scratch and no vector-register moves in the tile loop, nothing touches a fragment register while its read is in flight.
+//
+// Thresholds (filter hints: stale or low means less filtering, never a wrong result — but every bound must be VALID):
+//   * own bound: the workgroup's KP-th best so far (exclusive compare: its rows come in ascending order);
+//   * shared bound of a query: ONE slot per workgroup holds the best score the workgroup has published (RB = KP / 64-th
+//     best of a lane for the longer lists); any T that 64 slots reach is reached by 64 * RB = KP distinct rows of the
+//     corpus.  At every exchange (geometric schedule) a wave REFINES one of its queries — loads the query's 256 slots,
+//     builds the largest such T bit by bit (radix select on ballots), publishes it with atomicMax to the query's bound
+//     word — and reads the bound words of all its queries (the 256 workgroups cover all queries of the pass at every
+//     exchange).  64th largest of 256 per-workgroup maxima ~ the 74th best row seen so far (the 64-slot min-of-max
+//     table of scan_topk.hip: ~300th);
+//   * bootstrap: before scanning, a workgroup runs BH_BOOT_TILES tiles of its own first run for their maxima only,
+//     with two exchanges: the first scanned tile already meets a bound (otherwise every query's buffer fills and is
+//     sorted several times at the start: 0.25 ms per pass, independent of the corpus size).
+// Candidate path: a tile whose maximum beats the threshold appends its survivors to the per-(workgroup, query) buffer
+// (slot = count + hits of the lower lane groups), compaction (bitonic sort, keep KP) when a buffer nears CAP = 2 KP.
+//
+// Tile distribution: round robin over the first 7/8 of the corpus, the tail in runs claimed from a per-pass counter (an
+// atomic add; run lengths halve down to 8 tiles) — the XCDs clock differently under the power limit (3-4 % between
+// them) and a launch ends with its slowest workgroup.  The claim is made by wave 7 (no LDS-DMA: its vmcnt is its own),
+// waited for on the spot (an answer on its way into a compiler-allocated register gets copied while in flight), parked
+// in LDS and picked up by all waves a tile later, before the LDS-DMA issue cursor (up to LEAD tiles ahead) needs it.
+// Not at d = 1024 (the ring takes all 160 KiB of LDS).
+//
+// End of the launch: every wave sorts its queries' buffers (eight 64-key sorts side by side: the shuffles are a latency
+// chain) and writes the workgroup's best KP per query; merge_rescore.hip merges the 256 lists of every query of a GROUP
+// of passes in one launch (index.hip).  Diagnostics: a.clk gets per-workgroup phase stamps (profiles/scan_phases.py) and,
+// in the ABL & 32 instantiation, per-stage stamps of workgroup 0's waves (profiles/scan_timeline.py).
+//
+// Inline-asm VMEM with an "s" pointer operand starts with s_nop 4: the pointer may come out of v_readfirstlane, a VMEM
+// instruction that reads an SGPR written by a VALU instruction needs 5 wait states, and the hazard recognizer does not
+// look into inline asm (this read a stale pointer — address 0 — in one instantiation).
 #include "bh_device.h"
 #include "bh_kernels.h"
 
