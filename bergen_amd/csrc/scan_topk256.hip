@@ -822,29 +822,33 @@ hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int gr
     switch (dim_padded) {
         case 384: return launch256_kp<12, 6, 6, 4>(a, kp, grid, stream);
         case 512: return launch256_kp<16, 4, 9, 4>(a, kp, grid, stream);
-        case 1024: return launch256_kp<32, 4, 10, 4, 1>(a, kp, grid, stream);  // 16 KiB stages x 10 = all 160 KiB of LDS
+        case 1024:
+            if (a.ring_variant == 6) return launch256_kp<32, 4, 10, 4, 1>(a, kp, grid, stream);  // 16 KiB stages x 10: four rendezvous per tile
+            return launch256_kp<32, 8, 5, 4, 1>(a, kp, grid, stream);  // 32 KiB stages x 5 = all 160 KiB of LDS, two rendezvous per tile
         case 768:
             if (kp == 64) {
                 // bench-only: ablations (bit flags, see the kernel) and schedule variants of the headline geometry
                 switch (a.ablate) {
-                    case 1: return launch256_one<24, 64, 6, 6, 4, 1>(a, grid, stream);    // no filter
-                    case 3: return launch256_one<24, 64, 6, 6, 4, 3>(a, grid, stream);    // no filter, no fragment reads
-                    case 7: return launch256_one<24, 64, 6, 6, 4, 7>(a, grid, stream);    // stream only
-                    case 9: return launch256_one<24, 64, 6, 6, 4, 9>(a, grid, stream);    // no filter, no refill
-                    case 11: return launch256_one<24, 64, 6, 6, 4, 11>(a, grid, stream);  // MFMA + rendezvous only
-                    case 32: return launch256_one<24, 64, 6, 6, 4, 32>(a, grid, stream);  // production + timeline stamps
-                    case 33: return launch256_one<24, 64, 6, 6, 4, 33>(a, grid, stream);  // no filter + timeline stamps
+                    case 1: return launch256_one<24, 64, 12, 3, 4, 1>(a, grid, stream);    // no filter
+                    case 3: return launch256_one<24, 64, 12, 3, 4, 3>(a, grid, stream);    // no filter, no fragment reads
+                    case 7: return launch256_one<24, 64, 12, 3, 4, 7>(a, grid, stream);    // stream only
+                    case 9: return launch256_one<24, 64, 12, 3, 4, 9>(a, grid, stream);    // no filter, no refill
+                    case 11: return launch256_one<24, 64, 12, 3, 4, 11>(a, grid, stream);  // MFMA + rendezvous only
+                    case 32: return launch256_one<24, 64, 12, 3, 4, 32>(a, grid, stream);  // production + timeline stamps
+                    case 33: return launch256_one<24, 64, 12, 3, 4, 33>(a, grid, stream);  // no filter + timeline stamps
                     case 0: break;
                     default: return hipErrorInvalidValue;
                 }
                 switch (a.ring_variant) {
-                    case 1: return launch256_one<24, 64, 6, 6, 4, 0, 0, 1>(a, grid, stream);     // all waves load
-                    case 2: return launch256_one<24, 64, 6, 6, 4, 0, 1, 0>(a, grid, stream);     // rendezvous at the stage top, refill spread
+                    case 1: return launch256_one<24, 64, 12, 3, 4, 0, 0, 1>(a, grid, stream);     // all waves load
+                    case 2: return launch256_one<24, 64, 12, 3, 4, 0, 1, 0>(a, grid, stream);     // rendezvous at the stage top, refill spread
                     case 3: return launch256_one<24, 64, 6, 6, 3, 0, 1, 1, 4>(a, grid, stream);  // prefetch distance 3, four buffers
                     case 4: return launch256_one<24, 64, 4, 9, 4>(a, grid, stream);              // 4 lines x 9 stages
+                    case 5: return launch256_one<24, 64, 6, 6, 4>(a, grid, stream);              // 6 lines x 6 stages: two rendezvous per tile (the geometry until mid round 2)
                 }
             }
-            return launch256_kp<24, 6, 6, 4>(a, kp, grid, stream);
+            // a whole 32-row tile per stage, three stages: ONE rendezvous per tile (two with 6 lines x 6 stages: +2.7 % time)
+            return launch256_kp<24, 12, 3, 4>(a, kp, grid, stream);
     }
     return hipErrorInvalidValue;
 }
