@@ -783,7 +783,7 @@ template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int 
 static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t ring = (size_t)R * 32 * LS * 128;
     constexpr size_t smem = ring + 16 <= 160 * 1024 ? ring + 16 : ring;  // + the chunk claim word (dynamic tile distribution)
-    constexpr bool kProduction = ABL == 0 && LM == 1 && SCHED == 1 && NBUF == PD;
+    constexpr bool kProduction = ABL == 0 && (LM == 1 || LM == 0) && SCHED == 1 && NBUF == PD;
     // the bench-only instantiations exist with the non-temporal stream policy only (compile time)
     const bool nt = a.nontemporal != 0 || !kProduction;
     static bool attr_done[2] = {false, false};
@@ -800,12 +800,12 @@ static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t strea
     return hipGetLastError();
 }
 
-template <int NK32, int LS, int R, int PD, int NB = 2>
+template <int NK32, int LS, int R, int PD, int NB = 2, int LM = 1>
 static hipError_t launch256_kp(const BhScanArgs& a, int kp, int grid, hipStream_t stream) {
     switch (kp) {
-        case 64: return launch256_one<NK32, 64, LS, R, PD, 0, 1, 1, PD, NB>(a, grid, stream);
-        case 128: return launch256_one<NK32, 128, LS, R, PD, 0, 1, 1, PD, NB>(a, grid, stream);
-        case 256: return launch256_one<NK32, 256, LS, R, PD, 0, 1, 1, PD, NB>(a, grid, stream);
+        case 64: return launch256_one<NK32, 64, LS, R, PD, 0, LM, 1, PD, NB>(a, grid, stream);
+        case 128: return launch256_one<NK32, 128, LS, R, PD, 0, LM, 1, PD, NB>(a, grid, stream);
+        case 256: return launch256_one<NK32, 256, LS, R, PD, 0, LM, 1, PD, NB>(a, grid, stream);
     }
     return hipErrorInvalidValue;
 }
@@ -840,15 +840,16 @@ hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int gr
                     default: return hipErrorInvalidValue;
                 }
                 switch (a.ring_variant) {
-                    case 1: return launch256_one<24, 64, 12, 3, 4, 0, 0, 1>(a, grid, stream);     // all waves load
+                    case 1: return launch256_one<24, 64, 12, 3, 4, 0, 1, 1>(a, grid, stream);     // waves 0-3 load, at raised priority
                     case 2: return launch256_one<24, 64, 12, 3, 4, 0, 1, 0>(a, grid, stream);     // rendezvous at the stage top, refill spread
                     case 3: return launch256_one<24, 64, 6, 6, 3, 0, 1, 1, 4>(a, grid, stream);  // prefetch distance 3, four buffers
                     case 4: return launch256_one<24, 64, 4, 9, 4>(a, grid, stream);              // 4 lines x 9 stages
                     case 5: return launch256_one<24, 64, 6, 6, 4>(a, grid, stream);              // 6 lines x 6 stages: two rendezvous per tile (the geometry until mid round 2)
                 }
             }
-            // a whole 32-row tile per stage, three stages: ONE rendezvous per tile (two with 6 lines x 6 stages: +2.7 % time)
-            return launch256_kp<24, 12, 3, 4>(a, kp, grid, stream);
+            // a whole 32-row tile per stage, three stages: ONE rendezvous per tile (two with 6 lines x 6 stages: +2.9 % time);
+            // with 12 LDS-DMA instructions per stage all eight waves issue six each (four loader waves x 12: +0.9 % time)
+            return launch256_kp<24, 12, 3, 4, 2, 0>(a, kp, grid, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -125,7 +125,7 @@ def test_headline_kernel_uses_the_whole_register_file_without_scratch(kernels):
         m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
         if m and cur:
             usage[cur][m.group(1).strip()] = int(m.group(2))
-    head = [u for n, u in usage.items() if re.search(r"kernelILi24ELi64ELi12ELi3ELi4ELb[01]ELi0ELi1ELi1ELi4ELi2E", n)]
+    head = [u for n, u in usage.items() if re.search(r"kernelILi24ELi64ELi12ELi3ELi4ELb[01]ELi0ELi0ELi1ELi4ELi2E", n)]
     assert len(head) == 2
     for u in head:
         assert u["ScratchSize"] == 0 and u["Occupancy"] == 2 and u["VGPRs"] <= 128 and u["AGPRs"] <= 128, u
