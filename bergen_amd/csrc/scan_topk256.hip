@@ -844,6 +844,7 @@ hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int gr
                     case 2: return launch256_one<24, 64, 12, 3, 4, 0, 1, 0>(a, grid, stream);     // rendezvous at the stage top, refill spread
                     case 3: return launch256_one<24, 64, 6, 6, 3, 0, 1, 1, 4>(a, grid, stream);  // prefetch distance 3, four buffers
                     case 4: return launch256_one<24, 64, 4, 9, 4>(a, grid, stream);              // 4 lines x 9 stages
+                    case 7: return launch256_one<24, 64, 12, 3, 4, 0, 0, 2>(a, grid, stream);     // refill spread over the second half of the stage
                     case 5: return launch256_one<24, 64, 6, 6, 4>(a, grid, stream);              // 6 lines x 6 stages: two rendezvous per tile (the geometry until mid round 2)
                 }
             }
