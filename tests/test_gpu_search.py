@@ -511,3 +511,23 @@ def test_results_written_to_pinned_host_memory(amd):
     with pytest.raises(ValueError):
         ix.search(q, 50, host=True)
     ix.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(6000, 768, 8300, 10), (4000, 768, 2100, 200), (3000, 1024, 2200, 200)])
+def test_merge_groups_split_at_one_gibibyte_of_lists(amd, n, d, nq, k):
+    """The passes of a search are merged in groups whose per-workgroup lists fit 1 GiB (index.hip): 32 passes of 64-entry
+    lists, 8 passes of 256-entry lists (16 at d = 1024, 128 queries per pass).  These query sets need two groups; the
+    second group reuses the first one's list sets."""
+    rng = np.random.default_rng(n + nq)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    s, i = ix.search(q, k)
+    c = ix.counters()
+    ix.close()
+    per_pass = 256 * c["query_tile"] * c["k_padded"] * 8
+    assert c["n_passes"] * per_pass > (1 << 30), "the case no longer needs two merge groups"
+    compare.assert_bit_exact(s, i, ws, wi, f"two merge groups n={n} d={d} nq={nq} k={k}")
