@@ -531,3 +531,45 @@ def test_merge_groups_split_at_one_gibibyte_of_lists(amd, n, d, nq, k):
     per_pass = 256 * c["query_tile"] * c["k_padded"] * 8
     assert c["n_passes"] * per_pass > (1 << 30), "the case no longer needs two merge groups"
     compare.assert_bit_exact(s, i, ws, wi, f"two merge groups n={n} d={d} nq={nq} k={k}")
+
+
+def test_sharded_searcher_buffers_on_the_device(amd, monkeypatch):
+    """ShardedSearcher on device tensors (the path the 8-GPU bench runs): the local search writes into views of the packed
+    send buffer (FlatIndex.search(out=)), the gathered lists are split into dense [G, nq, k] tensors and merged into
+    preallocated outputs (merge_topk(out=)).  Two shards on one GPU, the collective replaced by a copy."""
+    import torch
+    from bergen_amd import sharded
+    rng = np.random.default_rng(31)
+    n, d, nq, k = 20001, 768, 77, 50      # nq * k odd: the int64 lists start at a padded offset
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    x[15000] = x[100]                     # a tie across the shard boundary
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    qd = torch.from_numpy(q).cuda()
+    shards = []
+    for r in range(2):
+        lo, hi = amd.shard_range(n, r, 2)
+        ix = amd.FlatIndex(hi - lo, d, metric="ip")
+        ix.upload(x[lo:hi])
+        ix.finalize()
+        shards.append((ix, lo))
+    sent = {}
+
+    def fake_gather(flat, packed, group=None):
+        per = packed.numel()
+        sent[fake_gather.rank] = packed.clone()
+        for r, p in sent.items():
+            flat[r * per:(r + 1) * per].copy_(p)
+    monkeypatch.setattr(sharded.dist, "all_gather_into_tensor", fake_gather)
+    s1 = amd.ShardedSearcher(shards[1][0], shards[1][1], rank=1, world_size=2)
+    s0 = amd.ShardedSearcher(shards[0][0], shards[0][1], rank=0, world_size=2)
+    for _ in range(2):                    # second round: the buffers are reused
+        fake_gather.rank = 1
+        assert s1.search(qd, k) is None
+        fake_gather.rank = 0
+        out_s, out_i = s0.search(qd, k)
+        assert out_s.is_cuda and out_i.dtype == torch.int64
+        compare.assert_bit_exact(out_s.cpu().numpy(), out_i.cpu().numpy(), ws, wi, "two shards, device buffers")
+    assert len(s0._buf) == 1
+    for ix, _ in shards:
+        ix.close()
