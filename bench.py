@@ -131,7 +131,8 @@ def cpu_baseline(args, dim, k):
     except Exception:
         model = "unknown"
     return {
-        "value": qps_full, "unit": "queries/s", "cores": cores, "kind": "port",
+        # `cores` = the threads torch was given: every LOGICAL CPU of the box (os.cpu_count(); SMT siblings included)
+        "value": qps_full, "unit": "queries/s", "cores": cores, "cores_are": "logical CPUs = torch intra-op threads", "kind": "port",
         "sample": (f"oracle/ref_port.py (the reference's torch.mm+torch.topk chunk loop, fp32, batch_size_sim=2048, "
                    f"chunks 150016/149504 rows) on Q={nq} x N={n} x d={dim}, best of 3 = {best:.3f} s, "
                    f"scaled x{scale:.1f} linearly in N to N={args.n_rows}; CPU: {model}; torch {torch.__version__}"),
