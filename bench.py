@@ -55,6 +55,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
+    p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg (index folders -> doc-id strings)")
+    p.add_argument("--stage-rows", type=int, default=2_100_000, help="documents of the Retrieve.retrieve-level leg")
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
     p.add_argument("--cpu-sample-queries", type=int, default=1000)
     p.add_argument("--no-encoder", action="store_true", help="skip the passages-encoded/s leg")
@@ -278,6 +280,60 @@ def splade_legs(args, device_index):
     sub.close()
     ix.close()
     return out
+
+
+def retrieve_stage_leg(args, device_index):
+    """The whole stage as RAG.retrieve calls it (reference modules/rag.py:322-330 -> modules/retrieve.py:52-108):
+    `Retrieve.retrieve(dataset, query_folder, doc_folder, k)` on index folders in the reference's layout — read the
+    query embeddings, bring the document folder into HBM (first call) or find it resident (second call), ONE search for
+    the whole query set, map the hit rows to doc-id strings.  A tenth of the headline corpus (the folders are written
+    here, outside the timed calls; the encode half is the encoder leg's business)."""
+    import shutil
+    import tempfile
+
+    import datasets
+
+    import bergen_amd
+    n, nq, dim, k = args.stage_rows, args.queries, args.dim, args.k
+    root = tempfile.mkdtemp(prefix="bergen_stage_")
+    try:
+        q_path, d_path = os.path.join(root, "queries"), os.path.join(root, "docs")
+        os.makedirs(q_path)
+        os.makedirs(d_path)
+        g = torch.Generator().manual_seed(11)
+        block = torch.nn.functional.normalize(torch.randn(150_000, dim, generator=g), dim=1).half()
+        done, i = 0, 0
+        while done < n:  # chunk files named after their last batch, 150 k rows each (the block repeated: sizes matter)
+            m = min(150_000, n - done)
+            i += m // 512 + 1
+            torch.save(block[:m].clone(), os.path.join(d_path, f"embedding_chunk_{i}.pt"))
+            done += m
+        torch.save(torch.nn.functional.normalize(torch.randn(nq, dim, generator=g), dim=1).half(),
+                   os.path.join(q_path, "embedding_chunk_0.pt"))
+        dataset = {"doc": datasets.Dataset.from_dict({"id": [f"d{j}" for j in range(n)]}),
+                   "query": datasets.Dataset.from_dict({"id": [f"q{j}" for j in range(nq)]})}
+
+        class _Plug:  # the folders exist: the model is only asked for its name and similarity
+            model_name = "bench/precomputed"
+            similarity = bergen_amd.DotProduct()
+            model = torch.nn.Identity()
+
+        r = bergen_amd.Retrieve(init_args=_Plug(), batch_size=512, batch_size_sim=2048, num_workers=0, device=device_index)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = r.retrieve(dataset, q_path, d_path, k)
+        cold = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out = r.retrieve(dataset, q_path, d_path, k)
+        warm = time.perf_counter() - t0
+        ok = (tuple(out["score"].shape) == (nq, k) and len(out["doc_id"]) == nq and isinstance(out["doc_id"][0][0], str)
+              and bool((out["score"][:, :-1] >= out["score"][:, 1:]).all()))
+        r.close()
+        return {"workload": f"Retrieve.retrieve: {nq} queries, {n} x {dim} fp16 documents in {len(os.listdir(d_path))} chunk files, top-{k}",
+                "first_call_seconds": cold, "first_call_queries_per_s": nq / cold,
+                "resident_call_seconds": warm, "resident_call_queries_per_s": nq / warm, "shaped_and_sorted": ok}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def config5_leg(args, local_rank, device):
@@ -552,6 +608,12 @@ def run(args, env):
                 out["config5"] = config5_leg(args, local_rank, device)
             except Exception as exc:
                 out["config5"] = {"error": repr(exc)}
+        if world == 1 and not args.no_stage:
+            ix.close()
+            try:
+                out["retrieve_stage"] = retrieve_stage_leg(args, local_rank)
+            except Exception as exc:
+                out["retrieve_stage"] = {"error": repr(exc)}
         if not args.no_encoder and world == 1:
             ix.close()  # the search index is no longer needed: give the HBM back before the encoder leg
             try:

@@ -424,3 +424,30 @@ def test_load_chunk_mmap_reads_the_same_tensor(tmp_path):
     assert torch.equal(utils.load_chunk(f, mmap=True), x) and torch.equal(utils.load_chunk(f), x)
     torch.save(x, f, _use_new_zipfile_serialization=False)  # legacy container: cannot be mapped, falls back to a read
     assert torch.equal(utils.load_chunk(f, mmap=True), x)
+
+
+def test_map_doc_ids_reads_the_arrow_table():
+    """Row indices -> id strings: through the Arrow id column (and the dataset's indices mapping, if any), -1 entries
+    dropped, same strings as the slow route the reference takes (materialise every id, retrieve.py:58,103)."""
+    import datasets
+    import torch
+    from bergen_amd.retrieve import Retrieve
+    n = 5000
+    ds = datasets.Dataset.from_dict({"id": [f"doc-{j}" for j in range(n)], "content": ["x"] * n})
+    rng = np.random.default_rng(3)
+    idx = torch.from_numpy(rng.integers(0, n, size=(17, 9)))
+    want = [[f"doc-{int(v)}" for v in row] for row in idx]
+    assert Retrieve._map_doc_ids(ds, idx) == want
+    assert all(isinstance(v, str) for v in Retrieve._map_doc_ids(ds, idx)[0])
+    # a dataset that carries an indices mapping (select / shuffle / filter)
+    view = ds.select(range(n - 1, -1, -1))
+    assert Retrieve._map_doc_ids(view, idx) == [[f"doc-{n - 1 - int(v)}" for v in row] for row in idx]
+    assert Retrieve._map_doc_ids(view, idx) == [[view[int(v)]["id"] for v in row] for row in idx]
+    # short index: -1 marks "no such row"
+    idx2 = idx.clone()
+    idx2[2, 5:] = -1
+    idx2[4, :] = -1
+    got = Retrieve._map_doc_ids(ds, idx2)
+    assert got[2] == want[2][:5] and got[4] == [] and got[0] == want[0]
+    # anything with an 'id' column
+    assert Retrieve._map_doc_ids({"id": ["a", "b", "c"]}, torch.tensor([[2, 0, -1]])) == [["c", "a"]]
