@@ -37,7 +37,7 @@ bool bh_scan192_supports(int dim_padded, int kp);
 #define BH_TL_TILE0 1200
 #define BH_TL_TILES 6
 #define BH_TL_WORDS (8 * BH_TL_TILES * 2 * 5)
-#define BH_BOOT_TILES 8  /* tiles a workgroup of scan_topk256.hip scans twice to seed the shared score bounds */
+#define BH_BOOT_TILES 4  /* tiles a workgroup of scan_topk256.hip scans twice to seed the shared score bounds */
 // scan_topk256: threshold slots per query (one per workgroup; the bound of a query is the 64th largest) and, behind the
 // slot tables of a pass, one refined bound per query
 #define BH_SLOTS256 256

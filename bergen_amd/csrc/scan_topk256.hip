@@ -304,7 +304,8 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     // of all its queries fill and are sorted several times before the shared bounds take hold (~0.25 ms per pass, a third
     // of a pass over one of eight shards).  So the workgroup first runs nboot tiles for their per-query maxima only
     // (published to the slot table, no candidates), exchanges bounds, and then scans its tiles.  The bootstrap tiles are
-    // tiles of the workgroup's OWN first run, spread evenly over it (0.3 % more corpus bytes at 21 M rows): a slot's value
+    // tiles of the workgroup's OWN first run, spread evenly over it (0.15 % more corpus bytes at 21 M rows; 4 tiles measured best: 2 / 3 / 4 / 8 / 16 give 1.043 / 1.034 / 1.040 / 1.071 /
+    // 1.166 ms per pass over an eighth of the corpus, 7.22 / - / 7.21 / 7.23 / 7.29 ms over all of it): a slot's value
     // is the score of a row that this workgroup — and no other — appends when the scan proper comes by, so distinct slots
     // still stand for distinct rows and the bound stays valid.
     const int nboot = !a.share ? 0 : run_len < BH_BOOT_TILES ? run_len : BH_BOOT_TILES;
