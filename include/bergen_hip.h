@@ -109,7 +109,10 @@ void bh_index_destroy(bh_index* ix);
 int bh_search(bh_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k,
               int64_t id_offset, float* out_scores, int64_t* out_ids);
 /* Same with DEVICE-resident queries and outputs (feeds the RCCL all-gather without a host
- * round trip). */
+ * round trip).  The output buffers may also be PINNED HOST memory (hipHostMalloc / torch pin_memory): the merge kernel
+ * then writes the result lists there itself and no device-to-host copy follows.  Synchronous: the lists are complete on
+ * return.  Every query's top-k is proven exact from the scan's candidate lists by a certificate; queries it cannot prove
+ * are re-done by an exact fp64 scan inside the call (bh_counters.uncertified_queries / exact_ms; option "certify"). */
 int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k,
                      int64_t id_offset, float* out_scores_dev, int64_t* out_ids_dev);
 
@@ -125,17 +128,20 @@ int bh_merge_topk_device(const float* scores_dev, const int64_t* ids_dev, int32_
 /* Counters of the last search on this index. */
 int bh_bench_counters(const bh_index* ix, bh_counters* out);
 
-/* Diagnostics: copies up to max_words 64-bit words of the last scan launch's clock / timeline record (per workgroup:
- * shader cycles, 100 MHz ticks; then, with option "ablate" 5, workgroup 0's per-wave stage stamps — layout in
- * bergen_amd/csrc/bh_kernels.h) into `out`; returns the number of words written or a negative error code. */
+/* Diagnostics: copies up to max_words 64-bit words of the last scan launch's record (scan_topk256.hip: 8 words per
+ * workgroup — 100 MHz ticks at entry / loop start / loop end / exit, shader cycles at loop start / end, candidates held —
+ * then, with option "ablate" 32, workgroup 0's per-wave stage stamps; layout in bergen_amd/csrc/bh_kernels.h) into
+ * `out`; returns the number of words written or a negative error code. */
 int64_t bh_debug_scan_timeline(const bh_index* ix, uint64_t* out, int64_t max_words);
 
 /* Tuning knobs (process-wide; bench sweeps and A/B comparisons; results are identical for every valid setting).
  * Dense scan: "query_tile" (128|256), "share_threshold" (0|1), "nontemporal" (0|1), "dma_interleave" (0|1, default 1),
  * "query_split" (1|2: paired workgroups share the corpus stream through L2), "pair_window" (0..64), "scan_kernel"
- * (3 = 256-query tile, two waves per SIMD, where it applies [d in {384, 512, 768}] else the 4-wave kernel, default;
- * 2 = 192-query tile where it applies [d = 768, k <= 56]; 0 = 4-wave kernel, 128-query tile), "ring_variant" (0..7:
- * bench-only variants of the selected kernel).  Sparse scan: "sparse_kernel"
+ * (3 = 256-query tile [128 at d = 1024], two waves per SIMD, where it applies [d in {384, 512, 768, 1024}] else the
+ * 4-wave kernel, default; 2 = 192-query tile where it applies [d = 768, k <= 56]; 0 = 4-wave kernel, 128-query tile),
+ * "dyn_tiles" (0|1, default 1: the last eighth of the corpus is handed out by a claim counter), "certify" (0|1, default
+ * 1: exactness certificate + exact fall-back scan), "ring_variant" (0..7: bench-only variants of the selected kernel).
+ * Sparse scan: "sparse_kernel"
  * (1 = csr_mfma.hip, default; 0 = csr_topk.hip).  Encoder GEMM: "gemm_stagger_phases", "gemm_stagger_pct".
  * "ablate" / "sparse_ablate" switch parts of the kernels OFF for profiling: results are INVALID while they are set. */
 int bh_set_option(const char* name, int64_t value);
