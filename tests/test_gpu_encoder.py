@@ -347,3 +347,44 @@ def test_encoder_large_batch():
     ref = bert_oracle.encode(sd, cfg, ids, mask, types, pooler="mean")
     _check_embeddings(got, ref, "large batch")
     enc.close()
+
+
+def test_encoder_with_outlier_features_against_oracle():
+    """Trained BERT-family checkpoints carry a few 'massive' hidden features (LayerNorm gains / biases an order of
+    magnitude above the rest, present at every layer) and attention heads with very peaked softmax; seeded random
+    weights have neither.  Inject both into the random weights and hold the fp16-storage / fp32-accumulate forward pass
+    to the oracle — with the error bound taken over the ORDINARY features too, so that an outlier of 20 cannot hide an
+    error of 0.5 on a feature of size 1."""
+    cfg = dict(vocab_size=2000, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=256, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=51)
+    hot = [77, 308, 381]                      # the outlier features
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)
+    names = ["embeddings.LayerNorm"] + [f"encoder.layer.{l}.{n}" for l in range(12) for n in ("attention.output.LayerNorm", "output.LayerNorm")]
+    for n in names:
+        w, b = sd[n + ".weight"].copy(), sd[n + ".bias"].copy()
+        w[hot] *= np.array([12.0, -9.0, 15.0], np.float32)
+        b[hot] += np.array([8.0, -6.0, 11.0], np.float32)
+        sd[n + ".weight"], sd[n + ".bias"] = f16(w), f16(b)
+    for l in range(12):
+        p = f"encoder.layer.{l}."
+        sd[p + "output.dense.bias"][hot] += np.array([5.0, -4.0, 3.0], np.float32)
+        sd[p + "output.dense.bias"] = f16(sd[p + "output.dense.bias"])
+        q = sd[p + "attention.self.query.weight"].copy()
+        q[:64] *= 6.0                          # head 0: logits six times larger -> near one-hot attention
+        sd[p + "attention.self.query.weight"] = f16(q)
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=5, max_len=90, seed=52)
+    ref_h = bert_oracle.bert_forward(sd, cfg, ids, mask, types)
+    assert np.abs(ref_h[..., hot]).max() > 10 * np.abs(np.delete(ref_h, hot, axis=-1)).mean()   # the outliers are there
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(types)}
+    for mode, ref in (("cls", bert_oracle.cls_pool(ref_h)), ("mean", bert_oracle.mean_pool(ref_h, mask))):
+        got = enc.encode_pooled(kw, mode).float().cpu().numpy().astype(np.float64)
+        _check_embeddings(torch.from_numpy(got), ref, f"outliers, {mode}")
+        ordinary = np.ones(768, bool)
+        ordinary[hot] = False
+        err = np.abs(got - ref)
+        bound = 3e-2 * np.abs(ref[:, ordinary]).max()
+        assert err[:, ordinary].max() <= bound, f"{mode}: ordinary features off by {err[:, ordinary].max():.4g} (bound {bound:.4g})"
+        assert (err[:, hot] <= 3e-2 * np.abs(ref[:, hot]).max()).all(), f"{mode}: outlier features off by {err[:, hot].max():.4g}"
+    enc.close()
