@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                     #pragma unroll
                     for (int c = 0; c < ST; ++c) asm volatile("" ::"v"(buf[step * ST + c]));
                 } else {
-                    // the four term-set lookups of the step first (entries past the group's end are 0: term 0, any word
-                    // will do, the position test below drops them): their LDS latencies overlap instead of adding up —
+                    // the term-set lookups of the step first (entries past the group's end are 0: the reserved id): their LDS
+                    // latencies overlap instead of adding up —
                     // looked up one chunk at a time, with two waves per SIMD to hide a ~100-cycle round trip each, this
                     // test alone was 2.4 of the pass's 6.5 ms on the 21 M-document corpus
                     unsigned word4[ST];
@@ -245,7 +245,8 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                         const unsigned p = cbase + (c >> 2) * 256 + 4 * lane + (c & 3);
                         const unsigned ent = buf[step * ST + c];
                         const unsigned term = ent & 0xffffu;
-                        const bool hit = ((word4[c] >> (term & 31)) & 1u) != 0u && p < total;
+                        // (no position test: an entry past the group's end reads as 0 = stored id 0, whose bit is never set)
+                        const bool hit = ((word4[c] >> (term & 31)) & 1u) != 0u;
                         // Hits are rare per chunk (a few of 64 lanes) but nearly every chunk has one: resolving them
                         // here would run the document search and the divergent slot lookup / pair walk once per chunk.
                         // They are queued instead (position in the group + entry, compacted by the ballot's prefix

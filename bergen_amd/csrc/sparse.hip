@@ -104,7 +104,8 @@ int bh_sparse_create(bh_sparse_index** out, int64_t n_rows, int32_t vocab) {
     if (!out) return bh_fail(BH_EINVAL, "null out");
     *out = nullptr;
     if (n_rows < 0 || n_rows >= 0xffffffffll) return bh_fail(BH_EINVAL, "n_rows %lld out of range", (long long)n_rows);
-    if (vocab <= 0 || vocab > 65536) return bh_fail(BH_EUNSUPPORTED, "vocab %d unsupported (1..65536: term ids are 16-bit)", vocab);
+    // (entries store term + 1 in 16 bits: id 0 is "no term" — what a load past a document group's end returns)
+    if (vocab <= 0 || vocab > 65535) return bh_fail(BH_EUNSUPPORTED, "vocab %d unsupported (1..65535: stored term ids are 16-bit, 0 is reserved)", vocab);
     int dev = 0;
     BH_HIP_TRY(hipGetDevice(&dev));
     hipDeviceProp_t prop;
@@ -194,12 +195,12 @@ int bh_sparse_upload_csr(bh_sparse_index* ix, int64_t row0, int64_t n, const int
             const unsigned short hb = val_dtype == BH_F16 ? v16[i] : f32_to_f16_bits(v32[i]);
             if ((hb & 0x7fffu) == 0) continue;  // +-0
             if (hb & 0x8000u) ix->nonneg_docs = false;
-            packed.push_back((unsigned)t | ((unsigned)hb << 16));
+            packed.push_back((unsigned)(t + 1) | ((unsigned)hb << 16));  // stored id = term + 1
         }
         std::sort(packed.begin() + start, packed.end(), [](unsigned x, unsigned y) { return (x & 0xffffu) < (y & 0xffffu); });
         for (size_t i = start + 1; i < packed.size(); ++i)
             if ((packed[i] & 0xffffu) == (packed[i - 1] & 0xffffu))
-                return bh_fail(BH_EINVAL, "duplicate term %u in row %lld (coalesce the tensor first)", packed[i] & 0xffffu,
+                return bh_fail(BH_EINVAL, "duplicate term %u in row %lld (coalesce the tensor first)", (packed[i] & 0xffffu) - 1u,
                                (long long)(row0 + r));
         rp[(size_t)r] = ix->nnz + (long long)packed.size();
     }
@@ -242,7 +243,10 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     if (nq == 0) return BH_OK;
     if (!q_host || !out_scores || !out_ids) return bh_fail(BH_EINVAL, "null buffer");
     BH_HIP_TRY(hipSetDevice(ix->device));
-    const int V = ix->vocab, n_words = (V + 31) / 32;
+    // Internally the vocabulary is the caller's shifted by one: stored id = term + 1, id 0 never occurs in a document or a
+    // query.  A buffer load past the end of a document group returns 0, i.e. id 0, whose term-set bit is never set: the
+    // scan needs no position test per entry (csr_mfma.hip).
+    const int Vu = ix->vocab, V = Vu + 1, n_words = (V + 31) / 32;
     const int off_prefix = n_words * 4;
     const int off_w = (off_prefix + n_words * 2 + 15) / 16 * 16;
     const int max_slots = (kLdsBytes - 256 - off_w) / 128 - 1;
@@ -275,25 +279,25 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     for (int q = 0; q < nq; ++q) {
         auto& out = qnz[(size_t)q];
         if (q_dtype == BH_F16) {  // the rows are almost all zeros: skip them eight bytes at a time
-            const unsigned short* row = q16 + (size_t)q * V;
+            const unsigned short* row = q16 + (size_t)q * Vu;
             int t = 0;
-            for (; t < V && ((uintptr_t)(row + t) & 7u); ++t)
-                if (row[t] & 0x7fffu) out.emplace_back(t, row[t]);
-            for (; t + 4 <= V; t += 4) {
+            for (; t < Vu && ((uintptr_t)(row + t) & 7u); ++t)
+                if (row[t] & 0x7fffu) out.emplace_back(t + 1, row[t]);
+            for (; t + 4 <= Vu; t += 4) {
                 unsigned long long w;
                 memcpy(&w, row + t, 8);
                 if ((w & 0x7fff7fff7fff7fffull) == 0) continue;
                 for (int u = 0; u < 4; ++u)
-                    if (row[t + u] & 0x7fffu) out.emplace_back(t + u, row[t + u]);
+                    if (row[t + u] & 0x7fffu) out.emplace_back(t + u + 1, row[t + u]);
             }
-            for (; t < V; ++t)
-                if (row[t] & 0x7fffu) out.emplace_back(t, row[t]);
+            for (; t < Vu; ++t)
+                if (row[t] & 0x7fffu) out.emplace_back(t + 1, row[t]);
         } else {
-            const float* row = q32 + (size_t)q * V;
-            for (int t = 0; t < V; ++t) {
+            const float* row = q32 + (size_t)q * Vu;
+            for (int t = 0; t < Vu; ++t) {
                 if (row[t] == 0.0f) continue;  // (+-0)
                 const unsigned short b = f32_to_f16_bits(row[t]);
-                if (b & 0x7fffu) out.emplace_back(t, b);
+                if (b & 0x7fffu) out.emplace_back(t + 1, b);
             }
         }
     }
@@ -361,8 +365,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     bh_counters& c = ix->counters;
     c = bh_counters{};
     c.n_rows = ix->n_rows;
-    c.dim = V;
-    c.dim_padded = V;
+    c.dim = Vu;
+    c.dim_padded = Vu;
     c.n_workgroups = grid;
     c.k_padded = kp;
     c.query_tile = kTileQ;

@@ -61,7 +61,7 @@ def _csr_from_any(rows, vocab):
 
 
 class SparseIndex:
-    """n_rows documents x vocab terms (<= 65536), fp16 weights, resident on one MI355X."""
+    """n_rows documents x vocab terms (<= 65535), fp16 weights, resident on one MI355X."""
 
     MAX_K = 120  # candidate lists of 64 / 128 entries with a margin of 8 (csrc/sparse.hip: pick_kp_sparse)
 

@@ -249,7 +249,7 @@ int bh_gemm_permlane_mode(void);
 
 typedef struct bh_sparse_index bh_sparse_index;
 
-/* n_rows documents over a vocabulary of `vocab` terms (<= 65536), weights stored as fp16 (the
+/* n_rows documents over a vocabulary of `vocab` terms (<= 65535: stored ids are 16-bit, 0 is reserved), weights stored as fp16 (the
  * reference stores fp16 sparse COO chunks, modules/retrieve.py:138-139).  Replaces the host
  * list of sparse chunk tensors of reference modules/retrieve.py:84-90. */
 int bh_sparse_create(bh_sparse_index** out, int64_t n_rows, int32_t vocab);

@@ -48,7 +48,7 @@ def test_golden_fixture(amd):
 
 
 @pytest.mark.parametrize("n,V,nq,k,qnnz", [(5000, 30522, 70, 50, 24), (300, 1000, 5, 10, 6), (20000, 30522, 130, 100, 40),
-                                           (40, 65536, 3, 56, 10), (3000, 5000, 64, 120, 200)])
+                                           (40, 65535, 3, 56, 10), (3000, 5000, 64, 120, 200)])
 def test_random_matches_oracle(amd, n, V, nq, k, qnnz):
     dp, dt, dw = synth.random_sparse_corpus(n, V, seed=n + k, mean_nnz=min(120, V // 8), lo=0, hi=min(300, V // 3))
     qp, qt, qw = synth.random_sparse_corpus(nq, V, seed=n + 7, mean_nnz=qnnz, lo=1, hi=min(4 * qnnz, V // 3))
