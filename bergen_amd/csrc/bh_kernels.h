@@ -45,15 +45,15 @@ bool bh_scan192_supports(int dim_padded, int kp);
 // in flight at d = 768, 4 at d = 512, 5 at d = 384: a run must outlast the look-ahead by two tiles); the pass's claim counter
 // sits behind its bounds
 __host__ __device__ constexpr int bh_scan256_chunk_tiles(int /*dim_padded*/) { return 8; }
-// tiles per workgroup that go round robin before the claimed part of the corpus starts (0: all of it is claimed in chunks,
-// chunk b first: the counter starts at tile grid * chunk); shared by the kernel and the host
+// tiles per workgroup that go round robin before the claimed part of the corpus starts (0: the corpus is too small, everything
+// stays round robin); shared by the kernel and the host
 __host__ __device__ inline int bh_scan256_round_robin_tiles(int n_tiles, int grid, int dim_padded) {
     const int rr = (int)(((long long)n_tiles * 7 / 8) / grid);
     return rr >= 4 * bh_scan256_chunk_tiles(dim_padded) ? rr : 0;
 }
 __host__ __device__ inline unsigned bh_scan256_first_claimed_tile(int n_tiles, int grid, int dim_padded) {
     const int rr = bh_scan256_round_robin_tiles(n_tiles, grid, dim_padded);
-    return rr > 0 ? (unsigned)rr * (unsigned)grid : (unsigned)grid * (unsigned)bh_scan256_chunk_tiles(dim_padded);
+    return rr > 0 ? (unsigned)rr * (unsigned)grid : 0u;  // (0: never read)
 }
 // scan_topk256.hip (8 waves, two per SIMD, 256 queries per pass; d in {384, 512, 768})
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);

@@ -187,22 +187,17 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     //             share of the tail down to CH tiles).  Workgroups do not run at one speed (the XCDs clock differently
     //             under the power limit: 3-4 % between them, plus the luck of the candidate path: +-5 % over an eighth
     //             of the corpus), and a launch ends with its slowest workgroup.  A corpus too small for a round-robin
-    //             run of 4 CH tiles is all chunks of CH: chunk b first, the counter hands out the tiles from G * CH on.
-    const bool dyn = DYN && a.dyn_tiles != 0;
+    //             run of 4 CH tiles (< 300 k rows on 256 workgroups) stays static: chunks of CH tiles would balance it
+    //             worse than round robin does.
+    const int rr = DYN && a.dyn_tiles != 0 ? bh_scan256_round_robin_tiles(n_tiles, G, D) : 0;  // (the host starts the claim counter behind them)
+    const bool dyn = rr > 0;
     int run_base = b, run_stride = G, run_len = n_tiles > b ? (n_tiles - b + G - 1) / G : 0;
     int nxt_base = 0, nxt_len = 0;
     int claim_len = CH;  // tiles the next claim asks for
     if (dyn) {
-        const int rr = bh_scan256_round_robin_tiles(n_tiles, G, D);  // (the host starts the claim counter behind them)
-        if (rr > 0) {
-            run_len = rr;
-            claim_len = (n_tiles - rr * G) / (2 * G);
-            if (claim_len < CH) claim_len = CH;
-        } else {
-            run_base = b * CH;
-            run_stride = 1;
-            run_len = run_base < n_tiles ? (n_tiles - run_base < CH ? n_tiles - run_base : CH) : 0;
-        }
+        run_len = rr;
+        claim_len = (n_tiles - rr * G) / (2 * G);
+        if (claim_len < CH) claim_len = CH;
     }
     const unsigned n_rows32 = (unsigned)a.n_rows;
     u64* cand_wg = a.cand + (size_t)b * BQ * CAP;

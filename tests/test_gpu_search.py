@@ -378,13 +378,12 @@ def test_tile256_kernel_dims_and_list_lengths(amd, n, d, nq, k):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(300001, 768, 40, 50), (300001, 384, 40, 50), (300001, 512, 40, 120), (70001, 384, 300, 50),
-                                      (70001, 512, 100, 200), (100003, 768, 257, 56), (2049 * 32, 768, 64, 50)])
+                                      (70001, 512, 100, 200), (100003, 768, 257, 56), (340000, 768, 30, 200), (299617, 768, 64, 50)])
 def test_dynamic_tile_distribution_matches_oracle(amd, n, d, nq, k):
     """scan_topk256's dynamic tile distribution (option dyn_tiles, default on): the first 7/8 of the corpus round robin and
-    the tail in runs claimed from the pass's counter (>= 300 k rows on 256 workgroups), or — smaller corpora — all of it in
-    claimed chunks of 8 tiles.  Every tile must be scanned exactly once whatever the claim order: bit-exact against the
-    oracle with the option on and off, at every ring geometry that has it (d = 384 / 512 / 768: the LDS-DMA look-ahead is
-    5 / 4 / 2.5 tiles) and with 64 / 128 / 256-entry candidate lists."""
+    the tail in runs claimed from the pass's counter (>= 300 k rows on 256 workgroups; smaller corpora stay round robin).
+    Every tile must be scanned exactly once whatever the claim order: bit-exact against the oracle with the option on and
+    off, at every ring geometry that has it (d = 384 / 512 / 768) and with 64 / 128-entry candidate lists."""
     from bergen_amd import _lib
     rng = np.random.default_rng(n + d + k)
     x = rng.standard_normal((n, d)).astype(np.float16)
