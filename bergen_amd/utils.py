@@ -77,7 +77,7 @@ def load_embeddings(index_path):
         embeds = [load_chunk(f) for f in sorted_chunk_files(index_path)]
         if not embeds:  # newer torch raises ValueError (not RuntimeError) for an empty cat: keep the intent
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
-        embeds = torch.concat(embeds)
+        embeds = embeds[0] if len(embeds) == 1 else torch.concat(embeds)  # (a query folder is one chunk: no copy)
     except RuntimeError:
         # torch.cat(): expected a non-empty list of Tensors --> embeddings were not found
         raise RuntimeError("No embeddings found. Check .trec run file name if you are running oracle provenance.")
