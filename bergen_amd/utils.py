@@ -93,10 +93,12 @@ def write_trec(fname, q_ids, d_ids, scores):
     The reference formats a 0-dim fp32 tensor, i.e. the shortest repr of the fp32 value widened
     to a Python float; ``float(score)`` reproduces that for tensors, numpy scalars and floats.
     """
+    rows = scores.tolist() if hasattr(scores, 'tolist') else scores  # (one conversion: element-wise float(tensor[i][j]) is 5x slower)
     with open(fname, 'w') as fout:
         for i, q_id in enumerate(q_ids):
-            for rank, (d_id, score) in enumerate(zip(d_ids[i], scores[i])):
-                fout.write(f'{q_id}\tq0\t{d_id}\t{rank+1}\t{float(score)}\trun\n')
+            row = rows[i].tolist() if hasattr(rows[i], 'tolist') else rows[i]
+            fout.write(''.join(f'{q_id}\tq0\t{d_id}\t{rank}\t{float(score)}\trun\n'
+                               for rank, (d_id, score) in enumerate(zip(d_ids[i], row), 1)))
 
 
 def load_trec(fname):
