@@ -29,6 +29,7 @@ from tqdm import tqdm
 from . import utils
 from .config import instantiate
 from .index import FlatIndex
+from .sharded import ShardedSearcher, shard_range
 from .sparse import SparseIndex
 
 _INCOMPLETE = '!!! Index is not complete. Please re-index. Missing {} documents in the index. !!!'
@@ -63,7 +64,10 @@ class Retrieve:
                  num_workers=4,
                  encode_rank=0,
                  encode_world=1,
-                 resident_on_encode=False):
+                 resident_on_encode=False,
+                 search_rank=None,
+                 search_world=None,
+                 search_results="all"):
         # encode_rank / encode_world: multi-GPU encoding.  The reference's only multi-GPU mechanism is
         # torch.nn.DataParallel around the encoder (dense.py:32-35: scatter inputs, re-broadcast every weight and
         # gather [B, T, d] outputs to GPU 0 on every forward).  Here each of `encode_world` processes (one per GPU)
@@ -73,6 +77,27 @@ class Retrieve:
         # copied device-to-device into the resident HBM index, so that retrieve() searches it without reading the folder
         # back (the reference writes the chunk files and then loads them again, retrieve.py:110-144 -> 153).  The folder is
         # written all the same: it is the cache the next run finds.
+        # search_rank / search_world: row-sharded multi-GPU SEARCH behind this same stage object (BASELINE configs[2] / [4];
+        # the reference has no multi-GPU search).  One process per GPU, every process calls retrieve() with the
+        # same arguments; process r keeps rows shard_range(N, r, world) of the document folder resident in its HBM, runs the
+        # same fused search with id_offset = its first row, ONE all-gather (RCCL over xGMI) brings the partial top-k lists
+        # to rank 0, which merges them (bergen_amd/sharded.py).  search_world="auto" takes rank and world size from an
+        # initialised torch.distributed; None / 1 = the single-GPU path.  search_results: "all" = every rank returns the
+        # same dict (one more small broadcast; what a pipeline run under torchrun needs), "rank0" = rank 0 returns the dict,
+        # the other ranks None.
+        if search_world == "auto":
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            search_world = dist.get_world_size() if on else 1
+            search_rank = dist.get_rank() if on else 0
+        self.search_world = 1 if search_world is None else int(search_world)
+        self.search_rank = 0 if search_rank is None else int(search_rank)
+        if not 0 <= self.search_rank < self.search_world:
+            raise ValueError(f"search_rank={self.search_rank} outside 0..{self.search_world - 1}")
+        if search_results not in ("all", "rank0"):
+            raise ValueError(f"search_results={search_results!r}: expected 'all' or 'rank0'")
+        self.search_results = search_results
+        self.search_group = None  # a torch.distributed process group, if the search ranks are not the default group
         self.resident_on_encode = bool(resident_on_encode)
         self.encode_rank = int(encode_rank)
         self.encode_world = int(encode_world)
@@ -86,6 +111,7 @@ class Retrieve:
         # config.instantiate converts that (and any other mapping) and passes an already-built plug-in object through
         self.model = instantiate(init_args)
         self._resident = {}  # doc_embeds_path -> (FlatIndex, signature)
+        self._searchers = {}
 
     # ------------------------------------------------------------------ indexing (encode)
     def index(self, dataset, index_path, query_or_doc, overwrite_index=False):
@@ -93,12 +119,17 @@ class Retrieve:
         `continue_batch` and `overwrite_index` force the encode) — reference retrieve.py:37-50."""
         if self.encode_world > 1:
             # Several processes fill ONE folder: its existence says nothing about this rank's range (the first rank to
-            # get here creates it).  This rank is done when the chunk file named after ITS last batch exists.
-            n_batches = (len(dataset[query_or_doc]) + self.batch_size - 1) // self.batch_size
+            # get here creates it).  A folder that already holds every row — written by a single process, another world
+            # size or batch size, merge_indexes or a download — is a cached index for every rank (the reference caches by
+            # existence, retrieve.py:40); otherwise this rank is done when the chunk file named after ITS last batch exists.
+            n_rows = len(dataset[query_or_doc])
+            n_batches = (n_rows + self.batch_size - 1) // self.batch_size
             b_lo, b_hi = self._batch_range(n_batches)
-            mine_done = b_hi <= b_lo or os.path.exists(self.get_chunk_path(index_path, b_hi - 1))
-            if mine_done and self.continue_batch is None and not overwrite_index:
-                return
+            if self.continue_batch is None and not overwrite_index:
+                if b_hi <= b_lo or os.path.exists(self.get_chunk_path(index_path, b_hi - 1)):
+                    return
+                if self._folder_rows(index_path) == n_rows:
+                    return
         else:
             have = os.path.exists(index_path)
             if have and self.continue_batch is None and not overwrite_index:
@@ -162,7 +193,7 @@ class Retrieve:
                     raise IOError(_INCOMPLETE.format(len(dataset) - row))
                 resident.finalize()
                 files = utils.sorted_chunk_files(save_path)
-                signature = (tuple(files), tuple(os.path.getmtime(f) for f in files), len(dataset), _metric_of(self.model))
+                signature = (tuple(files), tuple(os.path.getmtime(f) for f in files), len(dataset), _metric_of(self.model), None)
                 old = self._resident.pop(save_path, None)
                 if old is not None:
                     old[0].close()
@@ -180,10 +211,21 @@ class Retrieve:
         b_lo = min(n_batches, rank * share)
         return b_lo, min(n_batches, b_lo + share)
 
+    @staticmethod
+    def _folder_rows(index_path):
+        """Rows held by the chunk files of a folder (files are mapped, not read), or -1 if a file cannot be opened —
+        e.g. one another process is still writing under its temporary name."""
+        try:
+            return sum(int(utils.load_chunk(f, mmap=True).shape[0]) for f in utils.sorted_chunk_files(index_path))
+        except Exception:
+            return -1
+
     def wait_for_index(self, index_path, n_rows, timeout_s=None, poll_s=0.5):
         """Multi-process encoding: block until every rank's last chunk file is in `index_path` (each rank writes it after
-        all its other chunks).  No collective is involved — the ranks only share the folder.  TimeoutError after
-        `timeout_s` seconds (default: BERGEN_AMD_INDEX_WAIT_S or 3600)."""
+        all its other chunks), or the folder holds all n_rows rows whatever wrote it.  No collective is involved — the
+        ranks only share the folder.  A large corpus takes hours to encode, so there is no limit on the total wait; what
+        raises TimeoutError is LACK OF PROGRESS: no new chunk file for `timeout_s` seconds (default:
+        BERGEN_AMD_INDEX_WAIT_S or 3600)."""
         if self.encode_world <= 1:
             return
         import time
@@ -194,25 +236,56 @@ class Retrieve:
             if b_hi > b_lo:
                 need.append(self.get_chunk_path(index_path, b_hi - 1))
         limit = float(os.environ.get("BERGEN_AMD_INDEX_WAIT_S", "3600")) if timeout_s is None else timeout_s
-        t0 = time.time()
+        last_change, seen = time.time(), -1
         while True:
             missing = [f for f in need if not os.path.exists(f)]
             if not missing:
                 return
-            if time.time() - t0 > limit:
-                raise TimeoutError(f"index {index_path}: still waiting for {len(missing)} rank(s), e.g. {missing[0]}")
+            have = len(utils.sorted_chunk_files(index_path))
+            if have != seen:
+                if seen >= 0 or have:  # something was written since the last look
+                    last_change = time.time()
+                seen = have
+                if self._folder_rows(index_path) == n_rows:
+                    return
+            if time.time() - last_change > limit:
+                raise TimeoutError(f"index {index_path}: no new chunk file for {limit:.0f} s, still waiting for "
+                                   f"{len(missing)} rank(s), e.g. {missing[0]}")
             time.sleep(poll_s)
 
     # ------------------------------------------------------------------ resident index
-    def _build_resident(self, chunk_iter, dataset_size, dim, metric):
-        """Upload chunks into a new FlatIndex of dataset_size rows; reference size check."""
-        ix = FlatIndex(dataset_size, dim, metric=metric, device=self.device)
+    # The index classes and the cross-shard merge are attributes so that the CPU tests of the multi-rank path can drive
+    # this stage over gloo with oracle-backed stand-ins; the product never sets them (no CPU fallback).
+    _dense_index_cls = FlatIndex
+    _sparse_index_cls = SparseIndex
+    _shard_merge = None  # ShardedSearcher's default: the HIP merge kernel
+
+    @staticmethod
+    def _rows_of(emb_chunk, a, b):
+        """Rows [a, b) of a chunk tensor (dense, or sparse COO as SPLADE chunks are stored)."""
+        if a == 0 and b == emb_chunk.shape[0]:
+            return emb_chunk
+        if not emb_chunk.is_sparse:
+            return emb_chunk[a:b]
+        t = emb_chunk.coalesce()
+        idx = t.indices()
+        keep = (idx[0] >= a) & (idx[0] < b)
+        return torch.sparse_coo_tensor(torch.stack([idx[0][keep] - a, idx[1][keep]]), t.values()[keep],
+                                       (b - a, t.shape[1])).coalesce()
+
+    def _build_resident(self, chunk_iter, dataset_size, dim, metric, rows=None, sparse=False):
+        """Upload rows [lo, hi) (default: all) of the chunk sequence into a new index of hi - lo rows.  The size check is
+        the reference's (retrieve.py:165-166) and always covers the WHOLE folder, whatever part of it this process keeps."""
+        lo, hi = (0, dataset_size) if rows is None else rows
+        ix = (self._sparse_index_cls(hi - lo, dim, device=self.device) if sparse
+              else self._dense_index_cls(hi - lo, dim, metric=metric, device=self.device))
         num_emb = 0
         try:
             for emb_chunk in chunk_iter:
                 n_c = emb_chunk.shape[0]
-                if num_emb + n_c <= dataset_size:
-                    ix.upload(emb_chunk, row0=num_emb)
+                a, b = max(lo, num_emb), min(hi, num_emb + n_c)
+                if b > a and num_emb + n_c <= dataset_size:
+                    ix.upload(self._rows_of(emb_chunk, a - num_emb, b - num_emb), row0=a - lo)
                 num_emb += n_c
             if num_emb != dataset_size:  # retrieve.py:165-166
                 raise IOError(_INCOMPLETE.format(dataset_size - num_emb))
@@ -228,9 +301,10 @@ class Retrieve:
             emb_chunk = emb_chunk.to_dense()
         return emb_chunk
 
-    def _resident_index(self, doc_embeds_path, dataset_size, metric):
+    def _resident_index(self, doc_embeds_path, dataset_size, metric, rows=None):
+        """The resident index of this process: the whole folder, or rows [lo, hi) of it (sharded search)."""
         files = utils.sorted_chunk_files(doc_embeds_path)
-        signature = (tuple(files), tuple(os.path.getmtime(f) for f in files), dataset_size, metric)
+        signature = (tuple(files), tuple(os.path.getmtime(f) for f in files), dataset_size, metric, rows)
         hit = self._resident.get(doc_embeds_path)
         if hit is not None and hit[1] == signature:
             return hit[0]
@@ -240,40 +314,20 @@ class Retrieve:
         if not files:
             raise IOError(_INCOMPLETE.format(dataset_size))
 
-        def chunks():
-            # chunk i + 1 is read (mapped) on a worker thread while chunk i goes through the pinned staging buffers
-            loaded = utils.prefetched(files, lambda f: utils.load_chunk(f, mmap=True), depth=1)
-            for emb in tqdm(loaded, total=len(files), desc='Load embeddings into HBM...'):
-                yield self._dense_chunk(emb)
-
-        first = utils.load_chunk(files[0])
+        first = utils.load_chunk(files[0], mmap=True)
         dim = first.shape[1]
         sparse = bool(first.is_sparse)
         del first
-        if sparse:  # SPLADE chunks (retrieve.py:138-139): keep them sparse, resident CSR index
-            ix = self._build_resident_sparse((utils.load_chunk(f) for f in tqdm(files, total=len(files),
-                                                                               desc='Load sparse embeddings into HBM...')),
-                                             dataset_size, dim)
-        else:
-            ix = self._build_resident(chunks(), dataset_size, dim, metric)
-        self._resident[doc_embeds_path] = (ix, signature)
-        return ix
 
-    def _build_resident_sparse(self, chunk_iter, dataset_size, vocab):
-        ix = SparseIndex(dataset_size, vocab, device=self.device)
-        num_emb = 0
-        try:
-            for emb_chunk in chunk_iter:
-                n_c = emb_chunk.shape[0]
-                if num_emb + n_c <= dataset_size:
-                    ix.upload(emb_chunk, row0=num_emb)
-                num_emb += n_c
-            if num_emb != dataset_size:  # retrieve.py:165-166
-                raise IOError(_INCOMPLETE.format(dataset_size - num_emb))
-            ix.finalize()
-        except Exception:
-            ix.close()
-            raise
+        def chunks():
+            # chunk i + 1 is read (mapped) on a worker thread while chunk i goes through the pinned staging buffers
+            loaded = utils.prefetched(files, lambda f: utils.load_chunk(f, mmap=not sparse), depth=1)
+            what = 'sparse embeddings' if sparse else 'embeddings'
+            for emb in tqdm(loaded, total=len(files), desc=f'Load {what} into HBM...'):
+                yield emb  # SPLADE chunks (retrieve.py:138-139) stay sparse: resident CSR index
+
+        ix = self._build_resident(chunks(), dataset_size, dim, metric, rows=rows, sparse=sparse)
+        self._resident[doc_embeds_path] = (ix, signature)
         return ix
 
     # ------------------------------------------------------------------ search
@@ -300,27 +354,82 @@ class Retrieve:
         metric = "sparse" if (sparse_queries or getattr(self.model, "sparse", False)) else _metric_of(self.model)
         # the kernels carry candidate lists of at most 256 (dense) / 128 (sparse) entries: refuse a larger k BEFORE the
         # index is read and uploaded (the reference accepts any k; INTEGRATION.md "Limits")
-        k_max = SparseIndex.MAX_K if metric == "sparse" else FlatIndex.MAX_K
+        k_max = self._sparse_index_cls.MAX_K if metric == "sparse" else self._dense_index_cls.MAX_K
         if not 0 < int(top_k_documents) <= k_max:
             raise ValueError(f"top_k_documents={top_k_documents} outside 1..{k_max} supported by the {metric} search kernels")
-        index = self._resident_index(doc_embeds_path, dataset_size=len(dataset['doc']), metric=metric)
+        found = self.search_rows(query_embeds, doc_embeds_path, int(top_k_documents), metric, len(dataset['doc']))
+        if found is None:  # search_results="rank0" on another rank
+            return None
+        return {"score": found[0], "q_id": q_ids, "doc_id": self._map_doc_ids(dataset['doc'], found[1])}
 
+    def adopt_resident_index(self, doc_embeds_path, index, dataset_size, metric, rows=None):
+        """Register an index that is ALREADY resident in HBM as the index of `doc_embeds_path` (rows = this process's
+        (lo, hi) shard of it, None = all): retrieve() / search_rows() then search it without reading the folder — for
+        callers that filled HBM some other way (device-to-device from an encoder, a synthetic corpus generated on the
+        device).  The stage owns the index from here on (close() frees it)."""
+        old = self._resident.pop(doc_embeds_path, None)
+        if old is not None and old[0] is not index:
+            old[0].close()
+        self._resident[doc_embeds_path] = (index, ("adopted", dataset_size, metric, rows))
+
+    def search_rows(self, query_embeds, doc_embeds_path, top_k_documents, metric, n_docs):
+        """The search half of retrieve(): query embeddings [Q, d] (host tensor as load_embeddings returns it, or a device
+        tensor) -> (scores fp32 [Q, k], rows int64 [Q, k]) as CPU tensors, canonical order — the reference's
+        load_collection_and_retrieve over the whole folder (retrieve.py:81-101) without its per-chunk H2D copies.
+        search_world > 1: every rank calls it; this rank searches rows shard_range(n_docs, rank, world) with global row
+        ids, ONE all-gather of the partial lists, canonical merge on rank 0 (ShardedSearcher); with
+        search_results="rank0" the other ranks get None."""
+        k = int(top_k_documents)
+        sparse = metric == "sparse"
+        on_gpu = torch.cuda.is_available()
+        device = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
+        rows = shard_range(n_docs, self.search_rank, self.search_world) if self.search_world > 1 else None
+        hit = self._resident.get(doc_embeds_path)
+        if hit is not None and hit[1] == ("adopted", n_docs, metric, rows):
+            index = hit[0]
+        else:
+            index = self._resident_index(doc_embeds_path, dataset_size=n_docs, metric=metric, rows=rows)
         # ONE search call for the whole query set: the index is resident, the library walks it once per query TILE
         # (256 / 192 / 128 queries, chosen by the kernel).  The reference's batch_size_sim split (retrieve.py:81) bounded
         # its [Bq, n] score matrix, which does not exist here; splitting by it (1024 = 4 x 256 exactly, but 5.3 x 192)
         # could only add corpus passes.  Sparse search keeps the split: its host side builds per-tile term tables.
-        if metric == "sparse":
-            found_scores, found_rows = [], []
-            pieces = query_embeds.split(self.batch_size_sim, dim=0)
-            for part in tqdm(pieces, total=len(pieces), desc='Retrieving docs...'):
-                part_scores, part_rows = index.search(part.contiguous(), top_k_documents)
-                found_scores.append(torch.from_numpy(part_scores))
-                found_rows.append(torch.from_numpy(part_rows))
-            all_scores, all_rows = torch.cat(found_scores), torch.cat(found_rows)
+        pieces = query_embeds.split(self.batch_size_sim, dim=0) if sparse else [query_embeds]
+        if self.search_world == 1:
+            parts = []
+            for part in (tqdm(pieces, total=len(pieces), desc='Retrieving docs...') if sparse else pieces):
+                part = part.contiguous()
+                if part.is_cuda and not sparse:
+                    s, i = index.search(part, k, host=True)  # the merge kernel writes the lists into pinned host memory
+                    parts.append((s.clone(), i.clone()) if len(pieces) > 1 else (s, i))
+                else:
+                    s, i = index.search(part, k)
+                    parts.append((torch.as_tensor(s), torch.as_tensor(i)))
         else:
-            s_np, i_np = index.search(query_embeds.contiguous(), top_k_documents)
-            all_scores, all_rows = torch.from_numpy(s_np), torch.from_numpy(i_np)
-        return {"score": all_scores, "q_id": q_ids, "doc_id": self._map_doc_ids(dataset['doc'], all_rows)}
+            searcher = self._searcher(index, rows[0], device)
+            everywhere = self.search_results == "all"
+            parts = []
+            for part in pieces:
+                part = part.contiguous()
+                if on_gpu and not sparse and not part.is_cuda:
+                    part = part.to(device)  # (sparse search takes host queries: its host side builds the term tables)
+                res = searcher.search(part, k, broadcast=everywhere)
+                if res is not None:
+                    parts.append((res[0].cpu(), res[1].cpu()) if res[0].is_cuda or len(pieces) == 1 else (res[0].clone(), res[1].clone()))
+            if not parts:
+                return None
+        if len(parts) == 1:
+            return parts[0]
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+
+    def _searcher(self, index, row_lo, device):
+        """One ShardedSearcher per resident shard (its gather buffers are allocated once per query-set shape)."""
+        key = id(index)
+        hit = self._searchers.get(key)
+        if hit is None or hit[0] is not index:
+            self._searchers = {key: (index, ShardedSearcher(index, row_lo, rank=self.search_rank, world_size=self.search_world,
+                                                            merge=self._shard_merge, group=self.search_group, device=device))}
+            hit = self._searchers[key]
+        return hit[1]
 
     @staticmethod
     def _ids_at(doc_dataset, rows):
@@ -368,7 +477,7 @@ class Retrieve:
             raise IOError(_INCOMPLETE.format(dataset_size - num_emb))
         dim = int(emb_q.shape[1])
         if len(doc_embeds) and doc_embeds[0].is_sparse:
-            ix = self._build_resident_sparse(iter(doc_embeds), dataset_size, dim)
+            ix = self._build_resident(iter(doc_embeds), dataset_size, dim, "sparse", sparse=True)
         else:
             ix = self._build_resident((self._dense_chunk(c) for c in doc_embeds), dataset_size, dim, _metric_of(self.model))
         try:

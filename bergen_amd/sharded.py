@@ -41,10 +41,13 @@ class ShardedSearcher:
     merge: callable([G,Q,k] scores, [G,Q,k] ids) -> ([Q,k], [Q,k]); default = the HIP merge kernel.
     """
 
-    def __init__(self, local_index, row_lo, rank=None, world_size=None, merge=None, group=None, dst=0):
+    def __init__(self, local_index, row_lo, rank=None, world_size=None, merge=None, group=None, dst=0, device=None):
+        # device: where the collective's buffers live when the queries are host arrays (numpy / CPU tensors): RCCL moves
+        # device memory only, gloo host memory.  None = the queries' own device.
         self.local_index = local_index
         self.row_lo = int(row_lo)
         self.group = group
+        self.device = torch.device(device) if device is not None else None
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         self.dst = dst
@@ -81,16 +84,20 @@ class ShardedSearcher:
             self._buf[key] = buf
         return buf
 
-    def search(self, queries, k):
-        """All ranks call this with the same queries.  Returns (scores, ids) on rank `dst`, None elsewhere.  The result
-        tensors are reused by the next search of the same shape: copy them if they must outlive it."""
+    def search(self, queries, k, broadcast=False):
+        """All ranks call this with the same queries.  Returns (scores, ids) on rank `dst`, None elsewhere — or, with
+        broadcast=True, the merged lists on EVERY rank (one more small collective: a pipeline that runs the same script on
+        every rank, as BERGEN under torchrun would, needs the result everywhere).  The result tensors are reused by the
+        next search of the same shape: copy them if they must outlive it."""
         if self.world_size == 1:
             scores, ids = self.local_index.search(queries, k, id_offset=self.row_lo)
             return torch.as_tensor(scores), torch.as_tensor(ids)
         nq = int(queries.shape[0])
-        device = queries.device if isinstance(queries, torch.Tensor) else torch.device("cpu")
+        on_device = isinstance(queries, torch.Tensor) and queries.is_cuda
+        device = queries.device if on_device else (self.device or torch.device("cpu"))
         buf = self._buffers(nq, k, device)
-        if self._search_takes_out:
+        if self._search_takes_out and on_device:
+            # (out= is the device-queries path of FlatIndex.search: the local lists land in the packed send buffer)
             self.local_index.search(queries, k, id_offset=self.row_lo, out=(buf["scores"], buf["ids"]))
         else:
             scores, ids = self.local_index.search(queries, k, id_offset=self.row_lo)
@@ -99,7 +106,7 @@ class ShardedSearcher:
         # (score, id) lists in one byte buffer -> a single collective per search
         dist.all_gather_into_tensor(buf["flat"], buf["packed"], group=self.group)  # 1-D in/out: valid for RCCL and gloo
         if self.rank != self.dst:
-            return None
+            return self._broadcast(buf, None) if broadcast else None
         gathered = buf["flat"].view(self.world_size, buf["per"])
         nbs = nq * k * 4
         buf["all_s"].view(self.world_size, nq * k).copy_(gathered[:, :nbs].view(torch.float32))
@@ -108,4 +115,14 @@ class ShardedSearcher:
             out_s, out_i = self.merge(buf["all_s"], buf["all_i"], out=buf["out"])
         else:
             out_s, out_i = self.merge(buf["all_s"], buf["all_i"])
-        return torch.as_tensor(out_s), torch.as_tensor(out_i)
+        out_s, out_i = torch.as_tensor(out_s), torch.as_tensor(out_i)
+        return self._broadcast(buf, (out_s, out_i)) if broadcast else (out_s, out_i)
+
+    def _broadcast(self, buf, merged):
+        """Merged lists from rank `dst` to every rank, through the packed send buffer (its local lists are spent)."""
+        if merged is not None:
+            buf["scores"].copy_(merged[0])
+            buf["ids"].copy_(merged[1])
+        src = dist.get_global_rank(self.group, self.dst) if self.group is not None else self.dst
+        dist.broadcast(buf["packed"], src=src, group=self.group)
+        return buf["scores"], buf["ids"]

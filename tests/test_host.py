@@ -255,6 +255,56 @@ def test_multi_rank_index_route_encodes_every_range_and_waits(tmp_path):
     assert not [f for f in os.listdir(folder) if f.endswith(".tmp")]
 
 
+def test_multi_rank_index_route_reuses_a_complete_folder_whatever_wrote_it(tmp_path):
+    """A folder that already holds every row (single-process run, another world size or batch size, merge_indexes, a
+    download) has no per-rank marker files: every rank must still take it as the cached index — no re-encode (which would
+    append duplicate rows) and no wait (round-2 advisor finding; the reference caches by existence, retrieve.py:40)."""
+    import datasets
+    n = 203
+    ds = {"doc": datasets.Dataset.from_dict({"id": [f"d{i}" for i in range(n)], "content": [str(i) for i in range(n)]})}
+    folder = str(tmp_path / "cached")
+    Retrieve(init_args=_FakeDense(), batch_size=16, num_workers=0).index(ds, folder, "doc")  # one process, another batch size
+    before = {f: os.path.getmtime(os.path.join(folder, f)) for f in os.listdir(folder)}
+    ranks = [Retrieve(init_args=_FakeDense(), batch_size=8, num_workers=0, encode_rank=r, encode_world=3) for r in range(3)]
+    for r in ranks:
+        r.index(ds, folder, "doc")
+        r.wait_for_index(folder, n, timeout_s=0.2, poll_s=0.05)
+    assert before == {f: os.path.getmtime(os.path.join(folder, f)) for f in os.listdir(folder)}
+    assert utils.load_embeddings(folder).shape[0] == n
+    # a folder that is NOT complete (and has no marker of this rank) is still encoded into
+    short = str(tmp_path / "short")
+    os.makedirs(short)
+    torch.save(utils.load_embeddings(folder)[:40], os.path.join(short, "embedding_chunk_4.pt"))
+    assert Retrieve._folder_rows(short) == 40
+    ranks[2].index(ds, short, "doc")
+    assert len(os.listdir(short)) == 2
+
+
+def test_wait_for_index_times_out_on_lack_of_progress_only(tmp_path):
+    import threading
+    import time
+    import datasets
+    n, bs = 64, 8
+    ds = {"doc": datasets.Dataset.from_dict({"id": [f"d{i}" for i in range(n)], "content": [str(i) for i in range(n)]})}
+    folder = str(tmp_path / "slow")
+    ranks = [Retrieve(init_args=_FakeDense(), batch_size=bs, num_workers=0, encode_rank=r, encode_world=2) for r in range(2)]
+    ranks[0].index(ds, folder, "doc")
+
+    def late():  # progress (an unrelated chunk file) arrives inside the window, the last range after more than one window
+        time.sleep(0.25)
+        torch.save(torch.zeros(1, 4), os.path.join(folder, "embedding_chunk_900.pt.tmp"))
+        os.replace(os.path.join(folder, "embedding_chunk_900.pt.tmp"), os.path.join(folder, "embedding_chunk_900.pt"))
+        time.sleep(0.25)
+        os.remove(os.path.join(folder, "embedding_chunk_900.pt"))
+        ranks[1].index(ds, folder, "doc")
+
+    t = threading.Thread(target=late)
+    t.start()
+    ranks[0].wait_for_index(folder, n, timeout_s=0.4, poll_s=0.02)  # 0.5 s in total > 0.4 s, but never 0.4 s without a change
+    t.join()
+    assert utils.load_embeddings(folder).shape[0] == n
+
+
 def test_dense_call_only_falls_back_for_an_unknown_pooler():
     """Errors of the native forward pass (BH_EINVAL -> ValueError) must propagate; only a pooler the kernels have no mode
     for goes through the unpooled path."""

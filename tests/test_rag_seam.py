@@ -104,7 +104,7 @@ def test_reference_rag_retrieve_drives_our_retrieve(tmp_path, ref_rag, monkeypat
     retriever = bergen_amd.Retrieve(init_args=_Encoder(), batch_size=16, num_workers=0)
     built = []
 
-    def resident(path, dataset_size, metric):
+    def resident(path, dataset_size, metric, rows=None):
         rows = bergen_amd.utils.load_embeddings(path).numpy()
         assert rows.shape[0] == dataset_size
         built.append(path)
