@@ -53,6 +53,8 @@ def parse_args():
     p.add_argument("--share-threshold", type=int, default=None)
     p.add_argument("--nontemporal", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--full-list-queries", type=int, default=8,
+                   help="queries whose COMPLETE top-k lists the parity gate recomputes over the whole corpus (N = 1; 0 = off)")
     p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
     p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg (index folders -> doc-id strings)")
@@ -76,29 +78,42 @@ def make_queries(nq, dim, device):
     return torch.nn.functional.normalize(q, dim=1).half()
 
 
+BLOCK = 1_000_000
+
+
+def plant_table(nq, n_total):
+    gp = torch.Generator().manual_seed(3)
+    return torch.randint(0, n_total, (nq, 5), generator=gp)  # global rows, same on every rank
+
+
+def corpus_block(b, dim, queries, plant_rows, n_total, device):
+    """Block b (rows [b * BLOCK, ...)) of the synthetic corpus as fp16 device rows, plus the (query, j) plants inside it —
+    the one recipe behind the index fill, the re-scoring gate and the streaming full-list gate."""
+    b0 = b * BLOCK
+    m = min(BLOCK, n_total - b0)
+    g = torch.Generator(device=device).manual_seed(1000 + b)
+    rows = torch.nn.functional.normalize(torch.randn(m, dim, generator=g, device=device), dim=1)
+    sel = ((plant_rows >= b0) & (plant_rows < b0 + m)).nonzero().tolist()
+    for qi, j in sel:  # (in this order: a later plant on the same row wins)
+        r = int(plant_rows[qi, j])
+        gn = torch.Generator(device=device).manual_seed(7_000_000 + qi * 5 + j)
+        noise = torch.randn(dim, generator=gn, device=device) * (0.3 / dim ** 0.5)
+        rows[r - b0] = torch.nn.functional.normalize(queries[qi].float() + noise, dim=0)
+    return rows.half(), sel
+
+
 def fill_shard(ix, lo, hi, dim, queries, n_total, device):
     """Upload rows [lo, hi) of the synthetic corpus into ix (local row = global row - lo)."""
-    block = 1_000_000
     nq = queries.shape[0]
-    gp = torch.Generator().manual_seed(3)
-    plant_rows = torch.randint(0, n_total, (nq, 5), generator=gp)  # global rows, same on every rank
+    plant_rows = plant_table(nq, n_total)
     planted = []
-    b_first, b_last = lo // block, (max(hi, lo + 1) - 1) // block
+    b_first, b_last = lo // BLOCK, (max(hi, lo + 1) - 1) // BLOCK
     for b in range(b_first, b_last + 1):
-        b0 = b * block
-        m = min(block, n_total - b0)
-        if m <= 0:
+        b0 = b * BLOCK
+        if n_total - b0 <= 0:
             break
-        g = torch.Generator(device=device).manual_seed(1000 + b)
-        rows = torch.nn.functional.normalize(torch.randn(m, dim, generator=g, device=device), dim=1)
-        sel = ((plant_rows >= b0) & (plant_rows < b0 + m)).nonzero().tolist()
-        for qi, j in sel:
-            r = int(plant_rows[qi, j])
-            gn = torch.Generator(device=device).manual_seed(7_000_000 + qi * 5 + j)
-            noise = torch.randn(dim, generator=gn, device=device) * (0.3 / dim ** 0.5)
-            rows[r - b0] = torch.nn.functional.normalize(queries[qi].float() + noise, dim=0)
-        rows = rows.half()
-        a, e = max(lo, b0), min(hi, b0 + m)
+        rows, sel = corpus_block(b, dim, queries, plant_rows, n_total, device)
+        a, e = max(lo, b0), min(hi, b0 + rows.shape[0])
         if e > a:
             ix.upload(rows[a - b0:e - b0].contiguous(), row0=a - lo)
             for qi, j in sel:
@@ -107,6 +122,38 @@ def fill_shard(ix, lo, hi, dim, queries, n_total, device):
                     planted.append((qi, r))
         del rows
     return planted, plant_rows
+
+
+def streamed_full_lists(n_check, queries, dim, k, plant_rows, n_total, device):
+    """The COMPLETE top-k lists of the first n_check queries, computed without any of this repository's kernels: the
+    corpus is regenerated block by block, every block is scored with a float64 matrix product (torch / rocBLAS), rounded to
+    fp32, and the rows that can still be in the top k are kept; the union is ordered (score desc, row asc) at the end.
+    Why a float64 GEMM in ANY summation order gives the canonical score (= fp32 of the sequential fp64 sum) here: fp16
+    values are multiples of 2^-24, so every product and every partial sum is a multiple of 2^-48; with
+    sum_j |q_j x_j| <= |q| |x| < 16 (checked below; the rows are unit-norm) every partial sum has fewer than 53
+    significant bits — no fp64 operation rounds, whatever its order."""
+    q64 = queries[:n_check].double()
+    q_norm = float(q64.norm(dim=1).max())
+    keep_s, keep_i = [[] for _ in range(n_check)], [[] for _ in range(n_check)]
+    for b in range((n_total + BLOCK - 1) // BLOCK):
+        rows, _ = corpus_block(b, dim, queries, plant_rows, n_total, device)
+        x64 = rows.double()
+        assert q_norm * float(x64.norm(dim=1).max()) < 16.0, "exactness argument of the float64 gate does not hold"
+        sc = (q64 @ x64.T).float()  # [n_check, m], fp32 (RNE) of the exact sum
+        kth = torch.topk(sc, min(k, sc.shape[1]), dim=1).values[:, -1:]
+        hit = (sc >= kth).nonzero()  # every row that ties the block's k-th stays in
+        vals = sc[hit[:, 0], hit[:, 1]].cpu().tolist()
+        for (a, r), v in zip(hit.cpu().tolist(), vals):
+            keep_s[a].append(v)
+            keep_i[a].append(b * BLOCK + r)
+        del rows, x64, sc
+    want_s = np.empty((n_check, k), np.float32)
+    want_i = np.empty((n_check, k), np.int64)
+    for a in range(n_check):
+        cs, ci = np.asarray(keep_s[a], np.float32), np.asarray(keep_i[a], np.int64)
+        order = np.lexsort((ci, -cs.astype(np.float64)))[:k]
+        want_s[a], want_i[a] = cs[order], ci[order]
+    return want_s, want_i
 
 
 def cpu_baseline(args, dim, k):
@@ -431,6 +478,22 @@ class HipEnv:
         import bergen_amd
         return bergen_amd.FlatIndex(n_rows, dim, metric="ip", device=self.local_rank)
 
+    def make_stage(self, rank, world):
+        """The stage object BERGEN builds (modules/rag.py:177-181), here with the row-sharded search switched on: the
+        timed step is its search_rows() — the search half of Retrieve.retrieve."""
+        import bergen_amd
+
+        class _Plug:  # the index is filled on the device: the model is only asked for its name and similarity
+            model_name = "bench/synthetic"
+            similarity = bergen_amd.DotProduct()
+            model = torch.nn.Identity()
+
+        stage = bergen_amd.Retrieve(init_args=_Plug(), device=self.local_rank, search_rank=rank, search_world=world,
+                                    search_results="rank0")
+        if self.merge is not None:
+            stage._shard_merge = self.merge
+        return stage
+
     def sync(self):
         torch.cuda.synchronize()
 
@@ -465,19 +528,19 @@ def run(args, env):
     ix.finalize()
     env.sync()
     build_s = time.perf_counter() - t0
-    searcher = bergen_amd.ShardedSearcher(ix, lo, rank=rank, world_size=world, merge=env.merge) if world > 1 else None
+    # The search runs THROUGH THE STAGE: Retrieve.search_rows is the search half of Retrieve.retrieve (the code a BERGEN
+    # pipeline reaches through modules/rag.py:322-329) — single GPU: fused scan + merge, lists written into pinned host
+    # memory; N GPUs: the same on this rank's row shard with global row ids, one all-gather of the packed partial lists
+    # (RCCL), canonical merge on rank 0, D2H there.  The shard was filled on the device, so the stage adopts it instead
+    # of reading a 32 GB folder.
+    corpus_key = "bench://synthetic-corpus"
+    stage = env.make_stage(rank, world)
+    stage.adopt_resident_index(corpus_key, ix, n_total, "ip", rows=(lo, hi) if world > 1 else None)
 
     def step():
         # search_seconds includes the D2H of the result lists: [Q, k] fp32 + int64, 1.7 MB at Q = 2 837
-        if searcher is None and env.results_to_host:
-            r = ix.search(queries, k, host=True)  # the merge kernel writes the lists into pinned host memory
-            return r, r
-        r = searcher.search(queries, k) if searcher is not None else ix.search(queries, k)
-        if r is not None and r[0] is not None:
-            host = (torch.as_tensor(r[0]).cpu(), torch.as_tensor(r[1]).cpu())
-        else:
-            host = None
-        return r, host
+        r = stage.search_rows(queries, corpus_key, k, "ip", n_total)  # (CPU tensors on rank 0, None elsewhere)
+        return r, r
 
     def barrier():
         env.sync()
@@ -508,6 +571,7 @@ def run(args, env):
 
     # ---- parity gate (rank 0): planted positives on top + canonical scores of returned ids -------
     parity = "skipped"
+    full_list_gate = None
     if rank == 0:
         s_np, i_np = res_host[0].numpy(), res_host[1].numpy()
         ok = bool((np.diff(s_np, axis=1) <= 0).all())
@@ -527,6 +591,17 @@ def run(args, env):
             xf = got_rows.astype(np.float64).reshape(4, k, dim)
             want = np.cumsum(qf[:, None, :] * xf, axis=-1)[..., -1].astype(np.float32)
             ok &= bool(np.array_equal(want.view(np.uint32), s_np[:4].view(np.uint32)))
+            # ... and the COMPLETE lists of the first queries against a kernel-free recomputation over all n_total rows
+            if args.full_list_queries > 0:
+                t0 = time.perf_counter()
+                n_chk = min(args.full_list_queries, nq)
+                full_s, full_i = streamed_full_lists(n_chk, queries, dim, k, plant_rows, n_total, device)
+                full_ok = bool(np.array_equal(full_i, i_np[:n_chk]) and
+                               np.array_equal(full_s.view(np.uint32), s_np[:n_chk].view(np.uint32)))
+                ok &= full_ok
+                full_list_gate = {"queries": n_chk, "rows": n_total, "ids_and_fp32_scores_bit_exact": full_ok,
+                                  "seconds": time.perf_counter() - t0,
+                                  "how": "float64 GEMM per 1M-row block (exact for unit-norm fp16 data), fp32 round, (score desc, row asc)"}
         parity = "pass" if ok else "FAIL"
 
     if rank == 0:
@@ -573,6 +648,7 @@ def run(args, env):
             # candidate lists and that took the exact fall-back scan (bergen_amd/csrc/certify.hip); inside the timed region
             "uncertified_queries": uncertified,
             "parity_check": parity,
+            "full_list_gate": full_list_gate,
         }
         if world == 1 and args.query_split is None and not args.no_other_kernels:
             # secondary figures: the same search on the earlier scan kernels (library option scan_kernel), with result equality
@@ -631,7 +707,7 @@ def run(args, env):
             except Exception as exc:
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + repr(exc)}
         print(json.dumps(out), flush=True)
-    ix.close()
+    stage.close()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0 and parity == "FAIL":
@@ -640,26 +716,14 @@ def run(args, env):
 
 def _regenerate_rows(global_rows, dim, queries, plant_rows, n_total, device):
     """Rebuild specific corpus rows on the device exactly as fill_shard made them -> numpy fp16 [len, dim]."""
-    block = 1_000_000
     out = np.empty((len(global_rows), dim), np.float16)
-    planted = {int(plant_rows[qi, j]): (qi, j) for qi in range(plant_rows.shape[0]) for j in range(5)}
     by_block = {}
     for pos, r in enumerate(global_rows.tolist()):
-        by_block.setdefault(r // block, []).append((pos, r))
+        by_block.setdefault(r // BLOCK, []).append((pos, r))
     for b, items in by_block.items():
-        b0 = b * block
-        m = min(block, n_total - b0)
-        g = torch.Generator(device=device).manual_seed(1000 + b)
-        rows = torch.nn.functional.normalize(torch.randn(m, dim, generator=g, device=device), dim=1)
-        sel = ((plant_rows >= b0) & (plant_rows < b0 + m)).nonzero().tolist()
-        for qi, j in sel:  # same order as fill_shard: a later plant on the same row wins there too
-            r = int(plant_rows[qi, j])
-            gn = torch.Generator(device=device).manual_seed(7_000_000 + qi * 5 + j)
-            noise = torch.randn(dim, generator=gn, device=device) * (0.3 / dim ** 0.5)
-            rows[r - b0] = torch.nn.functional.normalize(queries[qi].float() + noise, dim=0)
-        rows = rows.half()
+        rows, _ = corpus_block(b, dim, queries, plant_rows, n_total, device)
         for pos, r in items:
-            out[pos] = rows[r - b0].cpu().numpy()
+            out[pos] = rows[r - b * BLOCK].cpu().numpy()
         del rows
     return out
 

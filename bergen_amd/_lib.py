@@ -42,6 +42,8 @@ class bh_counters(ctypes.Structure):
         ("shader_mhz", ctypes.c_double),
         ("uncertified_queries", ctypes.c_int64),
         ("exact_ms", ctypes.c_double),
+        ("exact_passes", ctypes.c_int64),
+        ("exact_rows_rescored", ctypes.c_int64),
     ]
 
 

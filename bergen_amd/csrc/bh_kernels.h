@@ -23,10 +23,16 @@ struct BhScanArgs {
     int pair_window;         // qsplit = 2: a workgroup may run at most this many tiles ahead of its partner (0 = free-running)
     int dyn_tiles;           // scan_topk256: tiles handed out in chunks by a claim counter instead of round robin
     bh_u64* clk;             // optional diagnostics [grid][8] phase stamps + BH_TL_WORDS timeline words (scan_topk256.hip)
+    // filter pass of the exactness fall-back (bh_launch_filter_scan; unused by the top-k scans)
+    const float* fix_thr = nullptr;  // [128] a row qualifies for query q iff its MFMA score >= fix_thr[q] (+inf: unused query)
+    unsigned* fix_cnt = nullptr;     // [128] qualifying rows per query, zeroed by the caller; may exceed fix_cap (overflow)
+    unsigned* fix_rows = nullptr;    // [128][fix_cap] their row indices
+    unsigned fix_cap = 0;
 };
 
 // scan_topk.hip
 hipError_t bh_launch_scan(const BhScanArgs& a, int dim_padded, int kp, int qw, int grid, hipStream_t stream);
+hipError_t bh_launch_filter_scan(const BhScanArgs& a, int dim_padded, int grid, hipStream_t stream);
 bool bh_scan_supports(int dim_padded, int kp, int qw);
 // scan_topk192.hip (192 queries per pass on v_mfma_f32_16x16x32_f16; d = 768, k <= 56 only)
 hipError_t bh_launch_scan192(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
@@ -89,7 +95,7 @@ hipError_t bh_launch_merge_lists(const float* scores, const long long* ids, int 
 
 // certify.hip: largest row norm of the corpus (for the certificate's error bound) and the exact fall-back scan
 hipError_t bh_launch_row_norm_max(const _Float16* rows, long long n, int dim_padded, unsigned* out_max_bits, hipStream_t stream);
-#define BH_EXACT_BATCH 8        /* queries per exact-scan launch (their fp64 images share 64 KiB of LDS at d = 1024) */
+#define BH_EXACT_BATCH 128      /* uncertified queries per filter pass (one query tile of the 128-query scan kernel) */
 #define BH_EXACT_CAP 65536      /* qualifying rows kept per query */
 struct BhExactArgs {
     const _Float16* corpus;   // [n_rows][D]
@@ -98,10 +104,15 @@ struct BhExactArgs {
     const _Float16* q;        // [nqf][D] the uncertified queries, gathered
     int nqf;                  // <= BH_EXACT_BATCH
     const bh_u64* kth_key;    // [nqf] a row qualifies iff its canonical key >= this one
-    bh_u64* out_keys;         // [nqf][BH_EXACT_CAP]
-    unsigned* out_cnt;        // [nqf] zeroed by the caller; may exceed the cap (overflow)
+    const unsigned* rows;     // [nqf][BH_EXACT_CAP] rows the filter pass let through
+    const unsigned* cnt;      // [nqf] how many (values above the cap are clamped)
+    bh_u64* out_keys;         // [nqf][BH_EXACT_CAP] out: canonical key of rows[q][i] if it qualifies, else 0
 };
-hipError_t bh_launch_exact_scan(const BhExactArgs& a, hipStream_t stream);
+// canonical (sequential fp64) score of every row the filter pass let through
+hipError_t bh_launch_exact_rescore(const BhExactArgs& a, hipStream_t stream);
+// gathers a batch of uncertified queries: rows -> q_out [BH_EXACT_BATCH][D] (zero beyond nb), k-th keys, filter thresholds
+hipError_t bh_launch_exact_prepare(const _Float16* qbuf, const int* todo, int nb, const bh_u64* kth_all, float err_coef, int dim_padded,
+                                   _Float16* q_out, bh_u64* kth_out, float* thr_out, hipStream_t stream);
 
 // convert.hip: dtype conversion / padding / normalisation
 hipError_t bh_launch_convert_rows(const void* src, int src_dtype /*0=f16,1=f32*/, long long n, int dim,

@@ -6,9 +6,9 @@
 // score.  merge_rescore.hip certifies each query: a dropped row x has  mfma(x) <= mfma(KP-th kept row)  and
 // |mfma(x) - canonical(x)| <= 2 d 2^-24 |q| |x| (fp32 accumulation of d exact products, any order, any tree), so its
 // canonical score is below  mfma(KP-th) + 2 d 2^-24 |q| max|x|.  If that is still below the k-th canonical score the
-// result is proven exact; otherwise the query goes through bh_exact_scan_kernel, which computes the canonical score of
-// EVERY row and returns all rows whose canonical key reaches the k-th kept one — exact by construction, at the price of
-// one more corpus pass per BH_EXACT_BATCH uncertified queries.
+// result is proven exact; otherwise the query goes through the fall-back below (an MFMA filter pass with a fixed threshold +
+// canonical re-scoring of the few rows it lets through) — exact by construction, at the price of one more corpus pass per
+// BH_EXACT_BATCH (128) uncertified queries.
 //
 // Reference lines this protects: torch.topk over the exact score matrix (modules/retrieve.py:157,175).
 #include "bh_device.h"
@@ -44,59 +44,90 @@ hipError_t bh_launch_row_norm_max(const _Float16* rows, long long n, int dim_pad
     return hipGetLastError();
 }
 
-// One thread per row, BH_EXACT_BATCH queries at a time; the queries' fp64 images sit in LDS (same address for every lane:
-// broadcast reads).  Canonical score = fp32 of the sequential fp64 FMA sum in dimension order — the arithmetic of
-// merge_rescore.hip and of the oracle's plain C loop.
-__global__ void __launch_bounds__(256) bh_exact_scan_kernel(BhExactArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* qd = reinterpret_cast<double*>(smem_raw);  // [nqf][D]
-    const int D = a.dim_padded;
-    for (int i = threadIdx.x; i < a.nqf * D; i += blockDim.x) qd[i] = (double)a.q[i];
+// ---- the fall-back for queries the certificate could not prove --------------------------------------------------
+// A row x can belong to the true top-k of query q only if its canonical key reaches the k-th kept one, and
+// canonical(x) <= mfma(x) + err_coef |q| (the certificate's own bound), so every such row has
+//     mfma(x) >= score(k-th canonical key) - err_coef |q|  =: fix_thr[q].
+// The FILTER PASS (scan_topk.hip, ABL = 5: the 128-query scan's stream + MFMA loop with that fixed threshold) lists these
+// rows — the top k and whatever lies within rounding error of the k-th score — for up to BH_EXACT_BATCH queries per
+// corpus pass, at the speed of a normal pass; bh_exact_rescore_kernel then gives each listed row its canonical score
+// (sequential fp64 sum in dimension order -> fp32: the arithmetic of merge_rescore.hip and of the oracle's plain C loop)
+// and keeps those whose key reaches the k-th one; the host sorts.  Exact by construction, whatever the cluster size (up to
+// BH_EXACT_CAP rows per query).  (Round 2 ran an fp64 scan of EVERY row for 8 queries at a time: one thread per row,
+// uncoalesced, ~fp64-peak-bound at best — a corpus pass per 8 queries; the matrix cores do the same filtering for 128.)
+
+// Gathers the batch: query rows, k-th keys, thresholds.  One workgroup per slot of the 128-query tile.
+__global__ void __launch_bounds__(256) bh_exact_prepare_kernel(const _Float16* qbuf, const int* todo, int nb, const bh_u64* kth_all,
+                                                               float err_coef, int dim_padded, _Float16* q_out, bh_u64* kth_out,
+                                                               float* thr_out) {
+    __shared__ float part[4];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    _Float16* dst = q_out + (size_t)j * dim_padded;
+    if (j >= nb) {  // unused query of the tile: zero row, nothing qualifies
+        for (int c = tid; c < dim_padded; c += 256) dst[c] = (_Float16)0.f;
+        if (tid == 0) thr_out[j] = __builtin_inff();
+        return;
+    }
+    const int q = todo[j];
+    const _Float16* src = qbuf + (size_t)q * dim_padded;
+    float s2 = 0.f;
+    for (int c = tid; c < dim_padded; c += 256) {
+        const _Float16 v = src[c];
+        dst[c] = v;
+        s2 += (float)v * (float)v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6] = s2;
     __syncthreads();
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (long long)gridDim.x * blockDim.x) {
-        const half8* x = reinterpret_cast<const half8*>(a.corpus + (size_t)r * D);
-        double s[BH_EXACT_BATCH];
-#pragma unroll
-        for (int qi = 0; qi < BH_EXACT_BATCH; ++qi) s[qi] = 0.0;
-        for (int c = 0; c < (D >> 3); ++c) {
-            const half8 xv = x[c];
-            double xd[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xd[e] = (double)xv[e];
-#pragma unroll
-            for (int qi = 0; qi < BH_EXACT_BATCH; ++qi) {
-                if (qi < a.nqf) {
-                    const double* qq = qd + (size_t)qi * D + c * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s[qi] = __builtin_fma(qq[e], xd[e], s[qi]);
-                }
-            }
-        }
-#pragma unroll
-        for (int qi = 0; qi < BH_EXACT_BATCH; ++qi) {
-            if (qi < a.nqf) {
-                const u64 key = bh_make_key((float)s[qi], (unsigned)r);
-                if (key >= a.kth_key[qi]) {
-                    const unsigned slot = atomicAdd(a.out_cnt + qi, 1u);
-                    if (slot < BH_EXACT_CAP) a.out_keys[(size_t)qi * BH_EXACT_CAP + slot] = key;
-                }
-            }
-        }
+    if (tid == 0) {
+        const bh_u64 kth = kth_all[q];
+        kth_out[j] = kth;
+        // the certificate's bound (merge_rescore.hip: same over-estimate of |q|), rounded towards -inf twice over
+        const float qn = sqrtf(part[0] + part[1] + part[2] + part[3]) * 1.0001f;
+        const float lim = bh_key_score(kth) - err_coef * qn * 1.0001f;
+        // (next float below lim: floats order like the bh_ordf image of their bits)
+        thr_out[j] = kth != 0ull ? bh_unordf(bh_ordf(lim) - 1u) : -__builtin_inff();
     }
 }
 
-hipError_t bh_launch_exact_scan(const BhExactArgs& a, hipStream_t stream) {
-    if (a.nqf <= 0 || a.nqf > BH_EXACT_BATCH || a.n_rows <= 0) return hipErrorInvalidValue;
-    const size_t smem = (size_t)a.nqf * a.dim_padded * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_exact_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           BH_EXACT_BATCH * 1024 * (int)sizeof(double));
-        if (e != hipSuccess) return e;
-        attr_done = true;
+hipError_t bh_launch_exact_prepare(const _Float16* qbuf, const int* todo, int nb, const bh_u64* kth_all, float err_coef, int dim_padded,
+                                   _Float16* q_out, bh_u64* kth_out, float* thr_out, hipStream_t stream) {
+    hipLaunchKernelGGL(bh_exact_prepare_kernel, dim3(BH_EXACT_BATCH), dim3(256), 0, stream, qbuf, todo, nb, kth_all, err_coef, dim_padded,
+                       q_out, kth_out, thr_out);
+    return hipGetLastError();
+}
+
+// One thread per listed (query, row): canonical score, key, keep iff it reaches the query's k-th key.
+__global__ void __launch_bounds__(256) bh_exact_rescore_kernel(BhExactArgs a) {
+    const int qi = blockIdx.y;
+    const unsigned n = min(a.cnt[qi], (unsigned)BH_EXACT_CAP);
+    const half8* qv = reinterpret_cast<const half8*>(a.q + (size_t)qi * a.dim_padded);
+    const bh_u64 kth = a.kth_key[qi];
+    const int n8 = a.dim_padded >> 3;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned row = a.rows[(size_t)qi * BH_EXACT_CAP + i];
+        const half8* x = reinterpret_cast<const half8*>(a.corpus + (size_t)row * a.dim_padded);
+        double s = 0.0;
+        for (int j = 0; j < n8; j += 4) {  // (dim_padded is a multiple of 32)
+            half8 xv[4], qq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = x[j + u];
+                qq[u] = qv[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = __builtin_fma((double)qq[u][e], (double)xv[u][e], s);
+        }
+        const u64 key = bh_make_key((float)s, row);
+        a.out_keys[(size_t)qi * BH_EXACT_CAP + i] = key >= kth ? key : 0ull;
     }
-    long long blocks = (a.n_rows + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(bh_exact_scan_kernel, dim3((unsigned)blocks), dim3(256), smem, stream, a);
+}
+
+hipError_t bh_launch_exact_rescore(const BhExactArgs& a, hipStream_t stream) {
+    if (a.nqf <= 0 || a.nqf > BH_EXACT_BATCH || a.n_rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bh_exact_rescore_kernel, dim3(32, (unsigned)a.nqf), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

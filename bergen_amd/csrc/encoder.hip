@@ -456,8 +456,14 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     for (int b = 0; b < batch; ++b) {
         slen[b] = len[b];
         long long r = off[b];
+        // RoBERTa-family position ids (position_offset = padding_idx + 1): HF numbers the NON-PAD tokens of a sequence
+        // from padding_idx + 1 whatever side the padding is on — cumsum(input_ids != padding_idx) * mask + padding_idx
+        // (modeling_roberta.create_position_ids_from_input_ids); for a right-padded batch that is t + position_offset.
+        long long seen = 0;
         for (int t = 0; t < seq_len; ++t) {
             const size_t i = (size_t)b * seq_len + t;
+            const bool nonpad = c.position_offset > 0 ? input_ids[i] != c.position_offset - 1 : true;
+            seen += nonpad;
             const bool keep = attention_mask ? attention_mask[i] != 0 : true;
             if (pool == 2) slot[i] = keep ? (int)r : -1;
             if (!keep) continue;
@@ -466,7 +472,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             const long long ty = token_type_ids ? token_type_ids[i] : 0;
             if (ty < 0 || ty >= c.type_vocab_size) return bh_fail(BH_EINVAL, "token type %lld out of range", ty);
             tok[r] = (int)id;
-            pos[r] = t + c.position_offset;
+            pos[r] = c.position_offset > 0 ? (int)(nonpad ? seen + c.position_offset - 1 : c.position_offset - 1) : t;
             typ[r] = (int)ty;
             ++r;
         }

@@ -60,6 +60,8 @@ struct Options {
     // 2 = scan_topk192.hip where it applies (d = 768, k <= 56); 0 = scan_topk.hip (4 waves, 128-query tile)
     int scan_kernel = 3;
     int certify = 1;  // exactness certificate + exact fall-back scan for the queries it cannot prove (certify.hip)
+    int tail128 = 1;  // scan_topk256: a last pass of at most 128 queries runs on the 128-query kernel (5.6 instead of 7.2 ms at 21 M x 768)
+    int err_scale = 1;  // test-only: multiplies the certificate's error bound (forces queries through the fall-back)
 } g_opt;
 
 int pad_dim(int dim) {
@@ -103,7 +105,8 @@ struct bh_index {
     DevBuf<bh_u64> kth;          // [nq] canonical key of each query's k-th result
     DevBuf<_Float16> exact_q;    // [BH_EXACT_BATCH][D] uncertified queries gathered for the exact scan
     DevBuf<bh_u64> exact_keys;   // [BH_EXACT_BATCH][BH_EXACT_CAP] + [BH_EXACT_BATCH] thresholds
-    DevBuf<unsigned> exact_cnt;  // [BH_EXACT_BATCH]
+    DevBuf<unsigned> exact_cnt;  // [4][BH_EXACT_BATCH] counts | thresholds | query indices
+    DevBuf<unsigned> exact_rows; // [BH_EXACT_BATCH][BH_EXACT_CAP] rows the filter pass let through
     DevBuf<_Float16> qbuf;
     DevBuf<unsigned char> staging;
     unsigned char* pinned[2] = {nullptr, nullptr};  // host staging of the load path (upload_common)
@@ -125,14 +128,19 @@ struct bh_index {
 namespace {
 
 // Wait for a stream by polling it.  hipStreamSynchronize parks the thread once the wait gets long (tens of milliseconds:
-// every search over a whole corpus) and the wake-up costs 1-2 ms, 2 % of the headline search; a search is a blocking call
-// on a thread that has nothing else to do, so it spins (and falls back to the blocking wait after 10 s).
+// every search over a whole corpus) and the wake-up costs 1-2 ms, 2 % of the headline search.  A full-speed spin for the
+// whole search would hold a host core per rank (8 ranks per node next to tokenizer workers), so: spin for the first
+// 200 us (short searches), then poll every 50 us with the thread asleep in between (wake-up latency <= ~0.1 ms, a few
+// per cent of a core), and fall back to the blocking wait after 10 s.
 hipError_t spin_sync(hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned n = 0;; ++n) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
-        if ((n & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return hipStreamSynchronize(st);
+        if ((n & 15u) != 15u) continue;
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited > std::chrono::seconds(10)) return hipStreamSynchronize(st);
+        if (waited > std::chrono::microseconds(200)) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 
@@ -291,6 +299,12 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "certify") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "certify must be 0 or 1");
         g_opt.certify = (int)value;
+    } else if (s == "tail128") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "tail128 must be 0 or 1");
+        g_opt.tail128 = (int)value;
+    } else if (s == "certificate_error_scale") {
+        if (value < 1 || value > (1 << 24)) return fail(BH_EINVAL, "certificate_error_scale must be 1..2^24");
+        g_opt.err_scale = (int)value;  // (results stay exact: a looser bound only sends more queries through the fall-back)
     } else if (s == "dyn_tiles") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "dyn_tiles must be 0 or 1");
         g_opt.dyn_tiles = (int)value;
@@ -390,6 +404,7 @@ void bh_index_destroy(bh_index* ix) {
     ix->exact_q.release();
     ix->exact_keys.release();
     ix->exact_cnt.release();
+    ix->exact_rows.release();
     ix->qbuf.release();
     ix->staging.release();
     for (int b = 0; b < 2; ++b) {
@@ -427,7 +442,7 @@ int bh_index_finalize(bh_index* ix) {
     // largest row norm: the scale of the exactness certificate's error bound (certify.hip); one pass over the corpus
     ix->max_norm = 0.f;
     if (ix->n_rows > 0) {
-        int rc = ix->exact_cnt.ensure(BH_EXACT_BATCH);
+        int rc = ix->exact_cnt.ensure(4 * BH_EXACT_BATCH);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(ix->exact_cnt.p, 0, sizeof(unsigned), ix->stream));
         HIP_TRY(bh_launch_row_norm_max(ix->rows, ix->n_rows, ix->dim_padded, ix->exact_cnt.p, ix->stream));
@@ -505,7 +520,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     }
     *ix->n_uncert_host = 0u;
     // |mfma - canonical| <= 2 d 2^-24 |q| |x| for any summation order of d exact products in fp32
-    const float err_coef = g_opt.certify ? 2.0f * (float)dp * 5.9604645e-8f * ix->max_norm : 0.f;
+    const float err_coef = g_opt.certify ? 2.0f * (float)dp * 5.9604645e-8f * ix->max_norm * (float)g_opt.err_scale : 0.f;
 
     hipStream_t st = ix->stream;
     if (!ix->merge_stream) HIP_TRY(hipStreamCreateWithFlags(&ix->merge_stream, hipStreamNonBlocking));
@@ -517,7 +532,11 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
 
     hipEvent_t ev_begin = ix->event(0), ev_end = ix->event(1);
     if (!ev_begin || !ev_end) return fail(BH_EHIP, "hipEventCreate failed");
-    const int n_group = grouped ? (n_pass + group - 1) / group : n_pass;
+    // scan_topk256: a last pass of at most 128 queries (2 837 = 11 x 256 + 21) runs on the 128-query kernel — the same
+    // corpus pass costs 5.6 instead of 7.2 ms there —, as a group of its own (its lists are 128 queries wide)
+    const bool tail128 = grouped && use256 && bq == 256 && g_opt.tail128 && g_opt.ablate == 0 && nq % bq != 0 && nq % bq <= 128;
+    const int n_main = tail128 ? n_pass - 1 : n_pass;
+    const int n_group = grouped ? (n_main + group - 1) / group + (tail128 ? 1 : 0) : n_pass;
     for (int p = 0; p < n_group; ++p)
         if (!ix->event(2 + 4 * p + 3)) return fail(BH_EHIP, "hipEventCreate failed");
 
@@ -575,8 +594,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
         return bh_launch_scan(sa, dp, kp, qw, grid, st);
     };
     if (grouped) {
-        for (int g0 = 0, gi = 0; g0 < n_pass; g0 += group, ++gi) {
-            const int g1 = std::min(n_pass, g0 + group);
+        for (int g0 = 0, gi = 0; g0 < n_main; g0 += group, ++gi) {
+            const int g1 = std::min(n_main, g0 + group);
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi), st));
             for (int p = g0; p < g1; ++p) {
                 HIP_TRY(launch_scan(scan_args(p, ix->partial.p + (size_t)(p - g0) * partial_elems)));
@@ -587,6 +606,18 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
             const int q0 = passes[g0].first;
             const int nq_group = std::min(nq, passes[g1 - 1].first + bq) - q0;
             HIP_TRY(bh_launch_merge_rescore(merge_args(q0, bq, grid, ix->partial.p, (long long)partial_elems), kp, nq_group, st));
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 3), st));
+        }
+        if (tail128) {
+            const int gi = n_group - 1, p = n_pass - 1, q0 = passes[p].first;
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi), st));
+            BhScanArgs sa = scan_args(p, ix->partial.p);  // (stream order: the main groups' merges are done with the lists)
+            sa.clk = nullptr;
+            sa.qsplit = 1;
+            HIP_TRY(bh_launch_scan(sa, dp, kp, 1, grid, st));
+            alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + 128.0 * ix->dim * 2.0 + 128.0 * k * 12.0;
+            HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 1), st));
+            HIP_TRY(bh_launch_merge_rescore(merge_args(q0, 128, grid, ix->partial.p, 0), kp, nq - q0, st));
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 3), st));
         }
     } else {
@@ -615,7 +646,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(spin_sync(st));
     // ---- exactness: queries the certificate could not prove go through the exact scan (certify.hip)
-    int64_t n_uncert = 0;
+    int64_t n_uncert = 0, n_filter_passes = 0, n_filter_rows = 0;
     double exact_ms = 0;
     if (g_opt.certify && *ix->n_uncert_host != 0u) {
         std::vector<unsigned> flags((size_t)nq);
@@ -629,44 +660,65 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
             hipEvent_t x0 = ix->event(2 + 4 * (size_t)n_group), x1 = ix->event(3 + 4 * (size_t)n_group);
             if (!x0 || !x1) return fail(BH_EHIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(x0, st));
+            // one FILTER PASS per BH_EXACT_BATCH (128) uncertified queries: the 128-query scan's stream + MFMA loop with the
+            // fixed threshold  k-th canonical score - error bound  lists every row that can still belong to the top k
+            // (scan_topk.hip ABL 5), bh_exact_rescore_kernel gives the listed rows their canonical scores, the host sorts
             if ((rc = ix->exact_q.ensure((size_t)BH_EXACT_BATCH * dp))) return rc;
             if ((rc = ix->exact_keys.ensure((size_t)BH_EXACT_BATCH * BH_EXACT_CAP + BH_EXACT_BATCH))) return rc;
-            if ((rc = ix->exact_cnt.ensure(BH_EXACT_BATCH))) return rc;
-            bh_u64* thr_dev = ix->exact_keys.p + (size_t)BH_EXACT_BATCH * BH_EXACT_CAP;
+            if ((rc = ix->exact_rows.ensure((size_t)BH_EXACT_BATCH * BH_EXACT_CAP))) return rc;
+            if ((rc = ix->exact_cnt.ensure(4 * BH_EXACT_BATCH))) return rc;  // counts | thresholds (float) | query indices | spare
+            bh_u64* kth_dev = ix->exact_keys.p + (size_t)BH_EXACT_BATCH * BH_EXACT_CAP;
+            unsigned* cnt_dev = ix->exact_cnt.p;
+            float* thr_dev = reinterpret_cast<float*>(ix->exact_cnt.p + BH_EXACT_BATCH);
+            int* todo_dev = reinterpret_cast<int*>(ix->exact_cnt.p + 2 * BH_EXACT_BATCH);
             std::vector<bh_u64> keys;
             std::vector<float> row_s((size_t)k);
             std::vector<long long> row_i((size_t)k);
             for (size_t b0 = 0; b0 < todo.size(); b0 += BH_EXACT_BATCH) {
                 const int nb = (int)std::min<size_t>(BH_EXACT_BATCH, todo.size() - b0);
-                for (int j = 0; j < nb; ++j) {
-                    const int q = todo[b0 + j];
-                    HIP_TRY(hipMemcpyAsync(ix->exact_q.p + (size_t)j * dp, ix->qbuf.p + (size_t)q * dp, (size_t)dp * 2, hipMemcpyDeviceToDevice, st));
-                    HIP_TRY(hipMemcpyAsync(thr_dev + j, ix->kth.p + q, sizeof(bh_u64), hipMemcpyDeviceToDevice, st));
-                }
-                HIP_TRY(hipMemsetAsync(ix->exact_cnt.p, 0, BH_EXACT_BATCH * sizeof(unsigned), st));
+                HIP_TRY(hipMemcpyAsync(todo_dev, todo.data() + b0, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemsetAsync(cnt_dev, 0, BH_EXACT_BATCH * sizeof(unsigned), st));
+                HIP_TRY(bh_launch_exact_prepare(ix->qbuf.p, todo_dev, nb, ix->kth.p, err_coef, dp, ix->exact_q.p, kth_dev, thr_dev, st));
+                BhScanArgs fa = scan_args(0, nullptr);
+                fa.qtile = ix->exact_q.p;
+                fa.cand = nullptr;
+                fa.gthr = nullptr;
+                fa.share = 0;
+                fa.ablate = 0;
+                fa.ring_variant = 0;
+                fa.qsplit = 1;
+                fa.dma_interleave = 1;
+                fa.clk = nullptr;
+                fa.fix_thr = thr_dev;
+                fa.fix_cnt = cnt_dev;
+                fa.fix_rows = ix->exact_rows.p;
+                fa.fix_cap = BH_EXACT_CAP;
+                HIP_TRY(bh_launch_filter_scan(fa, dp, grid, st));
                 BhExactArgs ea;
                 ea.corpus = ix->rows;
                 ea.n_rows = ix->n_rows;
                 ea.dim_padded = dp;
                 ea.q = ix->exact_q.p;
                 ea.nqf = nb;
-                ea.kth_key = thr_dev;
+                ea.kth_key = kth_dev;
+                ea.rows = ix->exact_rows.p;
+                ea.cnt = cnt_dev;
                 ea.out_keys = ix->exact_keys.p;
-                ea.out_cnt = ix->exact_cnt.p;
-                HIP_TRY(bh_launch_exact_scan(ea, st));
+                HIP_TRY(bh_launch_exact_rescore(ea, st));
                 unsigned cnt[BH_EXACT_BATCH];
-                HIP_TRY(hipMemcpyAsync(cnt, ix->exact_cnt.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(cnt, cnt_dev, sizeof cnt, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 for (int j = 0; j < nb; ++j) {
                     const int q = todo[b0 + j];
                     if (cnt[j] > BH_EXACT_CAP)
                         return fail(BH_EUNSUPPORTED, "query %d: more than %d rows reach its k-th score within rounding error "
                                     "(%u): exact fall-back list overflow", q, BH_EXACT_CAP, cnt[j]);
+                    n_filter_rows += cnt[j];
                     keys.resize(cnt[j]);
                     HIP_TRY(hipMemcpy(keys.data(), ix->exact_keys.p + (size_t)j * BH_EXACT_CAP, (size_t)cnt[j] * sizeof(bh_u64), hipMemcpyDeviceToHost));
-                    std::sort(keys.begin(), keys.end(), std::greater<bh_u64>());  // canonical order: score desc, row asc
+                    std::sort(keys.begin(), keys.end(), std::greater<bh_u64>());  // canonical order: score desc, row asc (0 = did not qualify: last)
                     for (int t = 0; t < k; ++t) {
-                        if ((size_t)t < keys.size()) {
+                        if ((size_t)t < keys.size() && keys[(size_t)t] != 0ull) {
                             const unsigned o = (unsigned)(keys[(size_t)t] >> 32);
                             const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
                             memcpy(&row_s[(size_t)t], &u, 4);
@@ -680,6 +732,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
                     HIP_TRY(hipMemcpy(reinterpret_cast<long long*>(out_ids_dev) + (size_t)q * k, row_i.data(), (size_t)k * sizeof(long long),
                                       hipMemcpyDefault));
                 }
+                ++n_filter_passes;
             }
             HIP_TRY(hipEventRecord(x1, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -714,6 +767,8 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     c.algorithmic_bytes = alg_bytes;
     c.uncertified_queries = n_uncert;
     c.exact_ms = exact_ms;
+    c.exact_passes = n_filter_passes;
+    c.exact_rows_rescored = n_filter_rows;
     c.shader_mhz = 0;
     if (use256) {  // effective shader clock of the last scan launch: cycles per 100 MHz tick, averaged over the workgroups
         std::vector<bh_u64> h((size_t)grid * 8);

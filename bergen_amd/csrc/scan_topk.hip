@@ -71,6 +71,11 @@ __device__ __forceinline__ void sort_candidates(u64 (&e)[2 * KP / 64], const u64
 // NT = non-temporal cache policy on the corpus stream.
 // ABL (ablation, bench-only, 0 in production): 1 = no threshold epilogue, 2 = stream only (no LDS
 // reads, no MFMA), 3 = LDS reads without MFMA, 4 = MFMA without LDS reads.
+// ABL = 5 is not an ablation but the FILTER PASS of the exactness fall-back (certify.hip, index.hip): the same stream and
+// MFMA loop against the queries the certificate could not prove, with a FIXED per-query threshold (their k-th canonical
+// score minus the MFMA error bound) instead of the running top-k: every row whose MFMA score reaches it is appended to
+// the query's list a.fix_rows (few rows: the top k and whatever lies within rounding error of the k-th score); no
+// candidate buffers, no bounds exchange, no final sort.
 template <int NK, int KP, int LS, int R, int QW, bool NT, int ABL = 0, bool IL = true>
 __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
 #pragma unroll
     for (int w2 = 0; w2 < QW; ++w2) {
         thr[w2] = -__builtin_inff();
+        if constexpr (ABL == 5) thr[w2] = a.fix_thr[(wave * QW + w2) * 32 + ql];  // (+inf for the tile's unused queries)
         cnt[w2] = 0;
         pub[w2] = -__builtin_inff();
 #pragma unroll
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * LS) : "memory");
                 // The refill of the slot everybody just left: either all LS instructions here (the matrix pipe is idle
                 // while they issue, ~100 cycles each under load), or one after every line's MFMAs (dma_interleave).
-                constexpr bool spread = ABL == 0 && IL;
+                constexpr bool spread = (ABL == 0 || ABL == 5) && IL;
                 if (!spread) issue_stage();
                 const unsigned char* st = smem + cslot * STAGE_BYTES;
                 // fragment reads run one 128-byte line (4 k-steps) ahead of the MFMAs
@@ -307,6 +313,20 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
                 float m = acc[w2][0];
 #pragma unroll
                 for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[w2][v]);
+                if constexpr (ABL == 5) {
+                    if (__builtin_amdgcn_ballot_w64(m >= thr[w2]) != 0ull) {
+                        const int qi = (wave * QW + w2) * 32 + ql;
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) {
+                            const long long row = row0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                            if (acc[w2][v] >= thr[w2] && row < a.n_rows) {
+                                const unsigned slot = atomicAdd(a.fix_cnt + qi, 1u);
+                                if (slot < a.fix_cap) a.fix_rows[(size_t)qi * a.fix_cap + slot] = (unsigned)row;
+                            }
+                        }
+                    }
+                    continue;
+                }
                 if constexpr (ABL != 0) {
                     asm volatile("" ::"v"(m));
                     m = -__builtin_inff();
@@ -392,6 +412,7 @@ __global__ void __launch_bounds__(256, 1) bh_scan_topk_kernel(BhScanArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail re-fetches
     }
 
+    if constexpr (ABL == 5) return;
     // ---- final: every wave sorts its queries' buffers and publishes the best KP -------------
 #pragma unroll
     for (int w2 = 0; w2 < QW; ++w2) {
@@ -483,6 +504,20 @@ hipError_t bh_launch_scan(const BhScanArgs& a, int dim_padded, int kp, int qw, i
             if (a.ring_variant == 4 && kp == 64) return launch_kp<48, 6, 5, 1>(a, kp, grid, stream);
             return launch_qw<48, 6, 6>(a, kp, qw, grid, stream);
         case 1024: return launch_qw<64, 8, 4>(a, kp, qw, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// The fall-back's filter pass (ABL = 5 above): 128 queries per launch, every padded dim.
+hipError_t bh_launch_filter_scan(const BhScanArgs& a, int dim_padded, int grid, hipStream_t stream) {
+    switch (dim_padded) {
+        case 64: return launch_one<4, 64, 1, 6, 1, true, 5>(a, grid, stream);
+        case 128: return launch_one<8, 64, 2, 6, 1, true, 5>(a, grid, stream);
+        case 256: return launch_one<16, 64, 4, 6, 1, true, 5>(a, grid, stream);
+        case 384: return launch_one<24, 64, 6, 6, 1, true, 5>(a, grid, stream);
+        case 512: return launch_one<32, 64, 8, 4, 1, true, 5>(a, grid, stream);
+        case 768: return launch_one<48, 64, 6, 6, 1, true, 5>(a, grid, stream);
+        case 1024: return launch_one<64, 64, 8, 4, 1, true, 5>(a, grid, stream);
     }
     return hipErrorInvalidValue;
 }

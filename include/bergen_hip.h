@@ -61,8 +61,11 @@ typedef struct bh_counters {
     double shader_mhz;        /* effective shader clock during the last scan launch (s_memtime per 100 MHz tick); 0 = not measured */
     int64_t uncertified_queries; /* queries whose top-k the exactness certificate could not prove from the scan's candidate
                                     lists (more than KP - k rows within MFMA rounding error of the k-th score); they were
-                                    answered by the exact fall-back scan (one more corpus pass per 8 such queries) */
+                                    answered by the exact fall-back: an MFMA filter pass with a fixed threshold (one more
+                                    corpus pass per 128 such queries) + canonical re-scoring of the rows it lets through */
     double exact_ms;          /* time spent in that fall-back (wall, included in total_ms) */
+    int64_t exact_passes;     /* filter passes (corpus passes) the fall-back of the last search took */
+    int64_t exact_rows_rescored; /* rows the filter passes let through, summed over the uncertified queries */
 } bh_counters;
 
 /* Library / device lifecycle ------------------------------------------------------- */
@@ -112,7 +115,7 @@ int bh_search(bh_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int
  * round trip).  The output buffers may also be PINNED HOST memory (hipHostMalloc / torch pin_memory): the merge kernel
  * then writes the result lists there itself and no device-to-host copy follows.  Synchronous: the lists are complete on
  * return.  Every query's top-k is proven exact from the scan's candidate lists by a certificate; queries it cannot prove
- * are re-done by an exact fp64 scan inside the call (bh_counters.uncertified_queries / exact_ms; option "certify"). */
+ * are re-done exactly inside the call (MFMA filter pass + fp64 re-scoring) (bh_counters.uncertified_queries / exact_ms; option "certify"). */
 int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k,
                      int64_t id_offset, float* out_scores_dev, int64_t* out_ids_dev);
 

@@ -174,25 +174,51 @@ void oracle_canonical_search(const uint16_t* q, const uint16_t* x, int64_t nq, i
                              int64_t id_offset, float* out_scores, int64_t* out_ids) {
     /* decode the corpus once */
     float* xf = (float*)malloc((size_t)n * d * sizeof(float) + 4);
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n * (int64_t)d; ++i) xf[i] = oracle_half_to_float(x[i]);
+    /* Tasks = (query, row range): a handful of queries over a million-row block (the streaming full-size check of
+     * tests/test_gpu_search.py) still fills every core.  Each task keeps the best k of its range; the best k of the union
+     * of the per-range lists is the best k of all rows (every row is offered to exactly one heap, and `precedes` is a
+     * total order), so the result does not depend on the split. */
+    const int64_t span = 16384;
+    const int64_t n_spans = n > 0 ? (n + span - 1) / span : 1;
+    pair_t* part = (pair_t*)malloc((size_t)nq * n_spans * k * sizeof(pair_t) + 8);
+    int* part_n = (int*)malloc((size_t)nq * n_spans * sizeof(int) + 8);
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int64_t qi = 0; qi < nq; ++qi) {
+        for (int64_t sp = 0; sp < n_spans; ++sp) {
+            double* qd = (double*)malloc((size_t)d * sizeof(double) + 8);
+            for (int j = 0; j < d; ++j) qd[j] = (double)oracle_half_to_float(q[qi * d + j]);
+            topk_t t;
+            t.h = part + (qi * n_spans + sp) * k;
+            t.n = 0;
+            t.k = k;
+            int64_t r1 = (sp + 1) * span < n ? (sp + 1) * span : n;
+            for (int64_t r = sp * span; r < r1; ++r) {
+                const float* xr = xf + r * d;
+                double s = 0.0;
+                for (int j = 0; j < d; ++j) s += qd[j] * (double)xr[j]; /* sequential, index order */
+                topk_push(&t, (float)s, id_offset + r);
+            }
+            part_n[qi * n_spans + sp] = t.n;
+            free(qd);
+        }
+    }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t qi = 0; qi < nq; ++qi) {
-        double* qd = (double*)malloc((size_t)d * sizeof(double) + 8);
-        for (int j = 0; j < d; ++j) qd[j] = (double)oracle_half_to_float(q[qi * d + j]);
         topk_t t;
-        t.h = (pair_t*)malloc((size_t)k * sizeof(pair_t));
+        t.h = (pair_t*)malloc((size_t)k * sizeof(pair_t) + 8);
         t.n = 0;
         t.k = k;
-        for (int64_t r = 0; r < n; ++r) {
-            const float* xr = xf + r * d;
-            double s = 0.0;
-            for (int j = 0; j < d; ++j) s += qd[j] * (double)xr[j]; /* sequential, index order */
-            topk_push(&t, (float)s, id_offset + r);
+        for (int64_t sp = 0; sp < n_spans; ++sp) {
+            const pair_t* h = part + (qi * n_spans + sp) * k;
+            for (int c = 0; c < part_n[qi * n_spans + sp]; ++c) topk_push(&t, h[c].score, h[c].id);
         }
         topk_emit(&t, out_scores + qi * k, out_ids + qi * k);
         free(t.h);
-        free(qd);
     }
+    free(part_n);
+    free(part);
     free(xf);
 }
 

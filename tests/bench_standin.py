@@ -79,6 +79,8 @@ class OracleEnv:
     def make_index(self, n_rows, dim):
         return OracleIndex(n_rows, dim)
 
+    make_stage = bench.HipEnv.make_stage  # the bench's own stage construction (Retrieve with search_rank / search_world)
+
     def sync(self):
         pass
 

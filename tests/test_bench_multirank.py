@@ -53,3 +53,5 @@ def test_bench_line_of_a_multi_rank_run(world):
 def test_single_rank_standin_agrees():
     r = _run(1, [])
     assert r["n_gpus"] == 1 and r["parity_check"] == "pass"
+    # the streaming full-list gate (a float64 GEMM per block, no oracle) agrees with the oracle-backed index on complete lists
+    assert r["full_list_gate"]["ids_and_fp32_scores_bit_exact"] is True and r["full_list_gate"]["queries"] == 8

@@ -114,6 +114,28 @@ def test_dense_from_a_checkpoint_directory_runs_on_the_hip_path(kind, pooler, to
     assert dense("query", qb)["embedding"].shape == (1, 128)
 
 
+@pytest.mark.parametrize("kind", ["xlmr", "bert64"])
+def test_left_padded_batches_get_hf_position_ids(kind, toy_tokenizer_files, tmp_path):
+    """A left-padding tokenizer (round-2 advisor finding): RoBERTa-family position ids are cumsum(input_ids != pad) + pad,
+    not token_index + pad + 1 — the HIP forward pass must number the real tokens as HF does on either padding side; BERT
+    positions are the plain token index (pads included), also as HF."""
+    import transformers as T
+    import bergen_amd
+    tok, vocab = toy_tokenizer_files
+    path = _make(kind, tok, vocab, tmp_path / kind)
+    dense = bergen_amd.Dense(model_name=path, max_len=32, pooler=bergen_amd.MeanPooler(), similarity=bergen_amd.DotProduct())
+    assert dense.backend == "hip"
+    dense.tokenizer.padding_side = "left"
+    batch = dense.collate_fn([{"content": t} for t in TEXTS], "doc")
+    assert int(batch["attention_mask"][:, 0].min()) == 0, "the batch is not left-padded: the case tests nothing"
+    got = dense("doc", batch)["embedding"]
+    ref_model = T.AutoModel.from_pretrained(path, torch_dtype=torch.float32).eval()
+    with torch.no_grad():
+        hidden = ref_model(**{k: v for k, v in batch.items() if k != "token_type_ids" or kind == "bert64"})[0]
+    want = bergen_amd.MeanPooler().pool(hidden, batch["attention_mask"])
+    _close(got.float().cpu().numpy(), want.numpy(), f"{kind}/left-padded")
+
+
 def test_splade_from_a_checkpoint_directory_runs_on_the_hip_path(toy_tokenizer_files, tmp_path):
     import transformers as T
     import bergen_amd

@@ -157,3 +157,59 @@ def test_host_upload_through_pinned_staging(dtype, dim):
     assert i[:, 0].tolist() == [5, n // 2, n - 1]
     ws, wi = c_oracle.canonical_search(q.numpy(), x.half().numpy(), 3)
     compare.assert_bit_exact(s, i, ws, wi, f"pinned staging {dtype} {dim}")
+
+
+@pytest.mark.parametrize("metric", ["ip", "cos"])
+def test_sharded_search_through_the_stage_two_shards_on_one_gpu(tmp_path, monkeypatch, metric):
+    """Retrieve(search_rank=r, search_world=2).retrieve(): each 'rank' keeps its row shard of the chunk folder resident
+    (the shard boundary cuts through a chunk file), searches it with global row ids through the HIP kernels, the packed
+    lists are gathered (the collective is replaced by a copy: both ranks live in this process, on this one GPU) and merged
+    by the HIP merge kernel on rank 0.  Result = the single-index stage = the oracle, bit for bit; rank 1 returns None
+    (search_results="rank0").  The gloo world-2/3 twin of this test runs in tests/test_retrieve_sharded_gloo.py."""
+    import datasets
+    import bergen_amd
+    from bergen_amd import sharded
+    g = torch.Generator().manual_seed(77)
+    n, nq, d, k = 30_001, 300, 768, 50
+    x = torch.randn(n, d, generator=g).half()
+    x[20_000] = x[100]                     # a tie across the shard boundary
+    q = torch.randn(nq, d, generator=g).half()
+    q_path, d_path = str(tmp_path / "q"), str(tmp_path / "d")
+    os.makedirs(q_path)
+    os.makedirs(d_path)
+    for j, (a, b) in enumerate([(0, 9000), (9000, 21_000), (21_000, n)]):
+        torch.save(x[a:b].clone(), os.path.join(d_path, f"embedding_chunk_{10 * (j + 1)}.pt"))
+    torch.save(q, os.path.join(q_path, "embedding_chunk_0.pt"))
+    dataset = {"doc": datasets.Dataset.from_dict({"id": [f"doc{i}" for i in range(n)]}),
+               "query": datasets.Dataset.from_dict({"id": [f"q{i}" for i in range(nq)]})}
+    sim = bergen_amd.DotProduct() if metric == "ip" else bergen_amd.CosineSim()
+
+    def stage(**kw):
+        return bergen_amd.Retrieve(init_args=_TableDense(q, x, sim), batch_size=64, num_workers=0, **kw)
+
+    sent = {}
+
+    def fake_gather(flat, packed, group=None):
+        per = packed.numel()
+        sent[fake_gather.rank] = packed.clone()
+        for r, p in sent.items():
+            flat[r * per:(r + 1) * per].copy_(p)
+    monkeypatch.setattr(sharded.dist, "all_gather_into_tensor", fake_gather)
+    ranks = [stage(search_rank=r, search_world=2, search_results="rank0") for r in range(2)]
+    for _ in range(2):                     # second round: shards resident, gather buffers reused
+        fake_gather.rank = 1
+        assert ranks[1].retrieve(dataset, q_path, d_path, k) is None
+        fake_gather.rank = 0
+        out = ranks[0].retrieve(dataset, q_path, d_path, k)
+    assert ranks[0]._resident[d_path][0].n_rows == 15_001 and ranks[1]._resident[d_path][0].n_rows == 15_000
+    single = stage()
+    want = single.retrieve(dataset, q_path, d_path, k)
+    assert torch.equal(out["score"], want["score"]) and out["doc_id"] == want["doc_id"] and out["q_id"] == want["q_id"]
+    xq, xd = q.numpy(), x.numpy()
+    if metric == "cos":
+        xq, xd = c_oracle.l2_normalize_rows(xq), c_oracle.l2_normalize_rows(xd)
+    ws, wi = c_oracle.canonical_search(xq, xd, k)
+    got_i = np.array([[int(s[3:]) for s in row] for row in out["doc_id"]])
+    compare.assert_bit_exact(out["score"].numpy(), got_i, ws, wi, f"sharded stage {metric}")
+    for r in ranks + [single]:
+        r.close()

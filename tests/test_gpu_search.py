@@ -268,7 +268,11 @@ def test_repeatability(amd):
 def test_full_size_properties(amd):
     """BASELINE configs[1] size: 21M x 768 fp16 resident (32 GB).  Size-independent properties:
     planted positives come back on top with their oracle scores, lists are canonically sorted,
-    and a 2-way row split merged by the HIP kernel equals the single-index result."""
+    and a 2-way row split merged by the HIP kernel equals the single-index result.
+    And the FULL lists of the first 16 queries against the oracle, bit for bit: the corpus blocks are copied to the host as
+    they are generated, the oracle keeps a running top-50 per block (`c_oracle.canonical_search` with the block's row
+    offset) and the per-block lists are merged by the oracle's own merge — ranks 1..50 at 21 M x 768 are then the oracle's
+    word, not the kernel's certificate vouching for itself."""
     free, total = torch.cuda.mem_get_info()
     n, d, nq, k = 21_000_000, 768, 200, 50
     if free < (n * d * 2) * 2.2:
@@ -282,6 +286,9 @@ def test_full_size_properties(amd):
     plant_rows = torch.randint(0, n, (nq, 5), generator=gen, device=dev)
     block = 1_000_000
     planted = {}
+    n_streamed = 16
+    q_head = q[:n_streamed].cpu().numpy()
+    part_s, part_i = [], []
     for b0 in range(0, n, block):
         m = min(block, n - b0)
         rows = torch.nn.functional.normalize(torch.randn(m, d, generator=gen, device=dev), dim=1)
@@ -295,6 +302,9 @@ def test_full_size_properties(amd):
             r = int(plant_rows[qi, j])
             planted[(qi, r)] = rows[r - b0].cpu().numpy()
         ix.upload(rows, row0=b0)
+        bs, bi = c_oracle.canonical_search(q_head, rows.cpu().numpy(), k, id_offset=b0)  # the streaming oracle's block step
+        part_s.append(bs)
+        part_i.append(bi)
         lo_n = n // 2
         if b0 + m <= lo_n:
             half_lo.upload(rows, row0=b0)
@@ -322,6 +332,10 @@ def test_full_size_properties(amd):
     for qi in range(nq):
         mine = sorted(r for (a, r) in planted if a == qi)
         assert sorted(i_np[qi, :len(mine)].tolist()) == mine
+    # the complete top-50 lists of the first queries vs the streaming oracle
+    ws, wi = c_oracle.merge_topk(np.stack(part_s), np.stack(part_i))
+    assert wi.min() >= 0 and len(set(wi[0].tolist())) == k
+    compare.assert_bit_exact(s_np[:n_streamed], i_np[:n_streamed], ws, wi, "full lists at 21M x 768 vs the streaming oracle")
     # shard invariance at full size
     s1, i1 = half_lo.search(q, k, id_offset=0)
     s2, i2 = half_hi.search(q, k, id_offset=n // 2)
@@ -408,7 +422,8 @@ def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
     """More rows than the candidate margin (KP - k = 14 / 8 / 8) whose canonical scores TIE the k-th one exactly while
     their fp32 MFMA scores differ in the last bits (same products, summed in another order): the scan's top-KP by MFMA
     score then holds an arbitrary subset of the tied rows, the canonical order wants the lowest row indices.  The
-    certificate must flag the query and the exact fall-back scan must return the oracle's list bit for bit."""
+    certificate must flag the query and the exact fall-back (MFMA filter pass + canonical re-scoring) must return the
+    oracle's list bit for bit."""
     from bergen_amd import _lib
     rng = np.random.default_rng(1000 + k + d)
     n, cluster, better = 4000, 40, k - 15
@@ -434,7 +449,7 @@ def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
         got_s, got_i = ix.search(q, k)
         c = ix.counters()
         compare.assert_bit_exact(got_s, got_i, ws, wi, f"near-tie cluster k={k} d={d}")
-        assert c["uncertified_queries"] >= 1 and c["exact_ms"] > 0
+        assert c["uncertified_queries"] >= 1 and c["exact_ms"] > 0 and c["exact_passes"] == 1
         # an ordinary workload is certified from the candidate lists alone
         got_s, got_i = ix.search(q[1:], k)
         assert ix.counters()["uncertified_queries"] == 0
@@ -445,6 +460,79 @@ def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
         assert ix.counters()["uncertified_queries"] == 0
     finally:
         _lib.set_option("certify", 1)
+        ix.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(30_011, 768, 300, 50), (9_000, 1024, 130, 200), (5_000, 384, 70, 100), (3_000, 100, 40, 10),
+                                      (2_000, 64, 9, 5), (4_000, 512, 129, 120), (4_001, 200, 5, 248)])
+def test_fall_back_filter_pass_is_exact_for_every_query(amd, n, d, nq, k):
+    """The exact fall-back on its own: with the certificate's error bound scaled up (test option
+    certificate_error_scale) NO query can be certified, so every result comes from the MFMA filter pass (fixed threshold =
+    k-th canonical score - bound; scan_topk.hip ABL 5) + canonical re-scoring of the rows it lets through + the host sort.
+    Bit-exact against the oracle at every padded dim, across the 128-query batches of the fall-back, with exact duplicates
+    straddling the k-th rank."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(n + d + k)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    x[n // 2: n // 2 + 30] = x[7]          # 31 exact duplicates: ties decided by row index
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    try:
+        _lib.set_option("certificate_error_scale", 32)   # a bound a little wider than the gaps: most queries, short lists
+        s, i = ix.search(q, k)
+        c = ix.counters()
+        assert 0 < c["uncertified_queries"] <= nq and c["exact_passes"] == -(-c["uncertified_queries"] // 128)
+        compare.assert_bit_exact(s, i, ws, wi, f"fall-back for most queries n={n} d={d} nq={nq} k={k}")
+        _lib.set_option("certificate_error_scale", 1 << 12)  # a bound wider than the score range: every query, every row listed
+        s, i = ix.search(q, k)
+        c = ix.counters()
+        assert c["uncertified_queries"] == nq and c["exact_passes"] == -(-nq // 128) and c["exact_ms"] > 0
+        assert c["exact_rows_rescored"] >= nq * k
+        compare.assert_bit_exact(s, i, ws, wi, f"fall-back only n={n} d={d} nq={nq} k={k}")
+        # device queries / device results, with a global row offset
+        import torch
+        sd, idd = ix.search(torch.from_numpy(q).cuda(), k, id_offset=1_000_000)
+        compare.assert_bit_exact(sd.cpu().numpy(), idd.cpu().numpy() - 1_000_000, ws, wi, "fall-back only, device path")
+        _lib.set_option("certificate_error_scale", 1)
+        s, i = ix.search(q, k)
+        assert ix.counters()["exact_passes"] == 0 or ix.counters()["uncertified_queries"] > 0
+        compare.assert_bit_exact(s, i, ws, wi, "certificate back on")
+    finally:
+        _lib.set_option("certificate_error_scale", 1)
+        ix.close()
+
+
+@pytest.mark.parametrize("nq", [1, 21, 128, 129, 256 + 21, 256 + 128, 256 + 129, 2 * 256 + 100])
+def test_tail_pass_on_the_128_query_kernel(amd, nq):
+    """scan_topk256 (d = 768): a last pass of at most 128 queries runs on the 128-query kernel, merged as a group of its own
+    (option tail128, default on) — same bits as without it and as the oracle, around the routing boundaries."""
+    from bergen_amd import _lib
+    rng = np.random.default_rng(nq)
+    n, d, k = 20_000, 768, 50
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    try:
+        for tail in (1, 0):
+            _lib.set_option("tail128", tail)
+            s, i = ix.search(q, k)
+            c = ix.counters()
+            assert c["n_passes"] == -(-nq // 256) and c["query_tile"] == 256
+            want_bytes = 0
+            for p in range(c["n_passes"]):
+                left = nq - 256 * p
+                w = 128 if (tail and left <= 128) else 256
+                want_bytes += n * d * 2 + w * d * 2 + w * k * 12
+            assert c["algorithmic_bytes"] == want_bytes
+            compare.assert_bit_exact(s, i, ws, wi, f"tail128={tail} nq={nq}")
+    finally:
+        _lib.set_option("tail128", 1)
         ix.close()
 
 
