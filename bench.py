@@ -57,6 +57,7 @@ def parse_args():
                    help="queries whose COMPLETE top-k lists the parity gate recomputes over the whole corpus (N = 1; 0 = off)")
     p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
+    p.add_argument("--no-certificate-leg", action="store_true", help="skip the certificate / fall-back leg on the clustered, non-unit-norm corpus")
     p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg (index folders -> doc-id strings)")
     p.add_argument("--stage-rows", type=int, default=2_100_000, help="documents of the Retrieve.retrieve-level leg")
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
@@ -66,6 +67,8 @@ def parse_args():
     p.add_argument("--enc-steps", type=int, default=3)
     p.add_argument("--no-splade", action="store_true", help="skip the SPLADE legs (configs[3]: MLM-head encode, sparse search)")
     p.add_argument("--splade-docs", type=int, default=21_000_000, help="documents of the synthetic SPLADE corpus (S4: 21 M, ~180 terms each)")
+    p.add_argument("--splade-term-seeds", type=int, default=3,
+                   help="independent draws of the S4 term-set recipe behind the SPLADE corpus blocks (every block gets fresh weights)")
     p.add_argument("--sweep", action="store_true", help="also time kernel variants (written to gpurun_out/sweep.json)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                    help="optional PMC-derived HBM bytes per scan launch (written by profiles/collect_pmc.py)")
@@ -239,7 +242,7 @@ def splade_legs(args, device_index):
     * encode: BERT-base + tied masked-LM head over 30 522 terms + max-over-tokens pooling on the encoder leg's batch
       (`BertEncoder.encode_splade`; the [B, T, vocab] logits are never materialised);
     * search: SURVEY §8d S4 as stated — synthetic CSR corpus of 21 M documents (V = 30 522, Poisson(180) terms per document
-      clipped to [16, 400], Zipf(1.1) term ids drawn without replacement; a 1 M-document block repeated), 64-query tiles,
+      clipped to [16, 400], Zipf(1.1) term ids drawn without replacement; 21 distinct 1 M-document blocks), 64-query tiles,
       top-k; roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per tile pass.
     Self-check on a 200 k-document slice: both HIP kernels agree bit for bit, canonical order, scores recomputed in numpy."""
     from bergen_amd import BertEncoder, SparseIndex, synth
@@ -274,13 +277,31 @@ def splade_legs(args, device_index):
     del emb
     enc.close()
     V, block = 30522, 1_000_000
-    blk = synth.random_sparse_corpus_device(min(block, args.splade_docs), V, seed=4, device=torch.device("cuda", device_index))
+    dev = torch.device("cuda", device_index)
+    # 21 DISTINCT 1 M-document blocks (round 2 repeated one block 21 times: every document then had 20 exact duplicates and a
+    # query's top-50 collapsed to its top-3 distinct documents, which flattered the threshold filter): the term sets come
+    # from --splade-term-seeds independent draws of the S4 recipe, used in turn, and EVERY block gets its own weights
+    # (log1p(Exp(1)), drawn on the device) — no two documents of the corpus share their scores.
+    n_blocks = (args.splade_docs + block - 1) // block
+    t_gen = time.perf_counter()
+    term_sets = [synth.random_sparse_corpus_device(min(block, args.splade_docs), V, seed=4 + 1000 * j, device=dev)
+                 for j in range(max(1, min(args.splade_term_seeds, n_blocks)))]
+    gen_s = time.perf_counter() - t_gen
     ix = SparseIndex(args.splade_docs, V, device=device_index)
-    done = 0
-    while done < args.splade_docs:  # the corpus is the block repeated (timing depends on sizes only)
-        m = min(len(blk[0]) - 1, args.splade_docs - done)
-        ix.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
+    done, b = 0, 0
+    blk = term_sets[0]
+    while done < args.splade_docs:
+        indptr, terms, w0 = term_sets[b % len(term_sets)]
+        m = min(len(indptr) - 1, args.splade_docs - done)
+        nnz_b = int(indptr[m])
+        if b < len(term_sets):
+            w = w0[:nnz_b]
+        else:
+            gw = torch.Generator(device=dev).manual_seed(40_000 + b)
+            w = torch.log1p(torch.empty(nnz_b, device=dev).exponential_(1.0, generator=gw)).half().clamp_(min=0.01).cpu().numpy()
+        ix.upload((indptr[:m + 1], terms[:nnz_b], w))
         done += m
+        b += 1
     ix.finalize()
     qp, qt, qw = synth.random_sparse_corpus_fast(256, V, seed=5, mean_nnz=24, lo=4, hi=64)
     q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
@@ -320,8 +341,10 @@ def splade_legs(args, device_index):
             ok &= bool(np.float32(acc[-1] if len(acc) else 0.0) == s2[a, b])
     out["splade_search"] = {
         "queries_per_s": 256 / dt, "docs": args.splade_docs, "nnz": int(ix.nnz), "scan_ms_per_pass": c["scan_ms"] / c["n_passes"],
+        "corpus": f"{n_blocks} distinct 1M-document blocks: term sets from {len(term_sets)} independent draws of SURVEY §8d S4 "
+                  f"({gen_s:.1f} s to draw), fresh weights per block",
         "roofline": {"bound": "hbm", "kernel": "bh_csr_scan_mfma_kernel", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.traffic_json, "bh_csr_scan_mfma_kernel", args.splade_docs, V),
                      "algorithmic_bytes_per_launch": c["algorithmic_bytes"] / c["n_passes"]},
         "parity_check": "pass" if ok else "FAIL"}
     sub.close()
@@ -427,9 +450,95 @@ def config5_leg(args, local_rank, device):
             "ms_per_step": dt * 1e3, "query_tile": c["query_tile"], "passes_per_step": c["n_passes"], "k_padded": c["k_padded"],
             "roofline": {"bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]) if c["query_tile"] != 128 or c.get("shader_mhz", 0) == 0
                          else "bh_scan_topk256_kernel", "achieved": per_launch / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": per_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": per_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic(args.traffic_json, "bh_scan_topk256_kernel", n, dim),
                          "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg},
             "uncertified_queries": c.get("uncertified_queries", 0), "parity_check": "pass" if ok else "FAIL"}
+
+
+def certificate_leg(args, local_rank, device):
+    """The exactness certificate and its fall-back on a corpus that is NOT unit-norm Gaussian: rows with
+    RetroMAE-like norms (|x| ~ U(10, 14); one row in 10 000 at 3x that: the certificate's bound uses the corpus-wide maximum),
+    2 % of the rows near-duplicates of their predecessor (templated passages: relative noise 1e-3 or 1e-2), and for a tenth of
+    the queries a planted cluster of 100 near-duplicates of one well-scoring row (half of them at noise 1e-3, half at 1e-2) —
+    the situation in which more than KP - k rows lie within MFMA rounding error of the k-th score.  Reported: how many
+    queries the certificate could not prove, how many filter passes and re-scored rows the fall-back took, its wall time,
+    against the time of the same search.  Gate: canonical scores of the returned ids recomputed with numpy, and the complete
+    lists of 4 clustered + 4 ordinary queries against a float64 GEMM over the whole corpus."""
+    import bergen_amd
+    dim, k, nq, n = args.dim, args.k, args.queries, args.n_rows
+    g = torch.Generator(device=device).manual_seed(77)
+    queries = (torch.nn.functional.normalize(torch.randn(nq, dim, generator=g, device=device), dim=1) * 12.0).half()
+    clustered = torch.arange(0, nq, 10)  # every tenth query
+    gp = torch.Generator().manual_seed(78)
+    cluster_at = torch.randint(0, n - 200, (len(clustered),), generator=gp)  # first row of each planted cluster
+
+    def block_rows(b):
+        b0 = b * BLOCK
+        m = min(BLOCK, n - b0)
+        gb = torch.Generator(device=device).manual_seed(5000 + b)
+        base = torch.nn.functional.normalize(torch.randn(m, dim, generator=gb, device=device), dim=1)
+        norms = 10.0 + 4.0 * torch.rand(m, 1, generator=gb, device=device)
+        norms = torch.where(torch.rand(m, 1, generator=gb, device=device) < 1e-4, norms * 3.0, norms)
+        rows = base * norms
+        dup = torch.rand(m, generator=gb, device=device) < 0.02
+        dup[0] = False
+        eps = torch.where(torch.rand(m, 1, generator=gb, device=device) < 0.5, 1e-3, 1e-2)
+        src = torch.arange(m, device=device)
+        src[dup] -= 1
+        noise = torch.randn(m, dim, generator=gb, device=device) * (eps * norms / dim ** 0.5)
+        rows = torch.where(dup[:, None], rows[src] + noise, rows)
+        for j, (qi, r0) in enumerate(zip(clustered.tolist(), cluster_at.tolist())):
+            if b0 <= r0 < b0 + m - 100:
+                gc = torch.Generator(device=device).manual_seed(9000 + j)
+                centre = torch.nn.functional.normalize(queries[qi].float() / 12.0 + 0.3 * torch.randn(dim, generator=gc, device=device) / dim ** 0.5,
+                                                       dim=0) * 12.0  # cosine ~0.96 with its query: the cluster IS the query's top 100
+                e = torch.cat([torch.full((50, 1), 1e-3, device=device), torch.full((50, 1), 1e-2, device=device)])
+                rows[r0 - b0:r0 - b0 + 100] = centre[None, :] + torch.randn(100, dim, generator=gc, device=device) * (e * 12.0 / dim ** 0.5)
+        return rows.half()
+
+    ix = bergen_amd.FlatIndex(n, dim, metric="ip", device=local_rank)
+    for b in range((n + BLOCK - 1) // BLOCK):
+        ix.upload(block_rows(b), row0=b * BLOCK)
+    ix.finalize()
+    torch.cuda.synchronize()
+    ix.search(queries, k)
+    t0 = time.perf_counter()
+    s_dev, i_dev = ix.search(queries, k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = ix.counters()
+    s_np, i_np = s_dev.cpu().numpy(), i_dev.cpu().numpy()
+    ix.close()
+    # gate: (a) canonical scores of returned ids (sequential fp64), (b) complete lists of 8 queries vs a float64 GEMM
+    ok = bool((np.diff(s_np, axis=1) <= 0).all())
+    check = clustered[:4].tolist() + [1, 2, 3, 4]
+    q64 = queries[check].double()
+    keep_s, keep_i = [[] for _ in check], [[] for _ in check]
+    for b in range((n + BLOCK - 1) // BLOCK):
+        x64 = block_rows(b).double()
+        sc = (q64 @ x64.T).float()
+        kth = torch.topk(sc, k, dim=1).values[:, -1:]
+        hit = (sc >= kth).nonzero()
+        vals = sc[hit[:, 0], hit[:, 1]].cpu().tolist()
+        for (a, r), v in zip(hit.cpu().tolist(), vals):
+            keep_s[a].append(v)
+            keep_i[a].append(b * BLOCK + r)
+        del x64, sc
+    full_ok = True
+    for a, qi in enumerate(check):
+        cs, ci = np.asarray(keep_s[a], np.float32), np.asarray(keep_i[a], np.int64)
+        order = np.lexsort((ci, -cs.astype(np.float64)))[:k]
+        full_ok &= bool(np.array_equal(ci[order], i_np[qi]) and np.array_equal(cs[order].view(np.uint32), s_np[qi].view(np.uint32)))
+    ok &= full_ok
+    in_cluster = float(np.mean([np.isin(i_np[qi], np.arange(r0, r0 + 100)).sum() for qi, r0 in zip(clustered.tolist(), cluster_at.tolist())]))
+    return {"workload": f"{nq} queries (|q| = 12; every tenth with a planted cluster of 100 near-duplicate rows) x {n} x {dim} fp16, "
+                        f"|x| ~ U(10, 14) with 1e-4 of the rows at 3x, 2 % near-duplicate rows, top-{k}",
+            "uncertified_queries": int(c.get("uncertified_queries", 0)), "uncertified_fraction": c.get("uncertified_queries", 0) / nq,
+            "fallback_filter_passes": int(c.get("exact_passes", 0)), "fallback_rows_rescored": int(c.get("exact_rows_rescored", 0)),
+            "fallback_ms": c.get("exact_ms", 0.0), "scan_ms": c["scan_ms"], "normal_pass_ms": c["scan_ms"] / c["n_passes"],
+            "search_ms_wall": dt * 1e3, "queries_per_s": nq / dt, "top_k_rows_inside_planted_cluster_mean": in_cluster,
+            "full_lists_of_8_queries_bit_exact_vs_float64_gemm": full_ok, "parity_check": "pass" if ok else "FAIL"}
 
 
 def scan_kernel_name(query_tile):
@@ -437,16 +546,25 @@ def scan_kernel_name(query_tile):
     return {256: "bh_scan_topk256_kernel", 192: "bh_scan_topk192_kernel"}.get(query_tile, "bh_scan_topk_kernel")
 
 
-def pmc_traffic(path, kernel, n_rows, dim):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/hbm_traffic.json, keyed by kernel), or None
-    when that file holds no entry for this kernel at this index geometry."""
+KERNEL_SOURCES = {"bh_scan_topk256_kernel": "scan_topk256.hip", "bh_scan_topk192_kernel": "scan_topk192.hip",
+                  "bh_scan_topk_kernel": "scan_topk.hip", "bh_csr_scan_mfma_kernel": "csr_mfma.hip"}
+
+
+def pmc_traffic(path, kernel, n_rows, dim_padded):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/hbm_traffic.json, keyed "<kernel>@<dim>"), or
+    None when that file holds no entry for this kernel at this geometry — or when the kernel's source file has changed since
+    the counters were collected (the entry carries the file's sha256): a stale measurement is not reported."""
+    import hashlib
     try:
-        ent = json.load(open(path)).get("kernels", {}).get(kernel)
-        if ent and ent.get("n_rows") == n_rows and ent.get("dim") == dim:
-            return ent.get("hbm_bytes_per_launch")
+        ent = json.load(open(path)).get("kernels", {}).get(f"{kernel}@{dim_padded}")
+        if not ent or ent.get("n_rows") != n_rows:
+            return None
+        src = os.path.join(ROOT, "bergen_amd", "csrc", KERNEL_SOURCES[kernel])
+        if ent.get("source_sha16") != hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+            return None
+        return ent.get("hbm_bytes_per_launch")
     except Exception:
-        pass
-    return None
+        return None
 
 
 class HipEnv:
@@ -550,7 +668,7 @@ def run(args, env):
 
     for _ in range(args.warmup):
         res, res_host = step()
-    scan_ms = merge_ms = kernel_total_ms = 0.0
+    scan_ms = merge_ms = kernel_total_ms = tail_ms = 0.0
     uncertified = 0
     barrier()
     t0 = time.perf_counter()
@@ -558,6 +676,7 @@ def run(args, env):
         res, res_host = step()
         c = ix.counters()
         scan_ms += c["scan_ms"]
+        tail_ms += c.get("tail_scan_ms", 0.0)
         merge_ms += c["merge_ms"]
         kernel_total_ms += c["total_ms"]
         uncertified += c.get("uncertified_queries", 0)
@@ -605,9 +724,12 @@ def run(args, env):
         parity = "pass" if ok else "FAIL"
 
     if rank == 0:
-        n_launch = c["n_passes"] * args.steps
-        per_launch_bytes = c["algorithmic_bytes"] / c["n_passes"]
-        avg_scan_ms = scan_ms / n_launch
+        # The roofline object is the DOMINANT kernel's: when the last pass (<= 128 queries left) ran on the 128-query kernel
+        # (counters tail_query_tile / tail_scan_ms), that launch is taken out of the average and reported beside it.
+        has_tail = c.get("tail_query_tile", 0) != 0 and c["n_passes"] > 1
+        n_launch = (c["n_passes"] - (1 if has_tail else 0)) * args.steps
+        per_launch_bytes = (hi - lo) * dim * 2.0 + c["query_tile"] * dim * 2.0 + c["query_tile"] * k * 12.0
+        avg_scan_ms = (scan_ms - (tail_ms if has_tail else 0.0)) / n_launch
         achieved = per_launch_bytes / (avg_scan_ms * 1e-3) / 1e9
         traffic = pmc_traffic(args.traffic_json, scan_kernel_name(c["query_tile"]), hi - lo, dim)
         flops_per_launch = 2.0 * c["query_tile"] * (hi - lo) * dim  # MFMA work of one launch (query tile padded to its full width)
@@ -640,6 +762,8 @@ def run(args, env):
                 "mfma_tflops": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12,
                 "mfma_frac": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                 "shader_mhz": c.get("shader_mhz", 0.0),
+                "tail_pass": ({"kernel": "bh_scan_topk_kernel", "query_tile": 128, "avg_launch_ms": tail_ms / args.steps,
+                               "what": "the last pass of a step (<= 128 queries left) runs on the 128-query kernel"} if has_tail else None),
             },
             "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,
                                    "stream_total": kernel_total_ms / args.steps},
@@ -684,6 +808,12 @@ def run(args, env):
                 out["config5"] = config5_leg(args, local_rank, device)
             except Exception as exc:
                 out["config5"] = {"error": repr(exc)}
+        if world == 1 and not args.no_certificate_leg:
+            ix.close()
+            try:
+                out["certificate"] = certificate_leg(args, local_rank, device)
+            except Exception as exc:
+                out["certificate"] = {"error": repr(exc)}
         if world == 1 and not args.no_stage:
             ix.close()
             try:
@@ -696,11 +826,12 @@ def run(args, env):
                 out.update(encoder_leg(args, local_rank))
             except Exception as exc:
                 out["encoder_error"] = repr(exc)
-            if not args.no_splade:
-                try:
-                    out.update(splade_legs(args, local_rank))
-                except Exception as exc:
-                    out["splade_error"] = repr(exc)
+        if not args.no_splade and world == 1:
+            ix.close()
+            try:
+                out.update(splade_legs(args, local_rank))
+            except Exception as exc:
+                out["splade_error"] = repr(exc)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, dim, k)

@@ -42,6 +42,9 @@ class bh_counters(ctypes.Structure):
         ("shader_mhz", ctypes.c_double),
         ("uncertified_queries", ctypes.c_int64),
         ("exact_ms", ctypes.c_double),
+        ("tail_scan_ms", ctypes.c_double),
+        ("tail_query_tile", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
         ("exact_passes", ctypes.c_int64),
         ("exact_rows_rescored", ctypes.c_int64),
     ]

@@ -99,7 +99,7 @@ hipError_t run_cfg(int cfg, const BhGemmArgs& a, int epi, hipStream_t s) {
 // variant: 0 = auto; 1..5 = explicit tile configuration (gemm_f16_kernel.h); 6 = generic bounds-checked kernel
 // for everything; 7 = persistent 256x256 kernel (gemm_f16_persist.h; burst stores); 8 = 7 with stores deferred into
 // the next tile's main loop, 9 = 7 with non-temporal stores (both valid results; ablations); 11..28 = bench-only
-// ablations (results invalid); 10 = 7 with the last partial round of tiles re-cut into 128x128 tiles (experiment, measured neutral).
+// ablations (results invalid); 33 = 7 with deferred stores and alternating loader teams; 10 = 7 with the last partial round of tiles re-cut into 128x128 tiles (experiment, measured neutral).
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t stream) {
     BhGemmArgs a = a_in;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -140,12 +140,16 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     if (variant == 10) variant = 7;
     if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? ((epi & BH_EPI_RESIDUAL) ? 5 : 7) : (a.M >= 256 && a.N >= 128) ? 2 : 1;
     if (variant == 6 || !epi_fast || g_swap_b != 0) return bh_gemm_generic(a, epi, stream);
-    const bool persist = (variant >= 7 && variant <= 9) || variant == 31 || variant == 32;
+    const bool persist = (variant >= 7 && variant <= 9) || variant == 31 || variant == 32 || variant == 33;
     if (a.c_block_rows && !(persist && a.M % 256 == 0 && a.N % 256 == 0 && !(epi & BH_EPI_RESIDUAL)))
         return hipErrorInvalidValue;  // blocked output: whole 256x256 tiles only (fast epilogues)
     // burst stores; non-temporal for the GELU (FFN-up) output, which is far larger than the caches and is read
     // back only by the next kernel (measured: +8 % on that GEMM, -7 % on the others)
-    const int pst = variant == 31 ? 5 : variant == 32 ? 9 : variant == 8 ? 0 : variant == 9 ? 3 : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
+    // 33: deferred stores with alternating loader teams (gemm_f16_persist.h PST 16) where the stage count allows it
+    const int kt_ = a.K / 64;
+    const bool alt_ok = (kt_ & 1) == 0 && kt_ >= 8;
+    const int pst = variant == 31 ? 5 : variant == 32 ? 9 : variant == 8 ? 0 : variant == 9 ? 3 : (variant == 33 && alt_ok) ? 16
+                    : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
     if (persist) {
         if (epi & BH_EPI_RESIDUAL) return bh_gemm_generic(a, epi, stream);  // (the encoder adds residuals in LayerNorm)
         variant = 5;  // same tile geometry

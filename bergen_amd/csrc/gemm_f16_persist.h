@@ -20,6 +20,15 @@
 // every stage hand-over wait for store acknowledgements); 0 = stores deferred two per stage into the next tile's
 // main loop (kept as an ablation); 2 = non-temporal stores; 4 / 8 = bench-only (results invalid): epilogue math
 // without its stores / no epilogue at all.
+// PST bit 16 (with bit 1 clear) = ALTERNATING LOADER TEAMS: the eight waves form two teams of four (one wave per SIMD each);
+// in even stages team 0 issues the WHOLE stage refill (16 LDS-DMA instructions per wave) and team 1 issues four of its
+// deferred stores, in odd stages the roles swap.  Why: the stage hand-over needs "my LDS-DMA loads have landed" =
+// s_waitcnt vmcnt(0) on a ring of two, and vmcnt counts stores too — with every wave loading in every stage, a deferred
+// store had to be acknowledged within the stage it was issued in (variant 8: slower than a burst).  Here a wave waits only
+// before the barrier that follows a stage in which it LOADED; the stores it issued one stage earlier have had two whole
+// stages (~3 us) to be acknowledged, and a wave that only stored does not wait at all.  The stores of a tile (128 KiB per
+// workgroup, 5 us as a burst with every CU bursting at the same time) then drain under the next tile's MFMAs.
+// Needs an even number of stages >= 8 per tile (K = 768: 12, K = 3072: 48): the team roles are then the same in every tile.
 template <int EPI, int PST = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -34,6 +43,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     constexpr int NST = TM * TN * 2;           // 16 deferred 16-byte stores per lane per tile
     constexpr int SLOTS = 8;                   // main-loop stages that carry deferred stores (2 each)
     static_assert(NST == 2 * SLOTS, "store schedule");
+    constexpr bool ALT = (PST & 16) != 0 && (PST & 1) == 0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,10 +77,13 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     // 2 i + (wave >> 2) (i < 4: A pieces, i >= 4: B pieces), so its offset is a per-lane base plus a uniform stride.
     constexpr int NLA = PA * SUBS / NW;  // 4: instructions 0..3 fetch A rows, 4..7 fetch B rows
     static_assert(NLA * NW == PA * SUBS && NW == 8 && SUBS == 4, "piece schedule");
+    // ALT: a team's wave fetches sub-piece (wave & 3) of EVERY piece: 16 instructions, pieces 0..7 = A rows, 8..15 = B rows
+    // (p0 = 0, piece stride 32 rows instead of 64)
+    const int team = wave >> 2;
     unsigned offA, offB;  // byte offsets of the lane's source inside the tile's A rows / B rows for i = 0 / i = NLA
     int dst0;             // wave-uniform LDS destination of instruction 0; instruction i adds i * 2 * PIECE
     {
-        const int sub = wave & 3, p0 = wave >> 2;
+        const int sub = wave & 3, p0 = ALT ? 0 : wave >> 2;
         const int row = 8 * sub + (lane >> 3);
         const int g = ((row >> 1) & 1) | ((row >> 3) << 1);
         const int chunk = (lane & 7) ^ g;
@@ -78,7 +91,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
         offB = (unsigned)((p0 * 32 + row) * a.ldb * 2 + chunk * 16);
         dst0 = p0 * PIECE + sub * 1024;
     }
-    const unsigned strideA = (unsigned)(64 * a.lda * 2), strideB = (unsigned)(64 * a.ldb * 2);
+    const unsigned strideA = (unsigned)((ALT ? 32 : 64) * a.lda * 2), strideB = (unsigned)((ALT ? 32 : 64) * a.ldb * 2);
     unsigned rd_off[KS];
     {
         const int g = ((ql >> 1) & 1) | ((ql >> 3) << 1);
@@ -112,6 +125,15 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
             (const __attribute__((address_space(1))) void*)(ub + off),
             (__attribute__((address_space(3))) void*)(smem + islot * STAGE_BYTES + dst0 + i * 2 * PIECE), 16, 0, 0);
     };
+    auto issue_piece_alt = [&](int p) {  // ALT: piece p of the stage at the issue cursor, this wave's quarter of it
+        const unsigned char* ub = (p < PA ? curA : curB) + (size_t)ikt * (BK * 2);
+        unsigned off = p < PA ? offA : offB;
+        asm volatile("" : "+v"(off));
+        off += p < PA ? (unsigned)p * strideA : (unsigned)(p - PA) * strideB;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ub + off),
+            (__attribute__((address_space(3))) void*)(smem + islot * STAGE_BYTES + dst0 + p * PIECE), 16, 0, 0);
+    };
     auto issue_advance = [&]() {
         if (++islot == R) islot = 0;
         if (++ikt == KT) {
@@ -124,9 +146,15 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
             }
         }
     };
-    auto issue_stage = [&]() {
+    auto issue_stage = [&]() {  // pipeline start: every wave takes part
+        if constexpr (ALT) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) issue_piece(i);
+            for (int p = 0; p < PA + PB; ++p)
+                if ((p & 1) == team) issue_piece_alt(p);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) issue_piece(i);
+        }
         issue_advance();
     };
 
@@ -161,8 +189,10 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     };
 
     int cslot = 0;
+    bool everyone_loaded = true;  // ALT: the stage in flight was issued by all eight waves (pipeline start only)
     // one pipeline stage of the consumed tile; SLOT >= 0: this stage also issues deferred stores 2*SLOT, 2*SLOT+1
-    auto stage = [&](auto slot_c, bool first) {
+    // (ALT: stage parity par = stage ordinal & 1; team == par loads the refill, the other team stores 4 * (SLOT / 2) ...)
+    auto stage = [&](auto slot_c, bool first, int par) {
         constexpr int SLOT = decltype(slot_c)::value;
         const unsigned char* st = smem + cslot * STAGE_BYTES;
         if (++cslot == R) cslot = 0;
@@ -192,7 +222,15 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
         for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wb[1][tn]));
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xa[tm]));
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // next stage landed (ring 2)
+        if constexpr (ALT) {
+            // the refill in flight was issued by the team that loaded in the PREVIOUS stage (parity par ^ 1): only its waves
+            // have LDS-DMA loads outstanding; the others may still have stores in flight and do not wait for them
+            if (everyone_loaded || team != par) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            everyone_loaded = false;
+            asm volatile("s_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // next stage landed (ring 2)
+        }
         const unsigned char* nst = smem + cslot * STAGE_BYTES;
         read_wb(0, nst, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -201,12 +239,23 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[1][tn], xa[tm], acc[tm][tn], 0, 0, 0);
-                issue_piece(tm * TN + tn);  // NL == NMF: one LDS-DMA instruction per MFMA gap
+                if constexpr (ALT) {
+                    if (team == par) {  // this team's turn to refill the slot everybody just left: two per MFMA gap
+                        issue_piece_alt(2 * (tm * TN + tn));
+                        issue_piece_alt(2 * (tm * TN + tn) + 1);
+                    }
+                } else {
+                    issue_piece(tm * TN + tn);  // NL == NMF: one LDS-DMA instruction per MFMA gap
+                }
             }
             read_xa(tm, nst, 0);
             if constexpr (SLOT >= 0 && (PST & 1) == 0) {
-                if (tm == 1 && pend_valid) store_pending(2 * SLOT);
-                if (tm == 3 && pend_valid) store_pending(2 * SLOT + 1);
+                if constexpr (ALT) {  // the other team: four of the previous tile's stores per stage
+                    if (team != par && pend_valid) store_pending(4 * (SLOT >> 1) + tm);
+                } else {
+                    if (tm == 1 && pend_valid) store_pending(2 * SLOT);
+                    if (tm == 3 && pend_valid) store_pending(2 * SLOT + 1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -231,12 +280,12 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
             int kt = 0;
 #define BH_ST(S)                                                          \
     if (kt < KT) {                                                        \
-        stage(std::integral_constant<int, S>{}, S == 0);                  \
+        stage(std::integral_constant<int, S>{}, S == 0, S & 1);           \
         ++kt;                                                             \
     }
             BH_ST(0) BH_ST(1) BH_ST(2) BH_ST(3) BH_ST(4) BH_ST(5) BH_ST(6) BH_ST(7)
 #undef BH_ST
-            for (; kt < KT; ++kt) stage(std::integral_constant<int, -1>{}, false);
+            for (; kt < KT; ++kt) stage(std::integral_constant<int, -1>{}, false, kt & 1);
             // K so short that some deferred stores found no stage: flush them now
             if (pend_valid && (PST & 1) == 0) {
 #pragma unroll

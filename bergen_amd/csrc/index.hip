@@ -746,7 +746,15 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     c.n_rows = ix->n_rows;
     c.dim = ix->dim;
     c.dim_padded = dp;
-    c.query_tile = bq * qs_max;
+    c.query_tile = (tail128 && n_pass == 1) ? 128 : bq * qs_max;  // (a search of at most 128 queries ran on the 128-query kernel alone)
+    c.tail_scan_ms = 0;
+    c.tail_query_tile = 0;
+    if (tail128) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * (n_group - 1)), ix->event(2 + 4 * (n_group - 1) + 1)));
+        c.tail_scan_ms = ms;
+        c.tail_query_tile = 128;
+    }
     c.n_passes = n_pass;
     c.n_workgroups = grid;
     c.k_padded = kp;

@@ -64,6 +64,9 @@ typedef struct bh_counters {
                                     answered by the exact fall-back: an MFMA filter pass with a fixed threshold (one more
                                     corpus pass per 128 such queries) + canonical re-scoring of the rows it lets through */
     double exact_ms;          /* time spent in that fall-back (wall, included in total_ms) */
+    double tail_scan_ms;      /* part of scan_ms spent in a last pass that ran on the 128-query kernel (<= 128 queries left), else 0 */
+    int32_t tail_query_tile;  /* 128 when the last pass ran on the 128-query kernel, else 0 */
+    int32_t reserved0;
     int64_t exact_passes;     /* filter passes (corpus passes) the fall-back of the last search took */
     int64_t exact_rows_rescored; /* rows the filter passes let through, summed over the uncertified queries */
 } bh_counters;

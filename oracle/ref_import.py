@@ -64,6 +64,18 @@ def load():
 
         torch.Tensor.to = _to
         torch.Tensor._bergen_to_patched = True
+        # ... and for modules: `self.model.model.to('cuda')` (retrieve.py:124) on a real torch.nn.Module
+        _orig_mod_to = torch.nn.Module.to
+
+        def _mod_to(self, *args, **kwargs):
+            args = tuple(a for a in args if not (isinstance(a, str) and a.startswith("cuda")))
+            if isinstance(kwargs.get("device"), str) and kwargs["device"].startswith("cuda"):
+                kwargs.pop("device")
+            if not args and not kwargs:
+                return self
+            return _orig_mod_to(self, *args, **kwargs)
+
+        torch.nn.Module.to = _mod_to
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     import importlib

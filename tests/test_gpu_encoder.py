@@ -92,6 +92,32 @@ def test_gemm_persistent_many_tiles_per_block():
                 assert_gemm_close(out, ref, f"persistent v{variant} {M}x{N}x{K} {sorted(kw)}")
 
 
+def test_gemm_alternating_loader_teams():
+    """Variant 33 (gemm_f16_persist.h PST 16): deferred stores with the two four-wave teams of a workgroup alternating
+    between refilling the LDS ring and storing — a wave skips the vmcnt wait of a stage it did not load in.  Several tiles per
+    workgroup (4096 x 8192 = 512 tiles on 256 CUs: every store schedule runs across a tile boundary), stage counts 8 / 12 /
+    48 (even, >= 8: the alternating kernel), 6 and 9 (falls back to the burst kernel), every epilogue; repeated launches must
+    agree bit for bit (a missing wait shows up as a rare wrong tile, not as a steady error)."""
+    from bergen_amd import encoder
+    rng = np.random.default_rng(33)
+    for (M, N, K) in [(4096, 8192, 512), (2048 + 256, 6144, 768), (1024, 2048, 3072), (1024, 1024, 384), (512, 512, 576)]:
+        a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
+        bc, br = rnd16(rng, N), rnd16(rng, M)
+        for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)),
+                        (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
+                        (dict(bias=h16(br), bias_mode=2), bert_oracle.gemm_ref(a, w, br, 2)),
+                        (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
+            first = None
+            for rep in range(3):
+                out, _ = encoder.gemm_f16(h16(a), h16(w), variant=33, **kw)
+                assert_gemm_close(out, ref, f"alternating teams {M}x{N}x{K} {sorted(kw)} run {rep}")
+                if first is None:
+                    first = out.clone()
+                assert torch.equal(out, first), f"run-to-run difference {M}x{N}x{K} {sorted(kw)}"
+            base, _ = encoder.gemm_f16(h16(a), h16(w), variant=7, **kw)
+            assert torch.equal(base, first), "variant 33 must produce the bits of variant 7"
+
+
 def test_gemm_identity_and_odd_n():
     """A = I picks out rows of B^T (catches transposed / permuted output maps); N not a multiple of 4."""
     from bergen_amd import encoder
