@@ -58,6 +58,7 @@ def parse_args():
     p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
     p.add_argument("--no-certificate-leg", action="store_true", help="skip the certificate / fall-back leg on the clustered, non-unit-norm corpus")
+    p.add_argument("--encode-stage-passages", type=int, default=16384, help="passages of the Retrieve.encode_and_save leg (0 = skip)")
     p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg (index folders -> doc-id strings)")
     p.add_argument("--stage-rows", type=int, default=2_100_000, help="documents of the Retrieve.retrieve-level leg")
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
@@ -456,6 +457,135 @@ def config5_leg(args, local_rank, device):
             "uncertified_queries": c.get("uncertified_queries", 0), "parity_check": "pass" if ok else "FAIL"}
 
 
+def retrieve_stage_full_leg(args, stage, index, queries, want_scores, want_rows, n_total, k):
+    """`Retrieve.retrieve` — the call RAG.retrieve makes (modules/rag.py:322-329) — at the HEADLINE size, on the headline's own
+    resident index (filled on the device: a 32 GB folder is not written here; the folder-read path is the `retrieve_stage` leg
+    and profiles/load_path.py): the real query-folder read (embedding_chunk_0.pt, as the reference writes it), one search
+    for the whole query set, the real id mapping over a 21 M-row Arrow id column, the reference's return dict.  What the
+    headline `value` leaves out is exactly this call's host side."""
+    import shutil
+    import tempfile
+
+    import datasets
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    nq, dim = queries.shape
+    root = tempfile.mkdtemp(prefix="bergen_stage_full_")
+    try:
+        q_path, d_path = os.path.join(root, "queries"), os.path.join(root, "docs")
+        os.makedirs(q_path)
+        os.makedirs(d_path)  # (empty: the stage adopts the resident index for this path)
+        torch.save(queries.cpu(), os.path.join(q_path, "embedding_chunk_0.pt"))
+        ids = pc.cast(pa.array(np.arange(n_total, dtype=np.int64)), pa.string())  # KILT ids are the stringified row (dataset_processor.py:336)
+        dataset = {"doc": datasets.Dataset(datasets.table.InMemoryTable(pa.table({"id": ids}))),
+                   "query": datasets.Dataset.from_dict({"id": [f"q{j}" for j in range(nq)]})}
+        stage.adopt_resident_index(d_path, index, n_total, "ip", rows=None)
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = stage.retrieve(dataset, q_path, d_path, k)
+            times.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        stage._map_doc_ids(dataset["doc"], torch.from_numpy(want_rows))
+        map_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        from bergen_amd import utils
+        utils.load_embeddings(q_path)
+        load_q_s = time.perf_counter() - t0
+        ok = (torch.equal(out["score"], torch.from_numpy(want_scores)) and
+              all(out["doc_id"][q][j] == str(int(want_rows[q, j])) for q in (0, nq // 2, nq - 1) for j in (0, k - 1)) and
+              len(out["doc_id"]) == nq and isinstance(out["doc_id"][0][0], str))
+        best = min(times)
+        return {"workload": f"Retrieve.retrieve: {nq} queries (folder read) x {n_total} x {dim} resident fp16 documents, top-{k}, "
+                            f"doc-id strings from a {n_total}-row Arrow column",
+                "seconds": best, "queries_per_s": nq / best, "all_calls_seconds": times,
+                "host_tail": {"query_folder_read_s": load_q_s, "id_mapping_s": map_s},
+                "same_scores_and_ids_as_the_headline_search": bool(ok)}
+    finally:
+        stage._resident.pop(os.path.join(root, "docs"), None)  # (the index stays with the caller)
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def encode_stage_leg(args, device_index):
+    """`Retrieve.encode_and_save` (reference modules/retrieve.py:110-144) as a stage: text passages -> tokeniser in DataLoader
+    worker processes (collate_fn, padding='longest') -> HIP forward pass -> D2H of every batch -> chunk files in the reference's
+    layout.  Synthetic KILT-like passages (100 words + a 4-word title, one WordPiece token per word from a 30 522-entry toy
+    vocabulary; no real text or tokenizer file exists offline), BERT-base random-init weights, batch 512 (retromae.yaml).
+    Tokenisation runs ahead of the GPU on 4 / 16 threads of this process (bergen_amd's default loader), on 4 DataLoader worker
+    processes (the reference's, retrieve.py:114-118) or in line; passages/s is end to end (the best is reported on top), the
+    tokeniser-only rate of the same batches (one call at a time) beside it."""
+    import shutil
+    import tempfile
+
+    import datasets
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+
+    import bergen_amd
+    from bergen_amd import BertEncoder, synth
+    n_pass = args.encode_stage_passages
+    cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    rng = np.random.default_rng(12)
+    syl = ["ka", "mi", "to", "ra", "ne", "lo", "si", "du", "pe", "ga", "vo", "ti", "ma", "re", "ku", "ban", "ter", "lin", "sor", "pad",
+           "an", "el", "ion", "st", "qu"]
+    pool = set()
+    while len(pool) < cfg["vocab_size"] - 5:  # letter-only pseudo-words of 1-4 syllables (word-like lengths for the tokeniser)
+        pool.add("".join(syl[j] for j in rng.integers(0, len(syl), size=int(rng.integers(1, 5)))))
+    words = sorted(pool)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
+    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer(lowercase=True)
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
+                                                     special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
+                                  mask_token="[MASK]", model_input_names=["input_ids", "token_type_ids", "attention_mask"])
+    lens = np.clip(np.rint(rng.normal(104, 24, size=n_pass)), 12, 250).astype(np.int64)
+    picks = rng.integers(0, len(words), size=int(lens.sum()))
+    texts, o = [], 0
+    for n in lens.tolist():
+        texts.append(" ".join(words[j] for j in picks[o:o + n].tolist()))
+        o += n
+    sd = synth.random_bert(cfg, seed=31)
+    enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=device_index)
+    dense = bergen_amd.Dense(model_name="bench/bert-base-random", max_len=256, pooler=bergen_amd.ClsPooler(),
+                             similarity=bergen_amd.DotProduct(), model=enc, tokenizer=tok)
+    root = tempfile.mkdtemp(prefix="bergen_encode_stage_")
+    res = {"workload": f"Retrieve.encode_and_save: {n_pass} synthetic passages (~{int(lens.mean())} words), WordPiece tokeniser, "
+                       f"BERT-base random-init on the HIP path, batch 512, chunk files written"}
+    try:
+        ds = datasets.Dataset.from_dict({"content": texts})
+        # tokeniser alone, one process
+        t0 = time.perf_counter()
+        for b0 in range(0, n_pass, 512):
+            dense.collate_fn([{"content": x} for x in texts[b0:b0 + 512]], "doc")
+        res["tokenizer_only_passages_per_s_one_process"] = n_pass / (time.perf_counter() - t0)
+        for loader, workers in (("threads", 4), ("threads", 16), ("processes", 4), ("inline", 0)):
+            stage = bergen_amd.Retrieve(init_args=dense, batch_size=512, num_workers=workers, device=device_index,
+                                        loader="threads" if loader == "inline" else loader)
+            path = os.path.join(root, f"idx_{loader}{workers}")
+            try:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                stage.encode_and_save(ds, save_path=path, query_or_doc="doc")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                rows = sum(int(torch.load(os.path.join(path, f)).shape[0]) for f in os.listdir(path))
+                res[f"workers_{loader}_{workers}"] = {"passages_per_s": n_pass / dt, "seconds": dt, "rows_written": rows,
+                                                      "chunk_files": len(os.listdir(path))}
+            except Exception as exc:
+                res[f"workers_{loader}_{workers}"] = {"error": repr(exc)}
+            shutil.rmtree(path, ignore_errors=True)
+        good = [v["passages_per_s"] for kk, v in res.items() if kk.startswith("workers_") and "passages_per_s" in v]
+        res["passages_per_s"] = max(good) if good else None
+        return res
+    finally:
+        enc.close()
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def certificate_leg(args, local_rank, device):
     """The exactness certificate and its fall-back on a corpus that is NOT unit-norm Gaussian: rows with
     RetroMAE-like norms (|x| ~ U(10, 14); one row in 10 000 at 3x that: the certificate's bound uses the corpus-wide maximum),
@@ -774,6 +904,13 @@ def run(args, env):
             "parity_check": parity,
             "full_list_gate": full_list_gate,
         }
+        if world == 1 and not args.no_stage:
+            try:
+                out["retrieve_stage_full"] = retrieve_stage_full_leg(args, stage, ix, queries, res_host[0].numpy().copy(),
+                                                                     res_host[1].numpy().copy(), n_total, k)
+                stage.adopt_resident_index(corpus_key, ix, n_total, "ip", rows=None)
+            except Exception as exc:
+                out["retrieve_stage_full"] = {"error": repr(exc)}
         if world == 1 and args.query_split is None and not args.no_other_kernels:
             # secondary figures: the same search on the earlier scan kernels (library option scan_kernel), with result equality
             out["other_kernels"] = []
@@ -826,6 +963,11 @@ def run(args, env):
                 out.update(encoder_leg(args, local_rank))
             except Exception as exc:
                 out["encoder_error"] = repr(exc)
+        if not args.no_encoder and world == 1 and args.encode_stage_passages > 0:
+            try:
+                out["encode_stage"] = encode_stage_leg(args, local_rank)
+            except Exception as exc:
+                out["encode_stage"] = {"error": repr(exc)}
         if not args.no_splade and world == 1:
             ix.close()
             try:

@@ -67,7 +67,8 @@ class Retrieve:
                  resident_on_encode=False,
                  search_rank=None,
                  search_world=None,
-                 search_results="all"):
+                 search_results="all",
+                 loader="threads"):
         # encode_rank / encode_world: multi-GPU encoding.  The reference's only multi-GPU mechanism is
         # torch.nn.DataParallel around the encoder (dense.py:32-35: scatter inputs, re-broadcast every weight and
         # gather [B, T, d] outputs to GPU 0 on every forward).  Here each of `encode_world` processes (one per GPU)
@@ -98,6 +99,14 @@ class Retrieve:
             raise ValueError(f"search_results={search_results!r}: expected 'all' or 'rank0'")
         self.search_results = search_results
         self.search_group = None  # a torch.distributed process group, if the search ranks are not the default group
+        # loader: how encode_and_save tokenises ahead of the GPU.  "processes" = the reference's DataLoader worker processes
+        # (retrieve.py:114-118).  "threads" (default) = `num_workers` THREADS of this process run collate_fn on the coming
+        # batches, in order: the Rust tokenizers release the GIL and keep their own parallelism, which a forked DataLoader
+        # worker loses ("the current process just got forked ... disabling parallelism"), nothing is pickled, no worker
+        # start-up per index() call.  Measured with bench.py's encode_stage leg.
+        if loader not in ("threads", "processes"):
+            raise ValueError(f"loader={loader!r}: expected 'threads' or 'processes'")
+        self.loader = loader
         self.resident_on_encode = bool(resident_on_encode)
         self.encode_rank = int(encode_rank)
         self.encode_world = int(encode_world)
@@ -165,8 +174,11 @@ class Retrieve:
         if self.encode_world > 1:
             from torch.utils.data import Subset
             source = Subset(dataset, range(b_lo * self.batch_size, min(len(dataset), b_hi * self.batch_size)))
-        loader = DataLoader(source, batch_size=self.batch_size, num_workers=self.num_workers,
-                            collate_fn=lambda rows: self.model.collate_fn(rows, query_or_doc))
+        if self.loader == "threads" and self.num_workers > 0:
+            loader = self._threaded_batches(source, query_or_doc)
+        else:
+            loader = DataLoader(source, batch_size=self.batch_size, num_workers=self.num_workers,
+                                collate_fn=lambda rows: self.model.collate_fn(rows, query_or_doc))
         self.model.model = self.model.model.to('cuda' if torch.cuda.is_available() else 'cpu')
         pieces = []
         progress = tqdm(enumerate(loader, start=b_lo), total=b_hi - b_lo, desc=f'Encoding: {self.model.model_name}',
@@ -203,6 +215,34 @@ class Retrieve:
             if resident is not None:
                 resident.close()
         self.model.model = self.model.model.to('cpu')
+
+    def _threaded_batches(self, source, query_or_doc):
+        """collate_fn over consecutive batches of `source`, in order, `num_workers` batches being tokenised at any time on
+        threads of this process while the caller runs the forward pass of an earlier one."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        n, bs = len(source), self.batch_size
+
+        def make(b0):
+            rows = [source[j] for j in range(b0, min(n, b0 + bs))] if not hasattr(source, "select") else None
+            if rows is None:
+                cols = source[b0:min(n, b0 + bs)]  # HF Dataset slice: dict of column lists
+                names = list(cols)
+                rows = [dict(zip(names, vals)) for vals in zip(*(cols[c] for c in names))]
+            return self.model.collate_fn(rows, query_or_doc)
+
+        with ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="bergen-tokenize") as pool:
+            pending, starts = deque(), iter(range(0, n, bs))
+            for b0 in starts:
+                pending.append(pool.submit(make, b0))
+                if len(pending) >= 2 * self.num_workers:
+                    break
+            while pending:
+                batch = pending.popleft().result()
+                nxt = next(starts, None)
+                if nxt is not None:
+                    pending.append(pool.submit(make, nxt))
+                yield batch
 
     def _batch_range(self, n_batches, rank=None):
         """Contiguous range of batches [b_lo, b_hi) that process `rank` of `encode_world` encodes."""
@@ -433,23 +473,29 @@ class Retrieve:
 
     @staticmethod
     def _ids_at(doc_dataset, rows):
-        """The 'id' strings of the given rows (any order, repeats allowed).  An HF `datasets.Dataset` is read through its Arrow table
-        (`take` on the id column, through the indices mapping if the dataset carries one): 0.07 s for the 137 k distinct
-        hits of 2 837 x 50 on a 2.1 M-document collection, where `Dataset.select(rows)['id']` took 2-4 s — 200 x the
-        search it follows."""
+        """The 'id' strings of the given rows (any order, repeats allowed) as a numpy object array.  An HF `datasets.Dataset` is
+        read through its Arrow table: one `take` on the id column (through the indices mapping if the dataset carries one)
+        and ONE conversion of the taken strings — `to_numpy(zero_copy_only=False)`, which builds the Python strings in C;
+        `to_pylist()` builds a pyarrow Scalar per element first and took 4x as long as everything else together.  For the
+        141 850 hits of 2 837 x 50 over 21 M documents: take 12 ms + strings 8 ms (+ 4 ms to nest them per query), where
+        `Dataset.select(rows)['id']` took seconds; what remains is CPython creating 141 850 str objects."""
+        import numpy as np
         if len(rows) == 0:
-            return []
+            return np.empty(0, dtype=object)
         table = getattr(doc_dataset, "data", None)
         if table is not None and hasattr(table, "column") and hasattr(doc_dataset, "_indices"):
             import pyarrow as pa
             take = pa.array(rows, type=pa.int64())
             if doc_dataset._indices is not None:
                 take = doc_dataset._indices.column(0).take(take)
-            return table.column("id").take(take).to_pylist()
+            got = table.column("id").take(take)
+            if isinstance(got, pa.ChunkedArray):
+                got = got.combine_chunks()
+            return got.to_numpy(zero_copy_only=False)
         if hasattr(doc_dataset, "select"):
-            return list(doc_dataset.select([int(r) for r in rows])['id'])
+            return np.array(list(doc_dataset.select([int(r) for r in rows])['id']), dtype=object)
         col = doc_dataset['id']
-        return [col[int(r)] for r in rows]
+        return np.array([col[int(r)] for r in rows], dtype=object)
 
     @staticmethod
     def _map_doc_ids(doc_dataset, indices):
@@ -461,7 +507,7 @@ class Retrieve:
         flat = idx.reshape(-1)
         short = bool((flat < 0).any())
         ids = Retrieve._ids_at(doc_dataset, np.where(flat < 0, 0, flat) if short else flat)  # one take for all hits
-        rows = [ids[q * k:(q + 1) * k] for q in range(nq)]
+        rows = ids.reshape(nq, k).tolist()
         if short:
             rows = [[v for v, r in zip(row, rr.tolist()) if r >= 0] for row, rr in zip(rows, idx)]
         return rows

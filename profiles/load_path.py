@@ -1,7 +1,8 @@
 """The index load path (SURVEY H-4): a reference-layout folder of embedding_chunk_*.pt files -> resident HBM index, timed end
 to end through the same code Retrieve.retrieve runs (utils.load_chunk on a prefetch thread -> FlatIndex.upload through two
 pinned staging buffers -> finalize), with its parts timed on their own.  Page cache warm (the files were just written).
-Run on the GPU box:  python profiles/load_path.py > profiles/r02_load_path.json"""
+Run on the GPU box:  python profiles/load_path.py > profiles/r02_load_path.json
+                     python profiles/load_path.py --full > profiles/r03_load_path_full.json   (32 GB folder, cold + warm)"""
 import json
 import os
 import shutil
@@ -53,7 +54,64 @@ def timed_load(files, n_rows, dim, prefetch, mmap):
     return {"seconds": total, "index_alloc_s": t_alloc, "waiting_for_chunk_s": t_load, "upload_calls_s": t_up}
 
 
+def evict_page_cache(files):
+    """Drop the files' pages from the page cache: the global knob where the container allows it, else per file
+    (fsync + POSIX_FADV_DONTNEED works for the owner of the files).  Returns what was done."""
+    os.sync()
+    try:
+        with open("/proc/sys/vm/drop_caches", "w") as f:
+            f.write("3\n")
+        return "drop_caches"
+    except OSError:
+        pass
+    for path in files:
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        finally:
+            os.close(fd)
+    return "posix_fadvise(DONTNEED) per file"
+
+
+def full_size_cold(tmp, n_rows=21_000_000, dim=768):
+    """The headline corpus as a reference-layout folder (141 chunk files, 32 GB), read with a COLD page cache through the
+    stage's own load path (Retrieve._resident_index: mapped files on a prefetch thread -> pinned staging -> HBM), then again
+    warm.  The first-touch figure is what a user sees after a reboot or on a box with less RAM than the folder."""
+    files = build_folder(tmp, n_rows, dim, torch.float16)
+    file_bytes = sum(os.path.getsize(f) for f in files)
+    how = evict_page_cache(files)
+
+    class _Plug:
+        model_name = "bench/precomputed"
+        similarity = bergen_amd.DotProduct()
+        model = torch.nn.Identity()
+
+    out = {"rows": n_rows, "dim": dim, "files": len(files), "file_bytes": file_bytes, "page_cache_eviction": how,
+           "folder_on": os.popen(f"df -T {tmp} | tail -1").read().split()[:2]}
+    for name in ("cold", "warm"):
+        stage = bergen_amd.Retrieve(init_args=_Plug(), batch_size=512, num_workers=0, device=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stage._resident_index(tmp, n_rows, "ip")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"seconds": dt, "file_GB_per_s": file_bytes / dt / 1e9}
+        stage.close()
+        print(name, out[name], file=sys.stderr, flush=True)
+    return out
+
+
 def main():
+    if "--full" in sys.argv:
+        _lib.init(0)
+        tmp = sys.argv[sys.argv.index("--dir") + 1] if "--dir" in sys.argv else "/tmp/bergen_load_path_full"
+        try:
+            print(json.dumps({"what": "reference-layout folder of the headline corpus -> resident HBM index, cold and warm page cache",
+                              "full_size": full_size_cold(tmp)}, indent=1))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return
     _lib.init(0)
     out = {"what": "reference-layout chunk folder -> resident HBM index (page cache warm)", "cases": []}
     tmp = "/tmp/bergen_load_path"

@@ -134,6 +134,34 @@ def test_encode_and_save_writes_the_reference_layout(tmp_path, golden_dir):
     assert r.get_chunk_path("p", 5) == "p/embedding_chunk_5.pt"
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_threaded_tokenisation_writes_the_same_index(tmp_path, world):
+    """loader="threads" (default): num_workers threads run collate_fn ahead of the encoder, in order — same chunk files as
+    the in-line loop and as the reference's DataLoader worker processes, also over a rank's Subset of the dataset."""
+    import datasets
+    import time
+    ds = datasets.Dataset.from_dict({"content": [str(i) for i in range(203)]})
+
+    class _Slow(_FakeDense):
+        def collate_fn(self, batch, query_or_doc=None):
+            time.sleep(0.002 * (int(batch[0]["content"]) % 3))  # batches finish out of order on the threads
+            return super().collate_fn(batch, query_or_doc)
+
+    outs = {}
+    for name, kw in (("inline", dict(num_workers=0)), ("threads", dict(num_workers=3)), ("threads1", dict(num_workers=1)),
+                     ("processes", dict(num_workers=2, loader="processes"))):
+        path = str(tmp_path / name)
+        for rank in range(world):
+            r = Retrieve(init_args=_Slow(), batch_size=8, encode_rank=rank, encode_world=world, **kw)
+            r.encode_and_save(ds, save_path=path, query_or_doc="doc", chunk_size=40)
+        outs[name] = (sorted(os.listdir(path)), utils.load_embeddings(path))
+    for name in ("threads", "threads1", "processes"):
+        assert outs[name][0] == outs["inline"][0] and torch.equal(outs[name][1], outs["inline"][1]), name
+    assert outs["inline"][1].shape[0] == 203
+    with pytest.raises(ValueError):
+        Retrieve(init_args=_FakeDense(), loader="fibres")
+
+
 def test_retrieve_defaults_match_reference_signature():
     import inspect
     sig = inspect.signature(Retrieve.__init__)
