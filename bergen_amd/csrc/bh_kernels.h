@@ -248,8 +248,10 @@ struct BhCsrMergeArgs {
 };
 hipError_t bh_launch_csr_merge_rescore(const BhCsrMergeArgs& a, int kp, int nq_tile, hipStream_t stream);
 
-#define BH_CSR_MFMA_QUEUE 512       /* pending-hit ring entries per wave (8 bytes each) */
-#define BH_CSR_MFMA_WAVE_LDS 16384  /* per wave: D tile 4 KiB + S tile 8 KiB + hit queue 4 KiB */
+#define BH_CSR_MFMA_QUEUE 256       /* pending-hit ring entries per wave (8 bytes each) */
+#define BH_CSR_MFMA_WAVE_LDS 14336  /* per wave: D tile 4 KiB + S tile 8 KiB + hit queue 2 KiB */
+#define BH_CSR_HEAD_TERMS 64        /* corpus-head terms stored as a dense tile per 32-document group */
+#define BH_CSR_HEAD_DWORDS 1024     /* = 32 documents x 64 terms x 2 bytes */
 struct BhCsrMfmaArgs {
     const unsigned* entries;
     const long long* row_ptr;
@@ -259,6 +261,9 @@ struct BhCsrMfmaArgs {
     const unsigned* sinfo;         // [n_slots] head: 0x80000000 | head index; tail: pair offset << 8 | pair count
     const unsigned* pairs;         // [n_pairs] tail pairs: fp16 weight << 16 | query
     const _Float16* WhT;           // [64 queries][64 head terms] weights of the head terms
+    const _Float16* WgT;           // [64 queries][64 corpus-head terms] (head_dwords != 0)
+    int head_dwords;               // 0: plain CSR stream; BH_CSR_HEAD_DWORDS: every 32-document group's entries are preceded by its
+                                   // dense corpus-head tile and `entries` / `row_ptr` are the TAIL stream (csr_mfma.hip header)
     int n_words, n_slots, n_pairs;
     int off_prefix, off_sinfo, off_pairs, off_thr, off_tiles;  // byte offsets of the LDS images
     bh_u64* cand;                  // [grid * 8][64][2 * KP]
@@ -271,8 +276,14 @@ struct BhCsrMfmaArgs {
     int ablate;                    // bench-only: 1 = no scatter, 2 = no candidate handling (results invalid)
 };
 hipError_t bh_launch_csr_scan_mfma(const BhCsrMfmaArgs& a, int kp, int grid, size_t smem, hipStream_t stream);
+// csr_head.hip: split a CSR corpus into the corpus-head tiles + tail stream the MFMA scan reads
+hipError_t bh_launch_csr_tail_count(const unsigned* entries, const long long* row_ptr, long long n_rows, const unsigned char* head_slot,
+                                    unsigned* tail_cnt, hipStream_t stream);
+hipError_t bh_launch_csr_split(const unsigned* entries, const long long* row_ptr, const long long* row_ptr2, long long n_rows,
+                               const unsigned char* head_slot, unsigned* stream_out, hipStream_t stream);
 void bh_sparse_set_kernel(int which);  // 1 = csr_mfma.hip (default), 0 = csr_topk.hip
 void bh_sparse_set_ablate(int bits);   // bench-only
+void bh_sparse_set_head(int on);       // 1 = MFMA scan on the corpus-head tiles + tail stream (default), 0 = plain CSR
 
 struct BhSpladeFinishArgs {
     const unsigned* seg;  // [batch][ld_seg] max over the sequence's tokens of relu(logit), as uint32 bit patterns

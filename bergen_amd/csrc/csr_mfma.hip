@@ -23,6 +23,17 @@
 // Exactness as before: candidates by fp32 score (tail sums in atomic order: fp32-noise-level differences only matter
 // at the KP >= k + 8 margin), canonical fp64 re-score in bh_csr_merge_rescore_kernel (csr_topk.hip).
 // Roofline: HBM — algorithmic bytes per launch = nnz*4 + (N+1)*8.
+//
+// Round 3 — the CORPUS-side head block (a.head_dwords = 1024).  The 64 terms with the largest document frequency of the
+// whole index (sparse.hip picks them at finalize; with Zipf-like term statistics they make up a third of all entries and
+// most of the hits, because they are in most queries too) are taken OUT of the entry stream: every 32-document group starts
+// with a dense fp16 tile G[32 docs][64 corpus-head terms] (4 KiB, stored in exactly the order the wave's register buffer
+// receives it: dword 256 s + 4 lane + j = half-pair j of the MFMA A fragment of k-step s for lane (doc, half)), followed by
+// the group's remaining ("tail") entries.  The tile arrives through the same buffer-load stream as the entries — no extra
+// load instructions, no extra waits — is parked in 16 registers and multiplied with WgT[query][corpus-head term] on the
+// matrix cores (8 more MFMAs per group).  These terms never touch the term-set lookup, the hit queue or the scatter; the
+// tile-side head (D) now covers the tile's most-used terms among the rest.  Bytes per document: 128 (tile) + 4 per tail
+// entry instead of 4 per entry — less traffic AND a third fewer entries to test.
 #include "bh_device.h"
 #include "bh_kernels.h"
 
@@ -59,6 +70,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     unsigned char* Dt = smem + a.off_tiles + wave * BH_CSR_MFMA_WAVE_LDS;
     float* St = reinterpret_cast<float*>(Dt + 4096);
     uint2* Qt = reinterpret_cast<uint2*>(Dt + 12288);  // ring of BH_CSR_MFMA_QUEUE pending hits: (position in the group, entry)
+    const unsigned HD = (unsigned)a.head_dwords;       // 0, or 1024: dwords of the corpus-head tile in front of every group's entries
     for (int i = tid; i < a.n_words; i += 512) {
         bitmap[i] = a.bitmap[i];
         prefix[i] = a.prefix[i];
@@ -72,9 +84,11 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     // per-group fragment reads (lane = query) are conflict-free; keeping the 8 fragments in registers for the whole
     // launch cost 32 VGPRs the kernel does not have
     unsigned char* whl = smem + a.off_thr + 512;
+    unsigned char* wgl = whl + 64 * 144;  // WgT[query][corpus-head term], same image
     {
         const int row = tid >> 3, ch = tid & 7;  // 64 rows x 8 chunks of 16 bytes
         *reinterpret_cast<uint4*>(whl + row * 144 + ch * 16) = *reinterpret_cast<const uint4*>(a.WhT + (size_t)row * 64 + ch * 8);
+        if (HD) *reinterpret_cast<uint4*>(wgl + row * 144 + ch * 16) = *reinterpret_cast<const uint4*>(a.WgT + (size_t)row * 64 + ch * 8);
     }
     __syncthreads();
     // A-fragment read offsets in the D tile (same XOR-permuted 128-byte-row image as the GEMM: conflict-free)
@@ -133,10 +147,11 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     auto load_group = [&](long long grp, long long& base, unsigned& rel) {
         if (grp < grp_hi) {
             const long long g0 = grp * 32;
-            base = a.row_ptr[g0];
+            const long long b0 = a.row_ptr[g0];
             long long r = g0 + (lane < 33 ? lane : 32);
             r = r <= a.n_rows ? r : a.n_rows;
-            rel = (unsigned)(a.row_ptr[r] - base);
+            rel = (unsigned)(a.row_ptr[r] - b0);   // (positions among the group's tail entries)
+            base = b0 + (long long)HD * grp;      // its stream starts with its corpus-head tile
         } else {
             base = 0;
             rel = 0u;
@@ -176,6 +191,9 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     unsigned n_entries = 0, n_appends = 0, n_app_early = 0, n_app_mid = 0;
     // pending hits of the current group (wave-uniform ring indices)
     unsigned q_head = 0, q_tail = 0;
+    unsigned gfrag[16];  // the current group's corpus-head tile: A fragments of 4 k-steps (HD != 0)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gfrag[i] = 0u;
     // resolve n <= 64 queued hits, lane = hit: a head term is ONE fp16 store into the dense tile D, a tail term walks its
     // short (query, weight) pair list (all lanes busy: the walk costs the longest list among 64 hits, once)
     auto drain = [&](unsigned n, unsigned rel) {
@@ -228,7 +246,10 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
 #pragma unroll
         for (int step = 0; step < SC / ST; ++step) {
             const unsigned cbase = (sc * SC + step * ST) * 64;
-            if (cbase < total) {        // wave-uniform
+            if (HD && sc == 0u && step < 2) {  // (wave-uniform) the group's corpus-head tile: 16 registers, parked for the MFMA phase
+#pragma unroll
+                for (int c = 0; c < ST; ++c) gfrag[step * ST + c] = buf[step * ST + c];
+            } else if (cbase < total) {        // wave-uniform
                 if (a.ablate & 1) {     // bench-only: stream the entries, no scatter
                     #pragma unroll
                     for (int c = 0; c < ST; ++c) asm volatile("" ::"v"(buf[step * ST + c]));
@@ -242,7 +263,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                     for (int c = 0; c < ST; ++c) word4[c] = bitmap[(buf[step * ST + c] & 0xffffu) >> 5];
 #pragma unroll
                     for (int c = 0; c < ST; ++c) {
-                        const unsigned p = cbase + (c >> 2) * 256 + 4 * lane + (c & 3);
+                        const unsigned p = cbase - HD + (c >> 2) * 256 + 4 * lane + (c & 3);  // position among the tail entries
                         const unsigned ent = buf[step * ST + c];
                         const unsigned term = ent & 0xffffu;
                         // (no position test: an entry past the group's end reads as 0 = stored id 0, whose bit is never set)
@@ -258,6 +279,8 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                                 Qt[pos & (BH_CSR_MFMA_QUEUE - 1)] = make_uint2(p, ent);
                             }
                             q_tail += (unsigned)__builtin_popcountll(hm);
+                            // (the ring holds BH_CSR_MFMA_QUEUE hits: never let a dense step overrun it)
+                            while (q_tail - q_head > (unsigned)(BH_CSR_MFMA_QUEUE - 64)) drain(64u, rel);
                         }
                     }
                     while (q_tail - q_head >= 64u) drain(64u, rel);
@@ -291,7 +314,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     unsigned rel, nrel;
     load_group(grp_lo, base, rel);
     unsigned buf[SC];
-    issue_sc(buf, a.entries + base, __builtin_amdgcn_readlane(rel, 32), 0u);
+    issue_sc(buf, a.entries + base, grp_lo < grp_hi ? __builtin_amdgcn_readlane(rel, 32) + HD : 0u, 0u);
     for (long long grp = grp_lo; grp < grp_hi; ++grp, ++n_groups_seen) {
         // ---- threshold exchange (filter hint only).  A wave sees only a few thousand documents, far too few for its own
         // KP-th best to become selective, so bounds are shared chip-wide through the dense scan's slot table
@@ -349,7 +372,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             }
         }
         const long long g0 = grp * 32;
-        const unsigned total = __builtin_amdgcn_readlane(rel, 32);
+        const unsigned total = __builtin_amdgcn_readlane(rel, 32) + HD;  // dwords of the group's stream (head tile + tail entries)
         const unsigned nsc = total == 0 ? 1u : (total + SC * 64 - 1) / (SC * 64);
         load_group(grp + 1, nbase, nrel);  // (used by the last refill of this group)
         // ---- clear the tiles
@@ -363,7 +386,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         for (unsigned sc = 0; sc < nsc; ++sc) {
             const bool last = sc + 1 == nsc;
             process_and_refill(buf, rel, total, sc, last ? a.entries + nbase : ent_base,
-                               last ? __builtin_amdgcn_readlane(nrel, 32) : total, last ? 0u : sc + 1);
+                               last ? (grp + 1 < grp_hi ? __builtin_amdgcn_readlane(nrel, 32) + HD : 0u) : total, last ? 0u : sc + 1);
         }
         if (q_tail != q_head) drain(q_tail - q_head, rel);  // (< 64 left)
         const long long tm0 = timed ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -385,6 +408,20 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int w2 = 0; w2 < 2; ++w2) acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(df[s], wf[w2][s], acc[w2], 0, 0, 0);
+        if (HD) {  // + G . WgT^T: the corpus-head tile straight from the entry stream's registers
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) wf[w2][s] = *reinterpret_cast<const half8*>(wgl + (w2 * 32 + ql) * 144 + (2 * s + h) * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+                const u32x4g raw = {gfrag[4 * s + 0], gfrag[4 * s + 1], gfrag[4 * s + 2], gfrag[4 * s + 3]};
+                const half8 gf = __builtin_bit_cast(half8, raw);
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) acc[w2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf, wf[w2][s], acc[w2], 0, 0, 0);
+            }
+        }
 
         // ---- threshold filter (as the dense scan: lane (query, half) holds 16 documents per 32-query block)
 #pragma unroll

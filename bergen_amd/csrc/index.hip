@@ -317,6 +317,9 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "sparse_kernel") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_kernel must be 0 (broadcast) or 1 (mfma)");
         bh_sparse_set_kernel((int)value);
+    } else if (s == "sparse_head") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_head must be 0 (plain CSR stream) or 1 (corpus-head tiles + tail stream)");
+        bh_sparse_set_head((int)value);
     } else if (s == "sparse_ablate") {
         if (value < 0 || value > 1023) return fail(BH_EINVAL, "sparse_ablate must be 0..1023");
         bh_sparse_set_ablate((int)value);

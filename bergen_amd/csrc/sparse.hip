@@ -38,7 +38,16 @@ struct bh_sparse_index {
     BhDevBuf<unsigned> gthr, bitmap;
     bool nonneg_docs = true;  // no stored document weight is negative (SPLADE vectors are log(1 + relu(.)) >= 0)
     BhDevBuf<unsigned short> prefix;
-    BhDevBuf<_Float16> W, qdense, WhT;
+    BhDevBuf<_Float16> W, qdense, WhT, WgT;
+    // corpus-side head block (csr_head.hip / csr_mfma.hip): the 64 terms of largest document frequency as a dense tile per
+    // 32-document group in front of the group's remaining entries; built at finalize, read by the MFMA scan only
+    std::vector<unsigned> term_df;        // [vocab + 1] document frequency by stored id, counted while the rows are uploaded
+    std::vector<int> head_terms;          // stored ids of the corpus-head terms, ascending
+    std::vector<unsigned char> head_slot; // [vocab + 1] slot 0..63 of a corpus-head term, 0xff otherwise
+    BhDevBuf<unsigned> stream2;           // tiles + tail entries
+    BhDevBuf<long long> row_ptr2;         // [n_rows + 1] row pointers of the tail entries
+    BhDevBuf<unsigned char> head_slot_dev;
+    bool has_head = false;
     BhDevBuf<unsigned> sinfo, pairs;
     BhDevBuf<unsigned char> outbuf;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -50,6 +59,7 @@ namespace {
 
 int g_sparse_ablate = 0;
 int g_sparse_kernel = 1;  // 1 = csr_mfma.hip (head terms through MFMA), 0 = csr_topk.hip (broadcast per hit)
+int g_sparse_head = 1;    // 1 = the MFMA scan reads the corpus-head tiles + tail stream built at finalize, 0 = the plain CSR
 
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kTileQ = 64;
@@ -97,6 +107,7 @@ int pick_kp_sparse(int k) {
 
 void bh_sparse_set_kernel(int which) { g_sparse_kernel = which ? 1 : 0; }
 void bh_sparse_set_ablate(int bits) { g_sparse_ablate = bits; }
+void bh_sparse_set_head(int on) { g_sparse_head = on ? 1 : 0; }
 
 extern "C" {
 
@@ -148,6 +159,10 @@ void bh_sparse_destroy(bh_sparse_index* ix) {
     ix->W.release();
     ix->qdense.release();
     ix->WhT.release();
+    ix->WgT.release();
+    ix->stream2.release();
+    ix->row_ptr2.release();
+    ix->head_slot_dev.release();
     ix->sinfo.release();
     ix->pairs.release();
     ix->outbuf.release();
@@ -176,6 +191,7 @@ int bh_sparse_upload_csr(bh_sparse_index* ix, int64_t row0, int64_t n, const int
     if (val_dtype != BH_F16 && val_dtype != BH_F32) return bh_fail(BH_EINVAL, "bad val_dtype %d", val_dtype);
     if (n == 0) return BH_OK;
     if (!indptr || indptr[0] != 0) return bh_fail(BH_EINVAL, "indptr must start at 0");
+    if (ix->term_df.empty()) ix->term_df.assign((size_t)ix->vocab + 1, 0u);
     const int64_t nnz_in = indptr[n];
     if (nnz_in < 0 || (nnz_in > 0 && (!terms || !values))) return bh_fail(BH_EINVAL, "null terms / values");
     BH_HIP_TRY(hipSetDevice(ix->device));
@@ -196,6 +212,7 @@ int bh_sparse_upload_csr(bh_sparse_index* ix, int64_t row0, int64_t n, const int
             if ((hb & 0x7fffu) == 0) continue;  // +-0
             if (hb & 0x8000u) ix->nonneg_docs = false;
             packed.push_back((unsigned)(t + 1) | ((unsigned)hb << 16));  // stored id = term + 1
+            ++ix->term_df[(size_t)t + 1];
         }
         std::sort(packed.begin() + start, packed.end(), [](unsigned x, unsigned y) { return (x & 0xffffu) < (y & 0xffffu); });
         for (size_t i = start + 1; i < packed.size(); ++i)
@@ -222,6 +239,45 @@ int bh_sparse_finalize(bh_sparse_index* ix) {
     if (ix->rows_have != ix->n_rows)
         return bh_fail(BH_EINCOMPLETE, "!!! Index is not complete. Please re-index. Missing %lld documents in the index. !!!",
                        (long long)(ix->n_rows - ix->rows_have));
+    // ---- corpus-side head block: the 64 terms of largest document frequency become a dense tile per 32-document group
+    // (csr_head.hip); the original CSR stays for the canonical re-score and the first-generation scan
+    if (!ix->finalized && ix->nnz > 0 && ix->n_rows > 0) {
+        BH_HIP_TRY(hipSetDevice(ix->device));
+        const int V = ix->vocab + 1;
+        std::vector<int> order;
+        for (int t = 1; t < V; ++t)
+            if (ix->term_df[(size_t)t] > 0) order.push_back(t);
+        std::sort(order.begin(), order.end(), [&](int x, int y) {
+            return ix->term_df[(size_t)x] != ix->term_df[(size_t)y] ? ix->term_df[(size_t)x] > ix->term_df[(size_t)y] : x < y;
+        });
+        order.resize(std::min<size_t>(order.size(), BH_CSR_HEAD_TERMS));
+        std::sort(order.begin(), order.end());
+        ix->head_terms = order;
+        ix->head_slot.assign((size_t)V, (unsigned char)0xff);
+        for (size_t i = 0; i < order.size(); ++i) ix->head_slot[(size_t)order[i]] = (unsigned char)i;
+        int rc;
+        if ((rc = ix->head_slot_dev.ensure((size_t)V))) return rc;
+        if ((rc = ix->row_ptr2.ensure((size_t)ix->n_rows + 1))) return rc;
+        BhDevBuf<unsigned> cnt;
+        if ((rc = cnt.ensure((size_t)ix->n_rows))) return rc;
+        hipStream_t st = ix->stream;
+        BH_HIP_TRY(hipMemcpyAsync(ix->head_slot_dev.p, ix->head_slot.data(), (size_t)V, hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(bh_launch_csr_tail_count(ix->entries.p, ix->row_ptr.p, ix->n_rows, ix->head_slot_dev.p, cnt.p, st));
+        std::vector<unsigned> cnt_h((size_t)ix->n_rows);
+        BH_HIP_TRY(hipMemcpyAsync(cnt_h.data(), cnt.p, (size_t)ix->n_rows * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        BH_HIP_TRY(hipStreamSynchronize(st));
+        cnt.release();
+        std::vector<long long> rp2((size_t)ix->n_rows + 1);
+        rp2[0] = 0;
+        for (int64_t r = 0; r < ix->n_rows; ++r) rp2[(size_t)r + 1] = rp2[(size_t)r] + (long long)cnt_h[(size_t)r];
+        const long long n_groups = (ix->n_rows + 31) / 32;
+        const size_t stream_dwords = (size_t)rp2[(size_t)ix->n_rows] + (size_t)BH_CSR_HEAD_DWORDS * (size_t)n_groups;
+        if ((rc = ix->stream2.ensure(stream_dwords + 64))) return rc;
+        BH_HIP_TRY(hipMemcpyAsync(ix->row_ptr2.p, rp2.data(), rp2.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+        BH_HIP_TRY(bh_launch_csr_split(ix->entries.p, ix->row_ptr.p, ix->row_ptr2.p, ix->n_rows, ix->head_slot_dev.p, ix->stream2.p, st));
+        BH_HIP_TRY(hipStreamSynchronize(st));
+        ix->has_head = true;
+    }
     ix->finalized = true;
     return BH_OK;
 }
@@ -302,10 +358,21 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         }
     }
     const bool mfma = g_sparse_kernel == 1;
+    // the MFMA scan on the corpus-head tiles + tail stream: a query's weights of the 64 corpus-head terms go into WgT (matrix
+    // cores), only its other terms enter the tile's term set
+    const bool use_head = mfma && ix->has_head && g_sparse_head != 0;
+    std::vector<std::vector<std::pair<int, unsigned short>>> qnz_tail;
+    if (use_head) {
+        qnz_tail.resize((size_t)nq);
+        for (int q = 0; q < nq; ++q)
+            for (auto& tv : qnz[(size_t)q])
+                if (ix->head_slot[(size_t)tv.first] == 0xffu) qnz_tail[(size_t)q].push_back(tv);
+    }
+    const auto& qsrc = use_head ? qnz_tail : qnz;  // what the tile's term tables are built from
     const int waves_per_wg = mfma ? 8 : 16;
     if ((rc = ix->cand.ensure((size_t)grid * waves_per_wg * 64 * 2 * kp))) return rc;
     // LDS budget of the MFMA kernel: tables + 8 waves x (4 KiB D tile + 8 KiB S tile)
-    const int mfma_fixed = n_words * 6 + 16 + 512 + 64 * 144 + 32 + 8 * BH_CSR_MFMA_WAVE_LDS;
+    const int mfma_fixed = n_words * 6 + 16 + 512 + 2 * 64 * 144 + 32 + 8 * BH_CSR_MFMA_WAVE_LDS;
     const int mfma_table_bytes = kLdsBytes - mfma_fixed;  // for sinfo (4 B per slot) + pairs (4 B per pair)
     if (mfma && mfma_table_bytes < 4096) return bh_fail(BH_EUNSUPPORTED, "vocab %d leaves no LDS for the tile tables", V);
 
@@ -313,6 +380,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         if ((rc = ix->sinfo.ensure((size_t)mfma_table_bytes / 4 + 64))) return rc;
         if ((rc = ix->pairs.ensure((size_t)mfma_table_bytes / 4 + 64))) return rc;
         if ((rc = ix->WhT.ensure(64 * 64))) return rc;
+        if ((rc = ix->WgT.ensure(2 * 64 * 64))) return rc;  // two sets, like the host tables
     }
     // Host tables come in two sets: while the GPU works on tile p the host builds tile p + 1 (its copies are enqueued
     // behind tile p's kernels); a set is reused only after the tile that used it has completed.
@@ -324,6 +392,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     std::vector<int> term_cnt((size_t)V, 0);
     std::vector<unsigned> sinfo_s[2], pairs_s[2];
     std::vector<unsigned short> WhT_s[2] = {std::vector<unsigned short>((size_t)64 * 64), std::vector<unsigned short>((size_t)64 * 64)};
+    std::vector<unsigned short> WgT_s[2] = {std::vector<unsigned short>((size_t)64 * 64), std::vector<unsigned short>((size_t)64 * 64)};
     // the dense fp16 query matrix for the re-score kernel, built ON the device from the non-zeros (memset + scatter)
     {
         std::vector<unsigned long long> qpos;
@@ -387,7 +456,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         std::fill(bm.begin(), bm.end(), 0u);
         int nt = 0, n_slots = 0, n_pairs_tot = 0;
         while (q0 + nt < nq && nt < kTileQ) {
-            const auto& nz = qnz[(size_t)(q0 + nt)];
+            const auto& nz = qsrc[(size_t)(q0 + nt)];
             int add = 0;
             for (auto& tv : nz)
                 if (!(bm[tv.first >> 5] >> (tv.first & 31) & 1u)) ++add;
@@ -395,7 +464,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
                                    : (n_slots + add <= max_slots);
             if (!fits) {
                 if (nt == 0)
-                    return bh_fail(BH_EUNSUPPORTED, "query %d has %d non-zero terms: too many for the LDS tile", q0, (int)nz.size());
+                    return bh_fail(BH_EUNSUPPORTED, "query %d has %d non-zero terms: too many for the LDS tile", q0, (int)qnz[(size_t)q0].size());
                 break;
             }
             for (auto& tv : nz) bm[tv.first >> 5] |= 1u << (tv.first & 31);
@@ -440,7 +509,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             // head = the (up to) 64 terms used by the most queries of the tile; the rest are tail terms with pair lists
             std::vector<int> terms;
             for (int j = 0; j < nt; ++j)
-                for (auto& tv : qnz[(size_t)(q0 + j)])
+                for (auto& tv : qsrc[(size_t)(q0 + j)])
                     if (term_cnt[(size_t)tv.first]++ == 0) terms.push_back(tv.first);
             std::vector<int> order(terms);
             std::sort(order.begin(), order.end(), [&](int x, int y) {
@@ -462,7 +531,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             pairs_h.assign((size_t)std::max<unsigned>(1u, off[(size_t)n_slots]), 0u);
             std::vector<unsigned> fill(off.begin(), off.end() - 1);
             for (int j = 0; j < nt; ++j)
-                for (auto& tv : qnz[(size_t)(q0 + j)]) {
+                for (auto& tv : qsrc[(size_t)(q0 + j)]) {
                     const int sl = slot_of(tv.first);
                     const int hi = head_idx_of_slot[(size_t)sl];
                     if (hi >= 0)
@@ -485,6 +554,21 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             BhCsrMfmaArgs ma2{};
             ma2.entries = ix->entries.p;
             ma2.row_ptr = ix->row_ptr.p;
+            if (use_head) {
+                auto& WgT_h = WgT_s[par];
+                std::fill(WgT_h.begin(), WgT_h.end(), (unsigned short)0);
+                for (int j = 0; j < nt; ++j)
+                    for (auto& tv : qnz[(size_t)(q0 + j)]) {
+                        const unsigned char hs = ix->head_slot[(size_t)tv.first];
+                        if (hs != 0xffu) WgT_h[(size_t)j * 64 + hs] = tv.second;
+                    }
+                _Float16* wg_dev = ix->WgT.p + (size_t)par * 64 * 64;
+                BH_HIP_TRY(hipMemcpyAsync(wg_dev, WgT_h.data(), 64 * 64 * 2, hipMemcpyHostToDevice, st));
+                ma2.entries = ix->stream2.p;
+                ma2.row_ptr = ix->row_ptr2.p;
+                ma2.WgT = wg_dev;
+                ma2.head_dwords = BH_CSR_HEAD_DWORDS;
+            }
             ma2.n_rows = ix->n_rows;
             ma2.bitmap = ix->bitmap.p;
             ma2.prefix = ix->prefix.p;
@@ -498,7 +582,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             ma2.off_sinfo = (ma2.off_prefix + n_words * 2 + 15) / 16 * 16;
             ma2.off_pairs = ma2.off_sinfo + n_slots * 4;
             ma2.off_thr = (ma2.off_pairs + n_pairs * 4 + 15) / 16 * 16;
-            ma2.off_tiles = (ma2.off_thr + 512 + 64 * 144 + 15) / 16 * 16;  // published[64] bound[64] | WhT image | per-wave tiles
+            ma2.off_tiles = (ma2.off_thr + 512 + 2 * 64 * 144 + 15) / 16 * 16;  // published[64] bound[64] | WhT image | WgT image | per-wave tiles
             ma2.cand = ix->cand.p;
             ma2.partial = ix->partial.p + (size_t)par * partial_elems;
             ma2.gthr = ix->gthr.p;

@@ -25,15 +25,18 @@ def _index(amd, indptr, terms, w, V, pieces=1):
     return ix.finalize()
 
 
-@pytest.fixture(scope="module", params=[1, 0], ids=["mfma-kernel", "broadcast-kernel"])
+@pytest.fixture(scope="module", params=[(1, 1), (1, 0), (0, 0)], ids=["mfma-kernel-corpus-head", "mfma-kernel-plain-csr", "broadcast-kernel"])
 def amd(request):
-    """Both scan kernels (csr_mfma.hip = default, csr_topk.hip) must give the same bit-exact results."""
+    """Every scan path must give the same bit-exact results: csr_mfma.hip on the corpus-head tiles + tail stream built at
+    finalize (the default), csr_mfma.hip on the plain CSR stream, and the first-generation csr_topk.hip."""
     import bergen_amd
     from bergen_amd import _lib
     _lib.init(0)
-    _lib.set_option("sparse_kernel", request.param)
+    _lib.set_option("sparse_kernel", request.param[0])
+    _lib.set_option("sparse_head", request.param[1])
     yield bergen_amd
     _lib.set_option("sparse_kernel", 1)
+    _lib.set_option("sparse_head", 1)
 
 
 def test_golden_fixture(amd):
@@ -57,6 +60,29 @@ def test_random_matches_oracle(amd, n, V, nq, k, qnnz):
     s, i = ix.search(q, k)
     want_s, want_i = c_oracle.sparse_canonical_search(dp, dt, dw, V, q, k)
     assert_bit_exact(s, i, want_s, want_i, f"sparse n={n} V={V} nq={nq} k={k}")
+    ix.close()
+
+
+@pytest.mark.parametrize("n,V,mean_nnz", [(33, 50, 20), (1000, 64, 30), (4097, 30522, 180), (2500, 200, 60), (31, 3000, 5)])
+def test_corpus_head_tiles_at_the_edges(amd, n, V, mean_nnz):
+    """The corpus-side head block (csr_head.hip): vocabularies with fewer than / exactly 64 terms (every entry is a head
+    entry, the tail stream is empty), Zipf corpora whose head terms sit in every document, a last group of fewer than 32
+    documents, a single group; queries with head terms only, tail terms only, both."""
+    dp, dt, dw = synth.random_sparse_corpus_fast(n, V, seed=n + V, mean_nnz=min(mean_nnz, V // 2), lo=0, hi=min(400, V - 1))
+    qp, qt, qw = synth.random_sparse_corpus_fast(70, V, seed=V + 1, mean_nnz=min(12, V // 3), lo=1, hi=min(40, V - 1))
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    df = np.bincount(dt, minlength=V)
+    head = np.argsort(-df, kind="stable")[:64]
+    q[0] = 0
+    q[0, head[:5]] = np.float16(1.5)                 # head terms only
+    q[1] = 0
+    rare = np.argsort(df, kind="stable")[:4]
+    q[1, rare] = np.float16(2.0)                     # (mostly) tail terms only
+    ix = _index(amd, dp, dt, dw, V, pieces=3)
+    k = min(50, n)
+    s, i = ix.search(q, k)
+    want_s, want_i = c_oracle.sparse_canonical_search(dp, dt, dw, V, q, k)
+    assert_bit_exact(s, i, want_s, want_i, f"corpus head n={n} V={V}")
     ix.close()
 
 

@@ -28,6 +28,22 @@ def test_max_passage_and_metrics_hand_checked(tmp_path):
     assert m["P_1"] == pytest.approx(0.5) and m["recall_2"] == pytest.approx(0.75)
 
 
+def test_zero_relevant_topics_and_cut_offs_follow_trec_eval():
+    """The cases round 2's review asked about, with the values trec_eval 9.0's m_recall.c / m_P.c give (pytrec_eval wraps
+    those functions and evaluates every run query that HAS a qrels entry, relevant documents or not; not installable here:
+    profiles/r03_pip_pytrec_eval_attempt.log):
+      * a judged query whose documents all have relevance 0: num_rel = 0 -> recall stays rel_so_far = 0 (m_recall.c only
+        normalises `if (res_rels.num_rel)`), P_1 = 0, and the query COUNTS in the mean (reference utils.py:295-296 divides by
+        len(metrics_out));
+      * fewer than k documents retrieved: recall_k uses what was retrieved;
+      * relevance grades > 1 count as relevant, negative grades do not."""
+    run = {"zero": {"A": 2.0, "B": 1.0}, "short": {"R": 1.0}, "graded": {"G2": 3.0, "NEG": 2.0, "G1": 1.0}}
+    qrel = {"zero": {"A": 0, "B": 0}, "short": {"R": 1, "S": 1, "T": 1}, "graded": {"G2": 2, "NEG": -1, "G1": 1}}
+    m = evaluation.ranking_metrics(run, qrel, top_k=2)
+    assert m["P_1"] == pytest.approx((0 + 1 + 1) / 3)
+    assert m["recall_2"] == pytest.approx((0 + 1 / 3 + 1 / 2) / 3)
+
+
 def test_eval_retrieval_kilt_files_and_early_returns(tmp_path):
     exp, qrels = tmp_path / "exp", tmp_path / "qrels"
     exp.mkdir()
