@@ -103,6 +103,7 @@ SYMBOLS = {
     "bh_encoder_set_tensor": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, _i32, _i64]),
     "bh_encoder_commit": (ctypes.c_int, [_vp]),
     "bh_encoder_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i64]),
+    "bh_encoder_set_rel_index": (ctypes.c_int, [_vp, _vp, _i32]),
     "bh_encoder_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32]),
     "bh_encoder_counters_get": (ctypes.c_int, [_vp, ctypes.POINTER(bh_encoder_counters)]),
     "bh_encoder_destroy": (None, [_vp]),

@@ -167,10 +167,21 @@ struct BhAttnArgs {
     int d_model;
     int v_lds_off;       // filled by the launcher: byte offset of the V^T image in LDS
     const int* seq_idx;  // filled by the launcher: optional indirection blockIdx.y -> sequence (length buckets)
+    // disentangled (DeBERTa-v2/v3) attention, attention_rel.hip only: score[i][j] = (Q_i.K_j + c2p[i][t(i-j)] + p2c[j][t(i-j)]) * scale
+    const _Float16* c2p = nullptr;  // [n_heads][tokens][rel_ld]: Q_i . Kr[p]  (Kr = key_proj(rel_embeddings))
+    const _Float16* p2c = nullptr;  // [n_heads][tokens][rel_ld]: K_j . Qr[p]  (Qr = query_proj(rel_embeddings))
+    long long rel_ld = 0;           // 2 * span
+    long long rel_head_stride = 0;  // tokens * rel_ld
+    const int* rel_idx = nullptr;   // [2 * rel_center + 1] t(delta) at index delta + rel_center
+    int rel_center = 0;             // max sequence length - 1
+    float rel_scale = 0.f;          // 1 / sqrt(3 * head_dim)
+    int rel_lds_off = 0;            // filled by the launcher: byte offset of the index table in LDS
 };
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
                                         int max_len_long, int n_heads, hipStream_t stream, int short_max = 128);
+// attention_rel.hip: DeBERTa-v2/v3 disentangled attention (one launch, 8-wave workgroups)
+hipError_t bh_launch_attention_rel(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 
 struct BhEmbedArgs {
     const int* tok;  // [n_rows] token id / position id / token-type id of each packed row
@@ -302,6 +313,7 @@ struct BhClsHeadArgs {
     const _Float16* bc;        // [n_labels]
     float* out;                // [batch][n_labels] logits, fp32
     int batch, d, n_labels;
+    int activation = 0;        // 0 = tanh (BertPooler), 1 = erf-GELU (DeBERTa's ContextPooler)
 };
 hipError_t bh_launch_cls_head(const BhClsHeadArgs& a, hipStream_t stream);
 

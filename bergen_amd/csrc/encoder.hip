@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -72,6 +73,15 @@ struct bh_encoder {
     _Float16 *cls_wp = nullptr, *cls_bp = nullptr, *cls_wc = nullptr, *cls_bc = nullptr;
     int n_labels = 0;
     std::map<std::string, bool> cls_have;
+    // optional disentangled attention (DeBERTa-v2 / v3; option "rel_attention_span" before the weights are set): the
+    // relative-position embedding table [2 span][d] with its LayerNorm, the index table t(delta) and per-forward workspace
+    int rel_span = 0;
+    _Float16* rel_arena = nullptr;
+    _Float16 *rel_emb = nullptr, *rel_g = nullptr, *rel_b = nullptr;
+    BhDevBuf<int> rel_idx;
+    int rel_center = -1;
+    BhDevBuf<_Float16> REL_LN, REL_QK, RELB;
+    int cls_activation = 0;      // 0 = tanh (BertPooler), 1 = erf-GELU (DeBERTa ContextPooler)
     BhDevBuf<int> ibuf;          // tok | pos | typ | seq_len | slot
     BhDevBuf<long long> seq_off;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -276,6 +286,11 @@ void bh_encoder_destroy(bh_encoder* e) {
     e->ibuf.release();
     e->seq_off.release();
     e->SEG.release();
+    e->rel_idx.release();
+    e->REL_LN.release();
+    e->REL_QK.release();
+    e->RELB.release();
+    if (e->rel_arena) (void)hipFree(e->rel_arena);
     if (e->arena) (void)hipFree(e->arena);
     if (e->mlm_arena) (void)hipFree(e->mlm_arena);
     if (e->cls_arena) (void)hipFree(e->cls_arena);
@@ -378,12 +393,50 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
         e->gemm_variant = (int)value;
         return BH_OK;
     }
+    if (std::string(name) == "rel_attention_span") {
+        // DeBERTa-v2 / v3 disentangled attention with 2 * span relative positions (config.position_buckets); must precede
+        // the weights: adds the slots of encoder.rel_embeddings.weight and encoder.LayerNorm.{weight,bias}
+        if (value < 8 || value > 512 || (value & 7)) return bh_fail(BH_EINVAL, "rel_attention_span must be a multiple of 8 in 8..512");
+        if (e->rel_arena) return bh_fail(BH_EINVAL, "rel_attention_span was already set");
+        if ((e->cfg.head_dim != 0 && e->cfg.head_dim != 64)) return bh_fail(BH_EUNSUPPORTED, "disentangled attention needs 64-dim heads");
+        const size_t d = e->cfg.hidden, rows = 2 * (size_t)value;
+        BH_HIP_TRY(hipSetDevice(e->device));
+        BH_HIP_TRY(hipMalloc((void**)&e->rel_arena, (rows * d + 2 * d + 64) * sizeof(_Float16)));
+        e->rel_emb = e->rel_arena;
+        e->rel_g = e->rel_emb + rows * d;
+        e->rel_b = e->rel_g + d;
+        e->slots["encoder.rel_embeddings.weight"] = {e->rel_emb, (int64_t)(rows * d)};
+        e->slots["encoder.LayerNorm.weight"] = {e->rel_g, (int64_t)d};
+        e->slots["encoder.LayerNorm.bias"] = {e->rel_b, (int64_t)d};
+        e->rel_span = (int)value;
+        e->committed = false;
+        return BH_OK;
+    }
+    if (std::string(name) == "cls_activation") {
+        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "cls_activation must be 0 (tanh) or 1 (erf-GELU)");
+        e->cls_activation = (int)value;
+        return BH_OK;
+    }
     if (std::string(name) == "attn_short_len") {
         if (value < 32 || value > 512 || (value & 31)) return bh_fail(BH_EINVAL, "attn_short_len must be a multiple of 32 in 32..512");
         e->attn_short = (int)value;
         return BH_OK;
     }
     return bh_fail(BH_EINVAL, "unknown encoder option '%s'", name);
+}
+
+int bh_encoder_set_rel_index(bh_encoder* e, const int32_t* table, int32_t n) {
+    if (!e || !table) return bh_fail(BH_EINVAL, "null argument");
+    if (e->rel_span <= 0) return bh_fail(BH_EINVAL, "set option rel_attention_span first");
+    if (n < 1 || (n & 1) == 0) return bh_fail(BH_EINVAL, "the index table has 2 * (max length) - 1 entries, got %d", n);
+    for (int i = 0; i < n; ++i)
+        if (table[i] < 0 || table[i] >= 2 * e->rel_span) return bh_fail(BH_EINVAL, "index %d at %d outside 0..%d", table[i], i, 2 * e->rel_span - 1);
+    int rc = e->rel_idx.ensure((size_t)n);
+    if (rc) return rc;
+    BH_HIP_TRY(hipSetDevice(e->device));
+    BH_HIP_TRY(hipMemcpy(e->rel_idx.p, table, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    e->rel_center = (n - 1) / 2;
+    return BH_OK;
 }
 
 int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* attention_mask,
@@ -397,6 +450,9 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if (pool == 4 && !(e->cls_arena && e->n_labels > 0))
         return bh_fail(BH_EINCOMPLETE, "pool 4 (classification head) needs the pooler.dense.* and classifier.* weights");
     if (pool == 3 && !e->has_mlm) return bh_fail(BH_EINCOMPLETE, "pool 3 (splade) needs the cls.predictions.* weights");
+    if (e->rel_span > 0 && (e->rel_center < 0 || seq_len - 1 > e->rel_center))
+        return bh_fail(BH_EINVAL, "disentangled attention: the relative index table covers sequences of at most %d tokens (bh_encoder_set_rel_index), got %d",
+                       e->rel_center + 1, seq_len);
     if (batch == 0) return BH_OK;
     if (!input_ids || !out) return bh_fail(BH_EINVAL, "null buffer");
     const bh_encoder_config& c = e->cfg;
@@ -525,6 +581,25 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
 
     // the blocked V^T layout is written by the persistent GEMM only (256-row tiles of the weight operand)
     const bool vt_blocked = (da % 256 == 0) && (e->gemm_variant == 0 || (e->gemm_variant >= 7 && e->gemm_variant <= 9));
+    const bool rel = e->rel_span > 0;
+    const int rel_n = 2 * e->rel_span;
+    if (rel) {
+        // relative-position embeddings, layer-normed once per forward (DebertaV2Encoder.get_rel_embedding); per layer their
+        // query / key projections, and per head the two position terms of every token against all 2 span positions
+        if ((rc = e->REL_LN.ensure((size_t)rel_n * d))) return rc;
+        if ((rc = e->REL_QK.ensure((size_t)rel_n * 2 * da))) return rc;
+        if ((rc = e->RELB.ensure((size_t)2 * c.n_heads * M * rel_n))) return rc;
+        BhLnArgs ra{};
+        ra.in = e->rel_emb;
+        ra.residual = nullptr;
+        ra.out = e->REL_LN.p;
+        ra.n_rows = rel_n;
+        ra.d = d;
+        ra.eps = c.ln_eps;
+        ra.gamma = e->rel_g;
+        ra.beta = e->rel_b;
+        BH_HIP_TRY(bh_launch_layernorm(ra, st));
+    }
     for (int l = 0; l < c.n_layers; ++l) {
         const Layer& L = e->layers[l];
         // Q | K projections: QK[m][2d] = X Wqk^T + bqk
@@ -543,7 +618,31 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         aa.seq_off = e->seq_off.p;
         aa.seq_len = d_len;
         aa.d_model = da;
-        BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short));
+        if (rel) {
+            // Qr | Kr = rel . Wqk^T + bqk (share_att_key: the layer's own query / key projections), then per head
+            // c2p = Q_h Kr_h^T and p2c = K_h Qr_h^T: [tokens][2 span] each (K = 64: one GEMM stage)
+            if ((rc = gemm(e, e->REL_LN.p, d, L.wqk, d, e->REL_QK.p, 2 * da, rel_n, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
+            _Float16* c2p = e->RELB.p;
+            _Float16* p2c = e->RELB.p + (size_t)c.n_heads * M * rel_n;
+            for (int hh = 0; hh < c.n_heads; ++hh) {
+                if ((rc = gemm(e, e->QK.p + hh * 64, 2 * da, e->REL_QK.p + da + hh * 64, 2 * da, c2p + (size_t)hh * M * rel_n, rel_n,
+                               m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0))) return rc;
+                if ((rc = gemm(e, e->QK.p + da + hh * 64, 2 * da, e->REL_QK.p + hh * 64, 2 * da, p2c + (size_t)hh * M * rel_n, rel_n,
+                               m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0))) return rc;
+            }
+            aa.c2p = c2p;
+            aa.p2c = p2c;
+            aa.rel_ld = rel_n;
+            aa.rel_head_stride = (long long)M * rel_n;
+            aa.rel_idx = e->rel_idx.p;
+            aa.rel_center = e->rel_center;
+            aa.rel_scale = 1.0f / sqrtf(3.0f * 64.0f);
+            int max_len_all = 0;
+            for (int b = 0; b < batch; ++b) max_len_all = std::max(max_len_all, len[b]);
+            BH_HIP_TRY(bh_launch_attention_rel(aa, batch, c.n_heads, max_len_all, st));
+        } else {
+            BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short));
+        }
         // attention output projection, then LayerNorm(projection + layer input)
         if ((rc = gemm(e, e->CTX.p, da, L.wo, da, e->Y.p, d, m_pad, d, da, L.bo, 1, nullptr, 0, 0))) return rc;
         BhLnArgs la{};
@@ -575,6 +674,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         ca.batch = batch;
         ca.d = d;
         ca.n_labels = e->n_labels;
+        ca.activation = e->cls_activation;
         BH_HIP_TRY(bh_launch_cls_head(ca, st));
     } else if (pool == 3) {
         // masked-LM head (BertOnlyMLMHead) + SPLADE pooling, reference models/retrievers/splade.py:36-43:

@@ -219,7 +219,10 @@ __global__ void __launch_bounds__(256) bh_cls_head_kernel(BhClsHeadArgs a) {
             for (int e = 0; e < 8; ++e) s += (float)v[e] * hs[c * 8 + e];
         }
         s = wave_sum(s);
-        if (lane == 0) ps[j] = tanhf(s + (float)a.bp[j]);
+        if (lane == 0) {
+            const float z = s + (float)a.bp[j];
+            ps[j] = a.activation == 1 ? 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)) : tanhf(z);
+        }
     }
     __syncthreads();
     for (int l = wave; l < a.n_labels; l += 4) {

@@ -44,7 +44,7 @@ def pool_mode_or_none(pooler):
         return None
 
 
-SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert")
+SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert", "deberta-v2")
 
 # DistilBERT names -> BERT names (same post-LN block, no token types, no pooler)
 _DISTIL = (("embeddings.word_embeddings.", "embeddings.word_embeddings."),
@@ -68,7 +68,45 @@ def canonical_config(config):
     mt = get("model_type", "bert") or "bert"
     if mt not in SUPPORTED_MODEL_TYPES:
         raise ValueError(f"model_type {mt!r} (BERT / DistilBERT / RoBERTa-family encoders only)")
-    if mt == "distilbert":
+    if mt == "deberta-v2":
+        # DeBERTa-v2 / v3 (the reference's default reranker, config/reranker/debertav3.yaml:3): the configuration the
+        # deberta-v3-* checkpoints ship — disentangled attention with shared keys, log-bucketed relative positions, no
+        # absolute positions, no token types, no convolution layer
+        pat = get("pos_att_type") or []
+        pat = sorted(x.strip() for x in (pat.split("|") if isinstance(pat, str) else pat))
+        norm = [x.strip() for x in str(get("norm_rel_ebd", "none")).lower().split("|")]
+        why = None
+        if not get("relative_attention", False):
+            why = "relative_attention is off"
+        elif pat != ["c2p", "p2c"]:
+            why = f"pos_att_type {pat} (c2p|p2c only)"
+        elif not get("share_att_key", False):
+            why = "share_att_key is off"
+        elif "layer_norm" not in norm:
+            why = f"norm_rel_ebd {norm} (layer_norm only)"
+        elif int(get("position_buckets", -1) or -1) <= 0:
+            why = "position_buckets <= 0"
+        elif get("position_biased_input", True):
+            why = "position_biased_input (absolute positions on top of the relative ones)"
+        elif int(get("conv_kernel_size", 0) or 0) > 0:
+            why = "conv_kernel_size > 0"
+        elif int(get("embedding_size", get("hidden_size")) or get("hidden_size")) != int(get("hidden_size")):
+            why = "embedding_size != hidden_size"
+        elif int(get("type_vocab_size", 0) or 0) != 0:
+            why = "type_vocab_size > 0"
+        elif int(get("pooler_hidden_size", get("hidden_size")) or get("hidden_size")) != int(get("hidden_size")):
+            why = "pooler_hidden_size != hidden_size"
+        elif str(get("pooler_hidden_act", "gelu")) != "gelu":
+            why = f"pooler_hidden_act {get('pooler_hidden_act')!r}"
+        if why:
+            raise ValueError(f"deberta-v2 configuration outside the HIP forward pass: {why}")
+        max_rel = int(get("max_relative_positions", -1) or -1)
+        c = dict(hidden_size=get("hidden_size"), num_attention_heads=get("num_attention_heads"),
+                 num_hidden_layers=get("num_hidden_layers"), intermediate_size=get("intermediate_size"),
+                 hidden_act=get("hidden_act", "gelu"), type_vocab_size=1, layer_norm_eps=get("layer_norm_eps", 1e-7),
+                 position_offset=0, rel_span=int(get("position_buckets")),
+                 max_relative_positions=max_rel if max_rel >= 1 else int(get("max_position_embeddings")))
+    elif mt == "distilbert":
         c = dict(hidden_size=get("dim"), num_attention_heads=get("n_heads"), num_hidden_layers=get("n_layers"),
                  intermediate_size=get("hidden_dim"), hidden_act=get("activation", "gelu"), type_vocab_size=1,
                  layer_norm_eps=1e-12, position_offset=0)
@@ -91,6 +129,8 @@ def canonical_config(config):
     hd = d // max(1, nh)
     if d != nh * hd or hd % 8 != 0 or not 8 <= hd <= 64:
         raise ValueError(f"head dim {d / max(1, nh):g} (multiples of 8 up to 64)")
+    if mt == "deberta-v2" and hd != 64:
+        raise ValueError(f"deberta-v2 with head dim {hd} (64 only)")
     if d % 64 != 0 or d > 2048 or nh * 64 > 2048:
         raise ValueError(f"hidden_size {d} with {nh} heads (multiple of 64, heads * 64 <= 2048)")
     c["head_dim"] = hd
@@ -104,12 +144,20 @@ def canonical_state_dict(cfg, state_dict):
     out = {}
     for name, t in state_dict.items():
         key = name
-        for pre in ("bert.", "distilbert.", "roberta.", "model."):
+        for pre in ("bert.", "distilbert.", "roberta.", "deberta.", "model."):
             if key.startswith(pre):
                 key = key[len(pre):]
         if key.endswith("position_ids") or key.endswith("token_type_ids"):
             continue
-        if mt == "distilbert":
+        if mt == "deberta-v2":
+            for a, b in ((".attention.self.query_proj.", ".attention.self.query."), (".attention.self.key_proj.", ".attention.self.key."),
+                         (".attention.self.value_proj.", ".attention.self.value.")):
+                if a in key:
+                    key = key.replace(a, b)
+                    break
+            if key.startswith(("lm_predictions.", "mask_predictions.", "cls.")):
+                continue
+        elif mt == "distilbert":
             if key.startswith("transformer.layer."):
                 key = "encoder.layer." + key[len("transformer.layer."):]
             for a, b in _DISTIL:
@@ -129,6 +177,10 @@ def canonical_state_dict(cfg, state_dict):
         out[key] = t
     if mt == "distilbert" or "embeddings.token_type_embeddings.weight" not in out:
         out["embeddings.token_type_embeddings.weight"] = torch.zeros(int(cfg["type_vocab_size"]), d, dtype=torch.float16)
+    if mt == "deberta-v2":  # word embeddings only (position_biased_input = False): a zero position table
+        out["embeddings.position_embeddings.weight"] = torch.zeros(int(cfg["max_position_embeddings"]), d, dtype=torch.float16)
+        if "encoder.rel_embeddings.weight" in out:  # the attention uses the first 2 * position_buckets rows
+            out["encoder.rel_embeddings.weight"] = out["encoder.rel_embeddings.weight"][:2 * int(cfg["rel_span"])]
     if hd != 64:
         scale = (64.0 / hd) ** 0.5
         for key in list(out):
@@ -178,6 +230,21 @@ class BertEncoder:
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))
         self._h = h
+        self.disentangled = canon.get("model_type") == "deberta-v2"
+        if self.disentangled:
+            # DeBERTa-v2 / v3: relative-position tensors, the ContextPooler's GELU, and the index table t(delta) — the log
+            # bucket of transformers' make_log_bucket_position (modeling_deberta_v2.py:57-69), evaluated with the same torch
+            # float32 operations (its ceil() sits on float32 logarithms: another libm could move a bucket boundary)
+            span, max_rel, L = int(canon["rel_span"]), int(canon["max_relative_positions"]), int(get("max_position_embeddings"))
+            _lib.check(_lib.lib().bh_encoder_set_option(self._h, b"rel_attention_span", span))
+            _lib.check(_lib.lib().bh_encoder_set_option(self._h, b"cls_activation", 1))
+            rel = torch.arange(-(L - 1), L, dtype=torch.long)
+            mid = span // 2
+            abs_pos = torch.where((rel < mid) & (rel > -mid), torch.tensor(mid - 1).type_as(rel), torch.abs(rel))
+            log_pos = torch.ceil(torch.log(abs_pos / mid) / torch.log(torch.tensor((max_rel - 1) / mid)) * (mid - 1)) + mid
+            bucket = torch.where(abs_pos <= mid, rel.type_as(log_pos), log_pos * torch.sign(rel)).to(torch.long)
+            table = torch.clamp(bucket + span, 0, 2 * span - 1).to(torch.int32).contiguous()
+            _lib.check(_lib.lib().bh_encoder_set_rel_index(self._h, ctypes.c_void_p(table.data_ptr()), int(table.numel())))
         n_set = 0
         classifier = {}
         for name, t in state_dict.items():
@@ -195,7 +262,8 @@ class BertEncoder:
                 continue
             if key.startswith("cls.predictions."):
                 self.has_mlm_head = True  # BertForMaskedLM checkpoint: SPLADE pooling available (encode_splade)
-            elif not (key.startswith("embeddings.") or key.startswith("encoder.layer.")):
+            elif not (key.startswith("embeddings.") or key.startswith("encoder.layer.") or
+                      (self.disentangled and key in ("encoder.rel_embeddings.weight", "encoder.LayerNorm.weight", "encoder.LayerNorm.bias"))):
                 continue
             a = t.detach().to("cpu")
             if a.dtype not in (torch.float16, torch.float32):
@@ -261,6 +329,8 @@ class BertEncoder:
             raise ValueError(f"input_ids must be [B, T], got {tuple(ids.shape)}")
         B, T = ids.shape
         keep = [ids]
+        if self.disentangled:
+            token_type_ids = None  # DeBERTa-v3 has no token-type embeddings (type_vocab_size = 0): HF ignores the ids too
 
         def host(x):
             if x is None:

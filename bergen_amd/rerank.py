@@ -6,11 +6,13 @@ Reference -> here
   Rerank.__init__/eval/sort_by_score_indexes/get_clean_model_name   modules/rerank.py:16-68
   Reranker (ABC)                                                    models/rerankers/reranker.py:9-19
   CrossEncoder.__init__/collate_fn/__call__                         models/rerankers/crossencoder.py:13-39
-On a gfx950 device a BERT-architecture sequence-classification checkpoint (BAAI/bge-large-en, ...) runs on
-bergen_amd.BertEncoder: the hand-written encoder forward pass plus the BertPooler / classifier head kernel
-(`classify`, fp32 logits).  The reference pads every (query, passage) pair to max_len (padding="max_length",
-crossencoder.py:30) and runs the padding through the model; the native path packs the attended tokens only.
-Other architectures (DeBERTa-v3, XLM-RoBERTa) stay on their HF module.
+On a gfx950 device a sequence-classification checkpoint of an architecture the kernels cover runs on
+bergen_amd.BertEncoder — the hand-written encoder forward pass plus the pooler / classifier head kernel (`classify`, fp32
+logits): BERT (BAAI/bge-large-en, MiniLM ...), RoBERTa / XLM-RoBERTa (bge-reranker-v2-m3 ...) and DeBERTa-v2 / v3 with
+disentangled attention (naver/trecdl22-crossencoder-debertav3, the reference's default reranker, config/reranker/debertav3.yaml:3;
+csrc/attention_rel.hip).  The reference pads every (query, passage) pair to max_len (padding="max_length",
+crossencoder.py:30) and runs the padding through the model; the native path packs the attended tokens only.  Any other
+architecture stays on its HF module, loudly (`.backend` says which path runs).
 Differences: no torch.nn.DataParallel (crossencoder.py:20-21); scores are fp32 (the reference's
 are the fp16 logits of an fp16 model); `sort_by_score_indexes` keeps Python's stable sort, i.e. ties stay in
 retrieval order, as in the reference.

@@ -213,6 +213,16 @@ int bh_encoder_commit(bh_encoder* enc);
  * bench sweeps), "attn_short_len" (32..512, multiple of 32; default 128: longest sequence whose attention runs in a
  * 4-wave workgroup)}. */
 int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
+/* DeBERTa-v2 / v3 encoders (the reference's default reranker, config/reranker/debertav3.yaml:3, loaded through
+ * AutoModelForSequenceClassification, models/rerankers/crossencoder.py:18): set option "rel_attention_span" (=
+ * config.position_buckets, 2 * span relative positions; BEFORE the weights — it adds the tensors
+ * "encoder.rel_embeddings.weight" [2 * span, hidden], "encoder.LayerNorm.{weight,bias}"), option "cls_activation" 1 (the
+ * ContextPooler's erf-GELU instead of BertPooler's tanh), and hand over the relative index table
+ * t(delta) = clamp(bucket(delta) + span, 0, 2 * span - 1) for delta = -(L - 1) .. L - 1 (n = 2 L - 1 entries, L = longest
+ * sequence the encoder will see; bucket = make_log_bucket_position of transformers' modeling_deberta_v2.py:57-69).  The
+ * attention is then the disentangled one: (Q K^T + c2p + p2c) / sqrt(3 * 64), modeling_deberta_v2.py:191-346.  Word
+ * embeddings only: pass zero position / token-type tables (position_biased_input = false, type_vocab_size = 0). */
+int bh_encoder_set_rel_index(bh_encoder* enc, const int32_t* table, int32_t n);
 
 /* One forward pass over a HOST batch in the layout of an HF BatchEncoding (row-major
  * [batch, seq_len] int64; attention_mask / token_type_ids may be NULL = all ones / all zeros).

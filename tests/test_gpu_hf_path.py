@@ -72,6 +72,13 @@ def _make(kind, tok, vocab, path):
         m = T.BertForMaskedLM(T.BertConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256, **kw))
     elif kind == "bert_cls":
         m = T.BertForSequenceClassification(T.BertConfig(hidden_size=128, num_attention_heads=4, intermediate_size=256, num_labels=1, **kw))
+    elif kind == "deberta_cls":
+        m = T.DebertaV2ForSequenceClassification(T.DebertaV2Config(
+            vocab_size=vocab, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+            max_position_embeddings=66, type_vocab_size=0, layer_norm_eps=1e-7, hidden_act="gelu", relative_attention=True,
+            position_buckets=16, norm_rel_ebd="layer_norm", share_att_key=True, pos_att_type="p2c|c2p", position_biased_input=False,
+            max_relative_positions=-1, pooler_hidden_size=128, pooler_hidden_act="gelu", pooler_dropout=0.0, hidden_dropout_prob=0.0,
+            attention_probs_dropout_prob=0.0, pad_token_id=1, num_labels=1))
     elif kind == "xlmr_cls":
         m = T.XLMRobertaForSequenceClassification(T.XLMRobertaConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256,
                                                                      type_vocab_size=1, layer_norm_eps=1e-5, num_labels=1, **kw))
@@ -155,7 +162,7 @@ def test_splade_from_a_checkpoint_directory_runs_on_the_hip_path(toy_tokenizer_f
     assert ((want > 0.05) <= (got > 0)).all() and ((want < -0.05) <= (got == 0)).all()
 
 
-@pytest.mark.parametrize("kind", ["bert_cls", "xlmr_cls"])
+@pytest.mark.parametrize("kind", ["bert_cls", "xlmr_cls", "deberta_cls"])
 def test_cross_encoder_from_a_checkpoint_directory_runs_on_the_hip_path(kind, toy_tokenizer_files, tmp_path):
     import transformers as T
     import bergen_amd
