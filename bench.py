@@ -586,6 +586,48 @@ def encode_stage_leg(args, device_index):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def rerank_leg(args, device_index):
+    """The rerank stage's model call (reference models/rerankers/crossencoder.py:34-38) at the shapes of the
+    reference's two reranker families, random-init weights: a DeBERTa-v3-large-shaped cross-encoder (24 x 1024, 16 heads, 256
+    position buckets: naver/trecdl22-crossencoder-debertav3, config/reranker/debertav3.yaml:3) with disentangled attention,
+    and a BERT-large-shaped one (BAAI/bge-reranker-large ...), on 32 (query, passage) pairs of ~180 attended tokens (the
+    reference pads each pair to max_len 256 and runs the padding through the model).  pairs/s from the forward's HIP events."""
+    from bergen_amd import BertEncoder, synth
+    out = {}
+    rng = np.random.default_rng(17)
+    lens = np.clip(np.rint(rng.normal(180, 40, size=32)), 32, 256).astype(np.int64)
+    T = 256
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    for name, deb in (("deberta_v3_large_shape", True), ("bert_large_shape", False)):
+        cfg = dict(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                   max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+        sd = synth.random_bert(cfg, seed=61)
+        synth.random_cls_head(cfg, seed=62, num_labels=1, sd=sd)
+        if deb:
+            g = np.random.default_rng(63)
+            cfg.update(model_type="deberta-v2", type_vocab_size=0, layer_norm_eps=1e-7, relative_attention=True, position_buckets=256,
+                       norm_rel_ebd="layer_norm", share_att_key=True, pos_att_type="p2c|c2p", position_biased_input=False,
+                       max_relative_positions=-1)
+            sd = {k.replace(".attention.self.query.", ".attention.self.query_proj.").replace(".attention.self.key.", ".attention.self.key_proj.")
+                  .replace(".attention.self.value.", ".attention.self.value_proj."): v for k, v in sd.items()
+                  if not k.startswith(("embeddings.position_embeddings", "embeddings.token_type_embeddings"))}
+            sd["encoder.rel_embeddings.weight"] = (g.standard_normal((512, 1024)) * 0.02).astype(np.float16).astype(np.float32)
+            sd["encoder.LayerNorm.weight"] = np.ones(1024, np.float32)
+            sd["encoder.LayerNorm.bias"] = np.zeros(1024, np.float32)
+        enc = BertEncoder(cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=device_index)
+        ids = rng.integers(1, cfg["vocab_size"], size=(32, T)).astype(np.int64) * mask
+        kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+        enc.classify(kw)
+        best = 1e9
+        for _ in range(3):
+            logits = enc.classify(kw)
+            best = min(best, enc.counters()["forward_ms"])
+        out[name] = {"pairs_per_s": 32 / (best * 1e-3), "forward_ms": best, "attended_tokens": int(lens.sum()),
+                     "backend": "hip", "finite": bool(torch.isfinite(logits).all())}
+        enc.close()
+    return out
+
+
 def certificate_leg(args, local_rank, device):
     """The exactness certificate and its fall-back on a corpus that is NOT unit-norm Gaussian: rows with
     RetroMAE-like norms (|x| ~ U(10, 14); one row in 10 000 at 3x that: the certificate's bound uses the corpus-wide maximum),
@@ -968,6 +1010,11 @@ def run(args, env):
                 out["encode_stage"] = encode_stage_leg(args, local_rank)
             except Exception as exc:
                 out["encode_stage"] = {"error": repr(exc)}
+        if not args.no_encoder and world == 1:
+            try:
+                out["rerank"] = rerank_leg(args, local_rank)
+            except Exception as exc:
+                out["rerank"] = {"error": repr(exc)}
         if not args.no_splade and world == 1:
             ix.close()
             try:

@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 typedef unsigned long long bh_u64;
+#define BH_MAX_LIST_K 248   /* largest k one fused search serves (candidate lists of 256 entries with a margin of 8) */
+#define BH_MAX_K 4096       /* largest k bh_search* accepts: above BH_MAX_LIST_K the corpus is searched range by range (index.hip) */
 
 struct BhScanArgs {
     const _Float16* corpus;  // [n_tiles*32][D] fp16, rows >= n_rows are zero padding

@@ -460,8 +460,25 @@ int bh_index_finalize(bh_index* ix) {
     return BH_OK;
 }
 
+namespace {
+int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                   float* out_scores_dev, int64_t* out_ids_dev);
+}
+
+// k <= 248: one fused search (scan + merge / re-score + certificate).  Larger k: search_large_k below.
+static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                               float* out_scores_dev, int64_t* out_ids_dev);
+
 int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
                      float* out_scores_dev, int64_t* out_ids_dev) {
+    if (!ix) return fail(BH_EINVAL, "null index");
+    if (k > BH_MAX_LIST_K && k <= BH_MAX_K && nq > 0 && ix->finalized)
+        return search_large_k(ix, q_dev, q_dtype, nq, k, id_offset, out_scores_dev, out_ids_dev);
+    return search_device_lists(ix, q_dev, q_dtype, nq, k, id_offset, out_scores_dev, out_ids_dev);
+}
+
+static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                               float* out_scores_dev, int64_t* out_ids_dev) {
     if (!ix) return fail(BH_EINVAL, "null index");
     if (!ix->finalized) {
         const int64_t have = rows_have(ix);
@@ -474,7 +491,7 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     if (nq < 0 || k <= 0) return fail(BH_EINVAL, "nq=%d k=%d", nq, k);
     if (q_dtype != BH_F16 && q_dtype != BH_F32) return fail(BH_EINVAL, "bad q_dtype %d", q_dtype);
     const int kp = pick_kp(k);
-    if (kp < 0) return fail(BH_EUNSUPPORTED, "k=%d unsupported (max 248)", k);
+    if (kp < 0) return fail(BH_EUNSUPPORTED, "k=%d unsupported (max %d)", k, BH_MAX_K);
     if (nq == 0) return BH_OK;
     if (!q_dev || !out_scores_dev || !out_ids_dev) return fail(BH_EINVAL, "null buffer");
     HIP_TRY(hipSetDevice(ix->device));
@@ -793,6 +810,144 @@ int bh_search_device(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t n
     }
     return BH_OK;
 }
+
+namespace {
+
+// k > 248 (the reference accepts any top_k_documents, modules/retrieve.py:157): the candidate lists of the scan kernels hold
+// at most 256 entries, so the corpus is cut into contiguous row RANGES small enough that no range is expected to hold more
+// than ~100 of the top k, every range is searched for its exact top 248 by the ordinary fused search (a view of the index:
+// same kernels, same certificate), and the ranges' lists are merged in canonical order.  This is exact iff no range holds
+// more than 248 of the true top k, which is CHECKED: a range whose list is full (248 entries) and whose last entry still
+// belongs to the merged top k may have dropped a row — it is split in four and searched again, down to ranges of one
+// 32-row tile (which cannot overflow a 248-entry list).  Bytes streamed: one corpus pass per tile of 128 queries
+// (candidate lists of 256), as for k = 248; the price is the per-range fixed cost and a host merge of S x 248 entries per query.
+int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                   float* out_scores_dev, int64_t* out_ids_dev) {
+    if (!q_dev || !out_scores_dev || !out_ids_dev) return fail(BH_EINVAL, "null buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    constexpr int KK = BH_MAX_LIST_K;
+    struct Range {
+        int64_t t0, t1;  // tiles [t0, t1)
+        std::vector<float> s;
+        std::vector<long long> i;
+    };
+    _Float16* const rows0 = ix->rows;
+    const int64_t n_rows0 = ix->n_rows, n_tiles0 = ix->n_tiles;
+    float* d_s = nullptr;
+    long long* d_i = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_s, (size_t)nq * KK * sizeof(float)));
+    if (hipMalloc((void**)&d_i, (size_t)nq * KK * sizeof(long long)) != hipSuccess) {
+        (void)hipFree(d_s);
+        return fail(BH_ENOMEM, "hipMalloc of the range lists");
+    }
+    bh_counters total{};
+    int rc = BH_OK;
+    auto search_range = [&](Range& r) -> int {
+        const int64_t row_lo = r.t0 * 32, row_hi = std::min<int64_t>(n_rows0, r.t1 * 32);
+        ix->rows = rows0 + (size_t)row_lo * ix->dim_padded;  // a view: rows of the range, tile-aligned
+        ix->n_rows = row_hi - row_lo;
+        ix->n_tiles = r.t1 - r.t0;
+        const int rc2 = search_device_lists(ix, q_dev, q_dtype, nq, KK, id_offset + row_lo, d_s, reinterpret_cast<int64_t*>(d_i));
+        ix->rows = rows0;
+        ix->n_rows = n_rows0;
+        ix->n_tiles = n_tiles0;
+        if (rc2 != BH_OK) return rc2;
+        const bh_counters& c = ix->counters;
+        total.scan_ms += c.scan_ms;
+        total.merge_ms += c.merge_ms;
+        total.total_ms += c.total_ms;
+        total.algorithmic_bytes += c.algorithmic_bytes;
+        total.n_passes += c.n_passes;
+        total.uncertified_queries += c.uncertified_queries;
+        total.exact_ms += c.exact_ms;
+        total.exact_passes += c.exact_passes;
+        total.exact_rows_rescored += c.exact_rows_rescored;
+        total.query_tile = c.query_tile;
+        total.n_workgroups = c.n_workgroups;
+        total.k_padded = c.k_padded;
+        total.shader_mhz = c.shader_mhz;
+        r.s.resize((size_t)nq * KK);
+        r.i.resize((size_t)nq * KK);
+        HIP_TRY(hipMemcpy(r.s.data(), d_s, r.s.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(r.i.data(), d_i, r.i.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        return BH_OK;
+    };
+    // ranges: ~100 expected members of the top k each, tile-aligned
+    std::vector<Range> ranges;
+    {
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>(n_tiles0, (k + 99) / 100));
+        const int64_t per = (n_tiles0 + want - 1) / want;
+        for (int64_t t = 0; t < n_tiles0; t += per) ranges.push_back(Range{t, std::min(n_tiles0, t + per), {}, {}});
+    }
+    for (auto& r : ranges)
+        if ((rc = search_range(r)) != BH_OK) break;
+    std::vector<float> out_s((size_t)nq * k);
+    std::vector<long long> out_i((size_t)nq * k);
+    struct Ent {
+        float s;
+        long long id;
+        int range;
+    };
+    std::vector<Ent> all;
+    for (int round = 0; rc == BH_OK && round < 64; ++round) {
+        std::vector<char> overflow(ranges.size(), 0);
+        bool any = false;
+        for (int q = 0; q < nq; ++q) {
+            all.clear();
+            for (size_t j = 0; j < ranges.size(); ++j)
+                for (int t = 0; t < KK; ++t) {
+                    const long long id = ranges[j].i[(size_t)q * KK + t];
+                    if (id >= 0) all.push_back(Ent{ranges[j].s[(size_t)q * KK + t], id, (int)j});
+                }
+            std::sort(all.begin(), all.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s > b.s : a.id < b.id; });
+            const size_t take = std::min<size_t>(all.size(), (size_t)k);
+            for (size_t t = 0; t < (size_t)k; ++t) {
+                out_s[(size_t)q * k + t] = t < take ? all[t].s : -INFINITY;
+                out_i[(size_t)q * k + t] = t < take ? all[t].id : -1;
+            }
+            // a FULL list whose last entry is still inside the merged top k may have dropped a member of the top k
+            for (size_t j = 0; j < ranges.size(); ++j) {
+                const long long last_id = ranges[j].i[(size_t)q * KK + KK - 1];
+                if (last_id < 0) continue;  // the range's list is not full: it holds every candidate of the range
+                const float last_s = ranges[j].s[(size_t)q * KK + KK - 1];
+                // (fewer than k entries in all: every full list may hide members of the top k)
+                const bool last_in_topk = take < (size_t)k || last_s > all[take - 1].s ||
+                                          (last_s == all[take - 1].s && last_id <= all[take - 1].id);
+                if (last_in_topk && ranges[j].t1 - ranges[j].t0 > 1) {
+                    overflow[j] = 1;
+                    any = true;
+                }
+            }
+        }
+        if (!any) break;
+        std::vector<Range> next;
+        for (size_t j = 0; j < ranges.size() && rc == BH_OK; ++j) {
+            if (!overflow[j]) {
+                next.push_back(std::move(ranges[j]));
+                continue;
+            }
+            const int64_t span = ranges[j].t1 - ranges[j].t0, per = (span + 3) / 4;
+            for (int64_t t = ranges[j].t0; t < ranges[j].t1 && rc == BH_OK; t += per) {
+                Range r{t, std::min(ranges[j].t1, t + per), {}, {}};
+                rc = search_range(r);
+                next.push_back(std::move(r));
+            }
+        }
+        ranges.swap(next);
+    }
+    (void)hipFree(d_s);
+    (void)hipFree(d_i);
+    if (rc != BH_OK) return rc;
+    HIP_TRY(hipMemcpy(out_scores_dev, out_s.data(), out_s.size() * sizeof(float), hipMemcpyDefault));
+    HIP_TRY(hipMemcpy(out_ids_dev, out_i.data(), out_i.size() * sizeof(long long), hipMemcpyDefault));
+    total.n_rows = n_rows0;
+    total.dim = ix->dim;
+    total.dim_padded = ix->dim_padded;
+    ix->counters = total;
+    return BH_OK;
+}
+
+}  // namespace
 
 int bh_search(bh_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
               float* out_scores, int64_t* out_ids) {

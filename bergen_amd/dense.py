@@ -118,6 +118,40 @@ class CosineSim:
         return _unit_rows(q) @ _unit_rows(d).transpose(0, 1)
 
 
+def fast_tokenize(tokenizer, texts, max_len):
+    """`tokenizer(texts, padding="longest", truncation="longest_first", max_length=max_len, return_tensors='pt')` for a
+    Rust-backed (PreTrainedTokenizerFast) tokenizer, without the Python post-processing of that call: HF configures the
+    backend tokenizer's truncation / padding (set_truncation_and_padding), lets it encode the batch — that part is Rust,
+    parallel, and releases the GIL — and then rebuilds every Encoding field by field in Python and pads again before the
+    tensor conversion, which is 5-10x the encoding time (46 of 50 ms per 512 passages on the GPU box's host).  Here the
+    padded ids / type ids / mask are read straight from the backend's Encodings.  Same values as the HF call
+    (tests/test_host.py::test_fast_tokenize_equals_the_hf_call); None for a slow (Python) tokenizer or any surprise — the
+    caller then makes the HF call."""
+    try:
+        import numpy as np
+        from transformers.tokenization_utils_base import BatchEncoding
+        from transformers.utils import PaddingStrategy
+        from transformers.tokenization_utils_base import TruncationStrategy
+        backend = getattr(tokenizer, "backend_tokenizer", None)
+        if backend is None or not getattr(tokenizer, "is_fast", False) or not hasattr(tokenizer, "set_truncation_and_padding"):
+            return None
+        tokenizer.set_truncation_and_padding(padding_strategy=PaddingStrategy.LONGEST, truncation_strategy=TruncationStrategy.LONGEST_FIRST,
+                                             max_length=max_len, stride=0, pad_to_multiple_of=None, padding_side=None)
+        encode = getattr(backend, "encode_batch_fast", None) or backend.encode_batch  # (_fast: no offsets, the fields used here are the same)
+        encs = encode(list(texts), add_special_tokens=True)
+        names = list(getattr(tokenizer, "model_input_names", ["input_ids", "token_type_ids", "attention_mask"]))
+        out = {}
+        if "input_ids" in names or True:
+            out["input_ids"] = torch.from_numpy(np.array([e.ids for e in encs], dtype=np.int64))
+        if "token_type_ids" in names:
+            out["token_type_ids"] = torch.from_numpy(np.array([e.type_ids for e in encs], dtype=np.int64))
+        if "attention_mask" in names:
+            out["attention_mask"] = torch.from_numpy(np.array([e.attention_mask for e in encs], dtype=np.int64))
+        return BatchEncoding(out)
+    except Exception:
+        return None
+
+
 class Dense(Retriever):
     """Bi-encoder: tokenizer + transformer encoder + pooler; fp16 embeddings [B, d].
 
@@ -180,6 +214,9 @@ class Dense(Retriever):
         is_query = query_or_doc == "query"
         prefix = self.prompt_q if is_query else self.prompt_d if query_or_doc == "doc" else ""
         texts = [prefix + row['generated_query' if is_query else "content"] for row in batch]
+        fast = fast_tokenize(self.tokenizer, texts, self.max_len)
+        if fast is not None:
+            return fast
         return self.tokenizer(texts, padding="longest", truncation="longest_first", max_length=self.max_len, return_tensors='pt')
 
     def similarity_fn(self, q, d):

@@ -58,7 +58,8 @@ def _prepare(x):
 class FlatIndex:
     """n_rows x dim fp16 index resident on one MI355X.  metric: 'ip' | 'cos'."""
 
-    MAX_K = 248  # candidate lists of 64 / 128 / 256 entries with a margin of 8 (csrc/index.hip: pick_kp)
+    MAX_K = 4096  # k <= 248: one fused search (candidate lists of 64 / 128 / 256 entries with a margin of 8, csrc/index.hip:
+    #               pick_kp); larger k: the corpus is searched range by range and the lists merged (csrc/index.hip: search_large_k)
 
     def __init__(self, n_rows, dim, metric="ip", device=0):
         self._h = None

@@ -66,8 +66,12 @@ class Splade(Retriever):
 
     def collate_fn(self, batch, query_or_doc=None):
         field = 'generated_query' if query_or_doc == "query" else "content"
-        return self.tokenizer([row[field] for row in batch], padding=True, truncation=True, max_length=self.max_len,
-                              return_tensors='pt')
+        texts = [row[field] for row in batch]
+        from .dense import fast_tokenize  # (padding=True / truncation=True are "longest" / "longest_first": the Dense call)
+        fast = fast_tokenize(self.tokenizer, texts, self.max_len)
+        if fast is not None:
+            return fast
+        return self.tokenizer(texts, padding=True, truncation=True, max_length=self.max_len, return_tensors='pt')
 
     def similarity_fn(self, q, d):
         """API compatibility only (materialises [Bq, n]); bergen_amd.Retrieve searches with the CSR kernel."""

@@ -253,7 +253,7 @@ def test_error_behaviour_matches_reference(amd):
     ix.upload(x[60:])
     ix.finalize()
     with pytest.raises(Exception):
-        ix.search(np.zeros((1, 64), np.float16), 500)   # k > 248 unsupported
+        ix.search(np.zeros((1, 64), np.float16), 5000)   # k > 4096 unsupported
     s, i = ix.search(np.zeros((0, 64), np.float16), 5)
     assert s.shape == (0, 5)
     ix.close()
@@ -513,6 +513,36 @@ def test_fall_back_filter_pass_is_exact_for_every_query(amd, n, d, nq, k):
     finally:
         _lib.set_option("certificate_error_scale", 1)
         ix.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k,cluster", [(50_000, 768, 40, 300, 0), (30_000, 384, 9, 1000, 0), (20_000, 128, 5, 2500, 0),
+                                              (40_000, 768, 7, 600, 700), (900, 64, 3, 1000, 0), (5_000, 1024, 130, 249, 0)])
+def test_large_k_is_searched_range_by_range(amd, n, d, nq, k, cluster):
+    """k > 248 (the reference accepts any top_k_documents, modules/retrieve.py:157): the corpus is cut into row ranges, every
+    range gives its exact top 248, the lists are merged, and a range that may have dropped a member of the top k is split and
+    searched again (index.hip: search_large_k).  `cluster` consecutive copies of a row that scores at the very top of query 0
+    put far more than 248 of its top k into ONE range: the split path must still return the oracle's list, ties by row index.
+    Also k larger than the corpus (short lists padded with -inf / -1), host and device entry points."""
+    import torch
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    if cluster:
+        x[n // 3: n // 3 + cluster] = (q[0].astype(np.float32) * 0.5).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, min(k, n))
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    s, i = ix.search(q, k, id_offset=7)
+    c = ix.counters()
+    assert c["n_passes"] >= 2 and c["scan_ms"] > 0
+    kk = min(k, n)
+    compare.assert_bit_exact(s[:, :kk], i[:, :kk] - 7, ws, wi, f"large k={k} n={n} d={d}")
+    if k > n:
+        assert (i[:, n:] == -1).all() and np.isneginf(s[:, n:]).all()
+    sd, idd = ix.search(torch.from_numpy(q).cuda(), k)
+    compare.assert_bit_exact(sd.cpu().numpy()[:, :kk], idd.cpu().numpy()[:, :kk], ws, wi, "large k, device path")
+    ix.close()
 
 
 @pytest.mark.parametrize("nq", [1, 21, 128, 129, 256 + 21, 256 + 128, 256 + 129, 2 * 256 + 100])

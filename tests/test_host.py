@@ -162,6 +162,25 @@ def test_threaded_tokenisation_writes_the_same_index(tmp_path, world):
         Retrieve(init_args=_FakeDense(), loader="fibres")
 
 
+def test_fast_tokenize_equals_the_hf_call():
+    """Dense.collate_fn reads the padded ids / type ids / mask straight from the Rust tokenizer's Encodings instead of going
+    through HF's Python post-processing (dense.fast_tokenize): the BatchEncoding must equal the reference's call
+    `tokenizer(texts, padding="longest", truncation="longest_first", max_length=..., return_tensors='pt')` (dense.py:57) —
+    keys, order, dtypes, values — with truncation, an empty string, non-ASCII text and a one-text batch."""
+    from bergen_amd.dense import fast_tokenize
+    from tests import ut1_fixture
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ut1.npz"))
+    tok, _ = ut1_fixture.tokenizer_for([str(w) for w in z["words"]])
+    texts = [str(t) for t in z["doc_texts"][:40]] + ["", "x", "caf\u00e9 na\u00efve \u4e2d\u6587 text", "the " * 400]
+    for batch, max_len in ((texts, 16), (texts, 128), (texts[:1], 128), (texts[40:41], 8)):
+        want = tok(batch, padding="longest", truncation="longest_first", max_length=max_len, return_tensors="pt")
+        got = fast_tokenize(tok, batch, max_len)
+        assert got is not None and list(got.keys()) == list(want.keys())
+        for k in want.keys():
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), (k, max_len)
+    assert fast_tokenize(object(), texts, 16) is None  # not a fast tokenizer: the caller falls back to the HF call
+
+
 def test_retrieve_defaults_match_reference_signature():
     import inspect
     sig = inspect.signature(Retrieve.__init__)
@@ -467,10 +486,10 @@ def test_k_is_validated_before_the_index_is_built(tmp_path):
     r = Retrieve(init_args=_FakeDense(), batch_size=8, num_workers=0)
     built = []
     r._resident_index = lambda *a, **k: built.append(1)
-    with pytest.raises(ValueError, match=r"top_k_documents=300 outside 1\.\.248"):
-        r.retrieve(ds, str(tmp_path / "q"), str(tmp_path / "d"), 300)
+    with pytest.raises(ValueError, match=r"top_k_documents=5000 outside 1\.\.4096"):
+        r.retrieve(ds, str(tmp_path / "q"), str(tmp_path / "d"), 5000)
     assert not built
-    assert bergen_amd.FlatIndex.MAX_K == 248 and bergen_amd.SparseIndex.MAX_K == 120
+    assert bergen_amd.FlatIndex.MAX_K == 4096 and bergen_amd.SparseIndex.MAX_K == 120
 
 
 def test_prefetched_keeps_order_and_forwards_errors():
