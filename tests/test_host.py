@@ -391,9 +391,11 @@ def test_unsupported_encoders_are_reported_not_silent(caplog):
     from types import SimpleNamespace
     from bergen_amd.dense import _native_encoder, _warned
     from bergen_amd.encoder import BertEncoder
-    cfg = SimpleNamespace(model_type="deberta-v2", _name_or_path="naver/trecdl22-crossencoder-debertav3")
+    cfg = SimpleNamespace(model_type="new", _name_or_path="Alibaba-NLP/gte-base-en-v1.5")  # rotary + GLU (config/retriever/gte-base-en-v1.5.yaml)
     model = SimpleNamespace(config=cfg)
-    assert BertEncoder.unsupported_reason(model).startswith("model_type 'deberta-v2'")
+    assert BertEncoder.unsupported_reason(model).startswith("model_type 'new'")
+    # a DeBERTa-v2 checkpoint outside deberta-v3's configuration (no relative attention) is refused with the reason
+    assert "relative_attention is off" in BertEncoder.unsupported_reason(SimpleNamespace(config=SimpleNamespace(model_type="deberta-v2")))
     relu = SimpleNamespace(config=SimpleNamespace(model_type="bert", hidden_act="relu", hidden_size=768, num_attention_heads=12,
                                                   num_hidden_layers=2, intermediate_size=3072, vocab_size=100,
                                                   max_position_embeddings=64, type_vocab_size=2))
@@ -403,13 +405,13 @@ def test_unsupported_encoders_are_reported_not_silent(caplog):
         assert _native_encoder(model) is model
         assert _native_encoder(model) is model
     msgs = [r.getMessage() for r in caplog.records if "stays on the HF torch implementation" in r.getMessage()]
-    assert len(msgs) == 1 and "crossencoder-debertav3" in msgs[0]
+    assert len(msgs) == 1 and "gte-base-en-v1.5" in msgs[0]
 
 
 def test_reference_model_families_resolve_to_the_hip_forward_pass():
     """Architectures of the reference's shipped retriever / reranker configs that the kernels cover: BERT with 64- and
     32-dim heads (e5-small-v2.yaml:3, bge-small-en-v1.5.yaml:3, reranker/minilm6.yaml:3), DistilBERT (tasb.yaml:3),
-    XLM-R (bge-m3.yaml:3).  DeBERTa-v3 (reranker/debertav3.yaml:3) is not one of them."""
+    XLM-R (bge-m3.yaml:3), DeBERTa-v3 (reranker/debertav3.yaml:3: disentangled attention, deberta-v3-large's shape)."""
     from types import SimpleNamespace as NS
     from bergen_amd.encoder import BertEncoder, canonical_config
     bert = dict(hidden_act="gelu", num_hidden_layers=2, intermediate_size=1536, vocab_size=100, max_position_embeddings=64, type_vocab_size=2)
@@ -423,7 +425,12 @@ def test_reference_model_families_resolve_to_the_hip_forward_pass():
                                intermediate_size=4096, hidden_act="gelu", vocab_size=250002, max_position_embeddings=8194,
                                type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5))
     assert xlmr["position_offset"] == 2 and xlmr["layer_norm_eps"] == 1e-5
-    assert not BertEncoder.supports(NS(config=NS(model_type="deberta-v2")))
+    deb = canonical_config(NS(model_type="deberta-v2", hidden_size=1024, num_attention_heads=16, num_hidden_layers=24, intermediate_size=4096,
+                              hidden_act="gelu", vocab_size=128100, max_position_embeddings=512, type_vocab_size=0, layer_norm_eps=1e-7,
+                              relative_attention=True, position_buckets=256, norm_rel_ebd="layer_norm", share_att_key=True,
+                              pos_att_type=["p2c", "c2p"], position_biased_input=False, max_relative_positions=-1))
+    assert (deb["rel_span"], deb["max_relative_positions"], deb["head_dim"], deb["type_vocab_size"]) == (256, 512, 64, 1)
+    assert not BertEncoder.supports(NS(config=NS(model_type="new")))
 
 
 def test_head_padding_keeps_the_attention_arithmetic():
