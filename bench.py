@@ -59,7 +59,10 @@ def parse_args():
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
     p.add_argument("--no-certificate-leg", action="store_true", help="skip the certificate / fall-back leg on the clustered, non-unit-norm corpus")
     p.add_argument("--encode-stage-passages", type=int, default=16384, help="passages of the Retrieve.encode_and_save leg (0 = skip)")
-    p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg (index folders -> doc-id strings)")
+    p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg at the headline size (resident index -> doc-id strings)")
+    p.add_argument("--folder-stage", action="store_true",
+                   help="also run Retrieve.retrieve on a reference-layout folder of --stage-rows documents (first call loads the folder); off by "
+                        "default: its small launches of the headline kernel would blur the kernel's average in a rocprofv3 --stats run")
     p.add_argument("--stage-rows", type=int, default=2_100_000, help="documents of the Retrieve.retrieve-level leg")
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
     p.add_argument("--cpu-sample-queries", type=int, default=1000)
@@ -993,7 +996,7 @@ def run(args, env):
                 out["certificate"] = certificate_leg(args, local_rank, device)
             except Exception as exc:
                 out["certificate"] = {"error": repr(exc)}
-        if world == 1 and not args.no_stage:
+        if world == 1 and args.folder_stage:
             ix.close()
             try:
                 out["retrieve_stage"] = retrieve_stage_leg(args, local_rank)

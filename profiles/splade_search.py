@@ -17,21 +17,35 @@ def main():
     sweep = ("", [None])
     for kv in sys.argv[2:]:
         k_, v_ = kv.split("=")
+        if k_ == "distinct":
+            continue
         if "," in v_:
             sweep = (k_, [int(x) for x in v_.split(",")])  # e.g. sparse_ablate=0,1,4,16 (bench-only kernel ablations)
         else:
             _lib.set_option(k_, int(v_))
     V, block = 30522, 1_000_000
+    dev = torch.device("cuda", 0)
     t0 = time.perf_counter()
-    blk = synth.random_sparse_corpus_device(min(block, docs), V, seed=4, device=torch.device("cuda", 0))
+    # the corpus of bench.py's splade leg: distinct 1 M-document blocks (term sets from 3 independent draws, fresh weights per
+    # block) — or, `distinct=0`, round 2's single block repeated (every document has 20 exact duplicates: flatters the filter)
+    distinct = not any(kv == "distinct=0" for kv in sys.argv[2:])
+    term_sets = [synth.random_sparse_corpus_device(min(block, docs), V, seed=4 + 1000 * j, device=dev) for j in range(3 if distinct else 1)]
     t_gen = time.perf_counter() - t0
     ix = SparseIndex(docs, V, device=0)
-    done = 0
+    done, b = 0, 0
     t0 = time.perf_counter()
     while done < docs:
-        m = min(len(blk[0]) - 1, docs - done)
-        ix.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
+        indptr, terms, w0 = term_sets[b % len(term_sets)]
+        m = min(len(indptr) - 1, docs - done)
+        nnz_b = int(indptr[m])
+        if b < len(term_sets) or not distinct:
+            w = w0[:nnz_b]
+        else:
+            gw = torch.Generator(device=dev).manual_seed(40_000 + b)
+            w = torch.log1p(torch.empty(nnz_b, device=dev).exponential_(1.0, generator=gw)).half().clamp_(min=0.01).cpu().numpy()
+        ix.upload((indptr[:m + 1], terms[:nnz_b], w))
         done += m
+        b += 1
     ix.finalize()
     t_up = time.perf_counter() - t0
     qp, qt, qw = synth.random_sparse_corpus_fast(256, V, seed=5, mean_nnz=24, lo=4, hi=64)

@@ -91,9 +91,11 @@ assert np.array_equal(i, i2.numpy()) and np.array_equal(s.view(np.uint32), s2.nu
 assert set(range(999, 1040)) >= set(i[0, :30].tolist())
 for kk in (1, 57, 248):
     ix.search(q[:130], kk)
+big_s, big_i = ix.search(q[:6], 700)   # k > 248: range-by-range search, host merge, write-back (index.hip: search_large_k)
+assert np.array_equal(big_i[:, :50], i[:6]) and (np.diff(big_s, axis=1) <= 0).all()
 try:
-    ix.search(q[:4], 249)
-    raise SystemExit("k = 249 accepted")
+    ix.search(q[:4], 4097)
+    raise SystemExit("k = 4097 accepted")
 except _lib.BergenHipError:
     pass
 ix.close()
