@@ -9,8 +9,12 @@
 // One 8-wave workgroup per (sequence, head); wave w takes the 32-query blocks w, w+8, ...  The workgroup
 // first stages the sequence's whole K slice (len x 64) and V^T slice (64 x len) of this head into LDS with
 // coalesced loads — K in the XOR-permuted 128-byte-row image of the GEMM (conflict-free ds_read_b128 fragment
-// reads), V^T in 64-byte rows with an 8-byte-chunk XOR (conflict-free ds_read_b64) — one barrier, then every
-// wave runs its key loop out of LDS with no further global loads or barriers.
+// reads), V^T in 64-byte rows with an 8-byte-chunk XOR — one barrier, then every wave runs its key loop out of LDS with
+// no further global loads or barriers.  The XOR term of V^T row dd is (dd >> 1) & 7: hipcc pairs the reads of head dims
+// ql and ql + 32 into ds_read2st64_b64, which the LDS serves in groups of 16 CONTIGUOUS lanes against 32 banks (a 128-byte
+// window: two rows); 16 lanes = 2 row parities x 8 distinct terms.  (Until round 3 the term was (dd >> 2) & 7 — right
+// for a plain ds_read_b64's 32-lane groups and 64 banks, two-way conflicts on the paired read and on the ds_write_b64 of
+// the staging: SQ_LDS_BANK_CONFLICT was 38 % of SQ_LDS_IDX_ACTIVE.)
 //   S^T = K . Q^T          v_mfma_f32_32x32x16_f16, A = K rows (i = key), B = Q rows (j = query):
 //                          lane l owns query l&31 and 16 of the 32 key scores -> the softmax reductions are
 //                          in-lane plus ONE exchange between the two half-lanes of a query.
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
                         lo[e] = vv[u][e];
                         hi[e] = vv[u][4 + e];
                     }
-                    const int g8 = (dd >> 2) & 7;
+                    const int g8 = (dd >> 1) & 7;
                     unsigned char* vb = smV + kbi * 4096 + dd * 64;
                     *reinterpret_cast<half4*>(vb + (((2 * c16) ^ g8) << 3)) = lo;
                     *reinterpret_cast<half4*>(vb + (((2 * c16 + 1) ^ g8) << 3)) = hi;
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
     __syncthreads();
     const float c = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
-    // LDS fragment offsets: K as the conflict-free ds_read_b128 pattern, V^T as conflict-free ds_read_b64
+    // LDS fragment offsets: K as the conflict-free ds_read_b128 pattern, V^T conflict-free for ds_read2st64_b64 (see the header)
     unsigned k_off[4];
     {
         const int g = ((ql >> 1) & 1) | ((ql >> 3) << 1);
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
     }
     unsigned v_off[2][2];  // [s2][lo|hi] for head dim ql; head dim 32 + ql sits 2048 bytes further (same XOR term)
     {
-        const int g8 = (ql >> 2) & 7;
+        const int g8 = (ql >> 1) & 7;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int c8 = 4 * s2 + h;  // keys 16 s2 + 4 h + 0..3; the second half of the fragment sits 8 keys later

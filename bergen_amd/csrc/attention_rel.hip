@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
                 lo[e] = vv[e];
                 hi[e] = vv[4 + e];
             }
-            const int g8 = (dd >> 2) & 7;
+            const int g8 = (dd >> 1) & 7;
             unsigned char* vbl = smV + kbi * 4096 + dd * 64;
             *reinterpret_cast<half4*>(vbl + (((2 * c16) ^ g8) << 3)) = lo;
             *reinterpret_cast<half4*>(vbl + (((2 * c16 + 1) ^ g8) << 3)) = hi;
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
     }
     unsigned v_off[2][2];
     {
-        const int g8 = (ql >> 2) & 7;
+        const int g8 = (ql >> 1) & 7;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int c8 = 4 * s2 + h;
