@@ -1,0 +1,180 @@
+"""Board power and shader clock while the hot kernels run (run on the GPU box):  python profiles/power_clock.py [seconds_per_leg]
+
+Is the dense scan (and the encoder GEMM) limited by its schedule or by the chip's power management?  The 2.5 PFLOP/s MFMA
+peak and the guide's per-CU rates assume ~2.4 GHz; under sustained MFMA + HBM load the chip lowers the shader clock to stay
+inside its power limit.  For every leg this samples, every 50 ms from a side thread while the leg loops on the GPU:
+  * socket power (hwmon power1_average / power1_input, or `amd-smi metric -p`), the power cap (power1_cap),
+  * shader clock as the driver reports it (hwmon freq1_input, or pp_dpm_sclk's starred level / amd-smi),
+and takes from the library the clock the scan kernel measured ITSELF (cycles per 100 MHz tick over its tile loops,
+bh_counters.shader_mhz).
+Legs: idle; dense scan production / no filter / MFMA + rendezvous only / stream only (bench-only ablations of the 256-query
+kernel: results invalid, timings meaningful); the BERT-base forward pass of bench.py's encoder leg.
+Prints one JSON object."""
+import glob
+import json
+import os
+import statistics
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import bergen_amd  # noqa: E402
+from bergen_amd import _lib  # noqa: E402
+
+
+def _read(path):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
+
+
+class Sampler:
+    """Side thread: (t, watts, sclk MHz) every `period` s from sysfs, falling back to amd-smi (slower: one process per sample)."""
+
+    def __init__(self, period=0.05):
+        self.period = period
+        self.hw = None
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if _read(os.path.join(h, "power1_average")) or _read(os.path.join(h, "power1_input")):
+                self.hw = h
+                break
+        self.dev = os.path.dirname(os.path.dirname(self.hw)) if self.hw else None
+        self.source = "hwmon " + self.hw if self.hw else "amd-smi"
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+
+    def cap_watts(self):
+        v = _read(os.path.join(self.hw, "power1_cap")) if self.hw else None
+        return int(v) / 1e6 if v else None
+
+    def _one(self):
+        if self.hw:
+            p = _read(os.path.join(self.hw, "power1_average")) or _read(os.path.join(self.hw, "power1_input"))
+            f = _read(os.path.join(self.hw, "freq1_input"))
+            mhz = int(f) / 1e6 if f else None
+            if mhz is None:
+                dpm = _read(os.path.join(self.dev, "pp_dpm_sclk")) or ""
+                for line in dpm.splitlines():
+                    if line.endswith("*"):
+                        mhz = float(line.split(":")[1].strip().rstrip("*").strip().lower().rstrip("mhz"))
+            return (int(p) / 1e6 if p else None), mhz
+        try:
+            out = subprocess.run(["amd-smi", "metric", "-g", "0", "-p", "-c", "--json"], capture_output=True, text=True, timeout=5).stdout
+            j = json.loads(out)
+            j = j[0] if isinstance(j, list) else j
+            pw = j.get("power", {}).get("socket_power", {})
+            pw = pw.get("value") if isinstance(pw, dict) else pw
+            clk = j.get("clock", {}).get("gfx_0", {}).get("clk", {})
+            clk = clk.get("value") if isinstance(clk, dict) else clk
+            return (float(pw) if pw not in (None, "N/A") else None), (float(clk) if clk not in (None, "N/A") else None)
+        except Exception:
+            return None, None
+
+    def start(self):
+        self.samples = []
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                w, f = self._one()
+                self.samples.append((time.perf_counter(), w, f))
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self, skip_s=0.5):
+        self._stop.set()
+        self._thread.join()
+        if not self.samples:
+            return {}
+        t0 = self.samples[0][0]
+        ws = [w for t, w, f in self.samples if w is not None and t - t0 >= skip_s]
+        fs = [f for t, w, f in self.samples if f is not None and t - t0 >= skip_s]
+        out = {"samples": len(ws)}
+        if ws:
+            out.update(watts_mean=round(statistics.mean(ws), 1), watts_max=round(max(ws), 1))
+        if fs:
+            out.update(sclk_mhz_mean=round(statistics.mean(fs)), sclk_mhz_min=round(min(fs)), sclk_mhz_max=round(max(fs)))
+        return out
+
+
+def main():
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+    _lib.init(0)
+    dev = torch.device("cuda", 0)
+    smp = Sampler()
+    res = {"sampler": smp.source, "power_cap_watts": smp.cap_watts(), "seconds_per_leg": secs, "legs": {}}
+
+    smp.start()
+    time.sleep(2.0)
+    res["legs"]["idle"] = smp.stop(0.0)
+
+    dim, k, n_total = 768, 50, 21_000_000
+    q = bench.make_queries(2837, dim, dev)
+    ix = bergen_amd.FlatIndex(n_total, dim, metric="ip", device=0)
+    bench.fill_shard(ix, 0, n_total, dim, q, n_total, dev)
+    ix.finalize()
+    q256 = q[:256].contiguous()
+    for name, abl in (("scan_production", 0), ("scan_no_filter", 1), ("scan_mfma_and_rendezvous_only", 11), ("scan_stream_only", 7), ("scan_production_again", 0)):
+        _lib.set_option("ablate", abl)
+        _lib.set_option("certify", 0 if abl else 1)  # (an ablated scan proves nothing: no fall-back passes behind it)
+        ix.search(q256, k)
+        ms, mhz = [], []
+        smp.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            for _ in range(20):
+                ix.search(q256, k)
+                c = ix.counters()
+                ms.append(c["scan_ms"] / c["n_passes"])
+                mhz.append(c["shader_mhz"])
+        leg = smp.stop()
+        leg.update(scan_ms_per_pass_median=round(statistics.median(ms), 4), scan_ms_per_pass_last_quarter=round(statistics.median(ms[-len(ms) // 4:]), 4),
+                   kernel_measured_shader_mhz=round(statistics.median(mhz)), launches=len(ms))
+        res["legs"][name] = leg
+    _lib.set_option("ablate", 0)
+    _lib.set_option("certify", 1)
+    ix.close()
+    del ix
+    torch.cuda.empty_cache()
+
+    # the encoder forward pass of bench.py's leg (BERT-base, 512 passages per step)
+    from bergen_amd import BertEncoder, synth
+    cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = synth.random_bert(cfg, seed=31)
+    enc = BertEncoder(cfg, {k_: torch.from_numpy(v) for k_, v in sd.items()}, device=0)
+    rng = np.random.default_rng(6)
+    lens = np.clip(np.rint(rng.normal(130, 30, size=512)), 16, 256).astype(np.int64)
+    T = int(lens.max())
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    ids = rng.integers(1, cfg["vocab_size"], size=(512, T)).astype(np.int64) * mask
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    enc.encode_pooled(kw, "cls")
+    torch.cuda.synchronize()
+    n = 0
+    smp.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < secs:
+        for _ in range(10):
+            enc.encode_pooled(kw, "cls")
+        torch.cuda.synchronize()
+        n += 10
+    dt = time.perf_counter() - t0
+    leg = smp.stop()
+    leg.update(forward_ms=round(dt / n * 1e3, 3), passages_per_s=round(512 * n / dt))
+    res["legs"]["encoder_forward"] = leg
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
