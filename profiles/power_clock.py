@@ -36,16 +36,33 @@ def _read(path):
         return None
 
 
+def _pci_address(device):
+    """'0000:bb:dd.f' of HIP device `device` (hipDeviceGetPCIBusId), or None."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        return buf.value.decode().lower()
+    except OSError:
+        return None
+
+
 class Sampler:
     """Side thread: (t, watts, sclk MHz) every `period` s from sysfs, falling back to amd-smi (slower: one process per sample)."""
 
     def __init__(self, period=0.05):
         self.period = period
+        # the hwmon node of THIS process's GPU (the box has eight; the HIP device is found by its PCI address)
         self.hw = None
-        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        bdf = _pci_address(0)
+        cands = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")) if bdf else []
+        for h in cands:
             if _read(os.path.join(h, "power1_average")) or _read(os.path.join(h, "power1_input")):
                 self.hw = h
                 break
+        self.pci = bdf
         self.dev = os.path.dirname(os.path.dirname(self.hw)) if self.hw else None
         self.source = "hwmon " + self.hw if self.hw else "amd-smi"
         self.samples = []
@@ -112,7 +129,7 @@ def main():
     _lib.init(0)
     dev = torch.device("cuda", 0)
     smp = Sampler()
-    res = {"sampler": smp.source, "power_cap_watts": smp.cap_watts(), "seconds_per_leg": secs, "legs": {}}
+    res = {"sampler": smp.source, "pci": smp.pci, "power_cap_watts": smp.cap_watts(), "seconds_per_leg": secs, "legs": {}}
 
     smp.start()
     time.sleep(2.0)
@@ -124,7 +141,8 @@ def main():
     bench.fill_shard(ix, 0, n_total, dim, q, n_total, dev)
     ix.finalize()
     q256 = q[:256].contiguous()
-    for name, abl in (("scan_production", 0), ("scan_no_filter", 1), ("scan_mfma_and_rendezvous_only", 11), ("scan_stream_only", 7), ("scan_production_again", 0)):
+    for name, abl in (("scan_production", 0), ("scan_no_filter", 1), ("scan_no_filter_no_lds_reads", 3), ("scan_no_filter_no_refill", 9),
+                      ("scan_mfma_and_rendezvous_only", 11), ("scan_stream_only", 7), ("scan_production_again", 0)):
         _lib.set_option("ablate", abl)
         _lib.set_option("certify", 0 if abl else 1)  # (an ablated scan proves nothing: no fall-back passes behind it)
         ix.search(q256, k)
@@ -143,6 +161,22 @@ def main():
         res["legs"][name] = leg
     _lib.set_option("ablate", 0)
     _lib.set_option("certify", 1)
+    for name, sk, nq in (("scan192_production", 2, 192), ("scan128_production", 0, 128)):
+        _lib.set_option("scan_kernel", sk)
+        qn = q[:nq].contiguous()
+        ix.search(qn, k)
+        ms = []
+        smp.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            for _ in range(20):
+                ix.search(qn, k)
+                c = ix.counters()
+                ms.append(c["scan_ms"] / c["n_passes"])
+        leg = smp.stop()
+        leg.update(scan_ms_per_pass_median=round(statistics.median(ms), 4), queries_per_pass=nq, launches=len(ms))
+        res["legs"][name] = leg
+    _lib.set_option("scan_kernel", 3)
     ix.close()
     del ix
     torch.cuda.empty_cache()
