@@ -67,6 +67,7 @@ def parse_args():
     p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
     p.add_argument("--cpu-sample-queries", type=int, default=1000)
     p.add_argument("--no-encoder", action="store_true", help="skip the passages-encoded/s leg")
+    p.add_argument("--no-power-leg", action="store_true", help="skip the board power / shader clock sampling behind the timed region")
     p.add_argument("--enc-batch", type=int, default=512, help="sequences per encoder step (retromae.yaml batch_size)")
     p.add_argument("--enc-steps", type=int, default=3)
     p.add_argument("--no-splade", action="store_true", help="skip the SPLADE legs (configs[3]: MLM-head encode, sparse search)")
@@ -716,6 +717,109 @@ def certificate_leg(args, local_rank, device):
             "full_lists_of_8_queries_bit_exact_vs_float64_gemm": full_ok, "parity_check": "pass" if ok else "FAIL"}
 
 
+def _read(path):
+    try:
+        return open(path).read().strip()
+    except OSError:
+        return None
+
+
+def _pci_address(device):
+    """'0000:bb:dd.f' of HIP device `device` (hipDeviceGetPCIBusId), or None."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        return buf.value.decode().lower()
+    except OSError:
+        return None
+
+
+class PowerSampler:
+    """Side thread: (t, socket watts, shader clock MHz) of THIS process's GPU every `period` s from its hwmon node in sysfs,
+    falling back to amd-smi (slower: one process per sample).  Why bench.py cares: the headline scan runs AT the board's
+    power cap (1 400 W) with the shader clock pulled down to ~1.5 GHz (profiles/r03_power_clock.json) — the time of a pass is
+    set by the energy it takes, which a roofline of HBM bytes or MFMA flops alone does not show."""
+
+    def __init__(self, period=0.05):
+        import glob
+        import threading
+        self.period = period
+        # the hwmon node of THIS process's GPU (the box has eight; the HIP device is found by its PCI address)
+        self.hw = None
+        bdf = _pci_address(0)
+        cands = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")) if bdf else []
+        for h in cands:
+            if _read(os.path.join(h, "power1_average")) or _read(os.path.join(h, "power1_input")):
+                self.hw = h
+                break
+        self.pci = bdf
+        self.dev = os.path.dirname(os.path.dirname(self.hw)) if self.hw else None
+        self.source = "hwmon " + self.hw if self.hw else "amd-smi"
+        self.samples = []
+        self._threading = threading
+        self._stop = threading.Event()
+        self._thread = None
+
+    def cap_watts(self):
+        v = _read(os.path.join(self.hw, "power1_cap")) if self.hw else None
+        return int(v) / 1e6 if v else None
+
+    def _one(self):
+        if self.hw:
+            p = _read(os.path.join(self.hw, "power1_average")) or _read(os.path.join(self.hw, "power1_input"))
+            f = _read(os.path.join(self.hw, "freq1_input"))
+            mhz = int(f) / 1e6 if f else None
+            if mhz is None:
+                dpm = _read(os.path.join(self.dev, "pp_dpm_sclk")) or ""
+                for line in dpm.splitlines():
+                    if line.endswith("*"):
+                        mhz = float(line.split(":")[1].strip().rstrip("*").strip().lower().rstrip("mhz"))
+            return (int(p) / 1e6 if p else None), mhz
+        try:
+            import subprocess
+            out = subprocess.run(["amd-smi", "metric", "-g", "0", "-p", "-c", "--json"], capture_output=True, text=True, timeout=5).stdout
+            j = json.loads(out)
+            j = j[0] if isinstance(j, list) else j
+            pw = j.get("power", {}).get("socket_power", {})
+            pw = pw.get("value") if isinstance(pw, dict) else pw
+            clk = j.get("clock", {}).get("gfx_0", {}).get("clk", {})
+            clk = clk.get("value") if isinstance(clk, dict) else clk
+            return (float(pw) if pw not in (None, "N/A") else None), (float(clk) if clk not in (None, "N/A") else None)
+        except Exception:
+            return None, None
+
+    def start(self):
+        self.samples = []
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                w, f = self._one()
+                self.samples.append((time.perf_counter(), w, f))
+                self._stop.wait(self.period)
+        self._thread = self._threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self, skip_s=0.5):
+        self._stop.set()
+        self._thread.join()
+        if not self.samples:
+            return {}
+        import statistics
+        t0 = self.samples[0][0]
+        ws = [w for t, w, f in self.samples if w is not None and t - t0 >= skip_s]
+        fs = [f for t, w, f in self.samples if f is not None and t - t0 >= skip_s]
+        out = {"samples": len(ws)}
+        if ws:
+            out.update(watts_mean=round(statistics.mean(ws), 1), watts_max=round(max(ws), 1))
+        if fs:
+            out.update(sclk_mhz_mean=round(statistics.mean(fs)), sclk_mhz_min=round(min(fs)), sclk_mhz_max=round(max(fs)))
+        return out
+
+
 def scan_kernel_name(query_tile):
     """Kernel that serves a query tile of this width (bergen_amd/csrc/index.hip)."""
     return {256: "bh_scan_topk256_kernel", 192: "bh_scan_topk192_kernel"}.get(query_tile, "bh_scan_topk_kernel")
@@ -863,6 +967,24 @@ def run(args, env):
         elapsed = float(t.item())
     c = ix.counters()
 
+    # ---- board power and shader clock under the headline load (rank 0's GPU, N = 1; outside the timed region): the same
+    # step repeated for ~1.5 s with the hwmon node of this GPU sampled from a side thread
+    power = None
+    if rank == 0 and world == 1 and not args.no_power_leg:
+        try:
+            smp = PowerSampler()
+            smp.start()
+            t_p = time.perf_counter()
+            n_p = 0
+            while time.perf_counter() - t_p < 1.5:
+                step()
+                n_p += 1
+            power = smp.stop(skip_s=0.4)
+            power.update(cap_watts=smp.cap_watts(), source=smp.source, steps=n_p,
+                         what="socket power / shader clock while the headline step repeats (after the timed region)")
+        except Exception as e:  # (no readable sensor in this container: the leg reports that, the bench line stands)
+            power = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- parity gate (rank 0): planted positives on top + canonical scores of returned ids -------
     parity = "skipped"
     full_list_gate = None
@@ -937,6 +1059,8 @@ def run(args, env):
                 "mfma_tflops": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12,
                 "mfma_frac": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                 "shader_mhz": c.get("shader_mhz", 0.0),
+                # the launch is power-bound before it is HBM- or MFMA-bound: see PowerSampler
+                "power": power,
                 "tail_pass": ({"kernel": "bh_scan_topk_kernel", "query_tile": 128, "avg_launch_ms": tail_ms / args.steps,
                                "what": "the last pass of a step (<= 128 queries left) runs on the 128-query kernel"} if has_tail else None),
             },

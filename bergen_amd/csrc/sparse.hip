@@ -11,6 +11,7 @@
 // There is no CPU fallback: every entry point that computes needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,7 @@ int g_sparse_head = 1;    // 1 = the MFMA scan reads the corpus-head tiles + tai
 
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kTileQ = 64;
+constexpr int kSparseListK = 120;  // largest k of ONE fused sparse search (candidate lists of 128 with a margin of 8)
 
 int grow_entries(bh_sparse_index* ix, size_t need) {
     if (need <= ix->entries.cap) return BH_OK;
@@ -282,8 +284,12 @@ int bh_sparse_finalize(bh_sparse_index* ix) {
     return BH_OK;
 }
 
-int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
-                     float* out_scores, int64_t* out_ids) {
+// One fused search over a VIEW of the corpus: documents [view_lo, view_lo + view_rows) (view_lo a multiple of 32, the scan's
+// document group), k <= kSparseListK.  Row ids inside the kernels are relative to the view (the row-pointer arrays are
+// passed from view_lo on, entry offsets stay absolute; the corpus-head tile of group g sits HD * g dwords into the tail
+// stream, so that stream is passed from the view's first group on): the caller folds view_lo into id_offset.
+static int sparse_search_view(bh_sparse_index* ix, int64_t view_lo, int64_t view_rows, const void* q_host, int32_t q_dtype, int32_t nq,
+                              int32_t k, int64_t id_offset, float* out_scores, int64_t* out_ids) {
     if (!ix) return bh_fail(BH_EINVAL, "null index");
     if (!ix->finalized) {
         if (ix->rows_have != ix->n_rows)
@@ -295,8 +301,14 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     if (nq < 0 || k <= 0) return bh_fail(BH_EINVAL, "nq=%d k=%d", nq, k);
     if (q_dtype != BH_F16 && q_dtype != BH_F32) return bh_fail(BH_EINVAL, "bad q_dtype %d", q_dtype);
     const int kp = pick_kp_sparse(k);
-    if (kp < 0) return bh_fail(BH_EUNSUPPORTED, "k=%d unsupported for sparse search (max 120)", k);
+    if (kp < 0) return bh_fail(BH_EUNSUPPORTED, "k=%d unsupported for one fused sparse search (max %d)", k, kSparseListK);
     if (nq == 0) return BH_OK;
+    if (view_lo < 0 || (view_lo & 31) != 0 || view_rows < 0 || view_lo + view_rows > ix->n_rows)
+        return bh_fail(BH_EINVAL, "internal: bad document view [%lld, +%lld)", (long long)view_lo, (long long)view_rows);
+    const long long* const rp_v = ix->row_ptr.p + view_lo;
+    const long long* const rp2_v = ix->row_ptr2.p ? ix->row_ptr2.p + view_lo : nullptr;
+    const unsigned* const stream2_v = ix->stream2.p ? ix->stream2.p + (size_t)BH_CSR_HEAD_DWORDS * (size_t)(view_lo / 32) : nullptr;
+    const int64_t n_rows_v = view_rows;
     if (!q_host || !out_scores || !out_ids) return bh_fail(BH_EINVAL, "null buffer");
     BH_HIP_TRY(hipSetDevice(ix->device));
     // Internally the vocabulary is the caller's shifted by one: stored id = term + 1, id 0 never occurs in a document or a
@@ -433,7 +445,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     };
     bh_counters& c = ix->counters;
     c = bh_counters{};
-    c.n_rows = ix->n_rows;
+    c.n_rows = n_rows_v;
     c.dim = Vu;
     c.dim_padded = Vu;
     c.n_workgroups = grid;
@@ -490,8 +502,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             BH_HIP_TRY(hipMemcpyAsync(ix->W.p, Wh.data(), (size_t)(n_slots + 1) * 128, hipMemcpyHostToDevice, st));
             BhCsrScanArgs sa{};
             sa.entries = ix->entries.p;
-            sa.row_ptr = ix->row_ptr.p;
-            sa.n_rows = ix->n_rows;
+            sa.row_ptr = rp_v;
+            sa.n_rows = n_rows_v;
             sa.bitmap = ix->bitmap.p;
             sa.prefix = ix->prefix.p;
             sa.W = ix->W.p;
@@ -553,7 +565,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             BH_HIP_TRY(hipMemcpyAsync(ix->WhT.p, WhT_h.data(), 64 * 64 * 2, hipMemcpyHostToDevice, st));
             BhCsrMfmaArgs ma2{};
             ma2.entries = ix->entries.p;
-            ma2.row_ptr = ix->row_ptr.p;
+            ma2.row_ptr = rp_v;
             if (use_head) {
                 auto& WgT_h = WgT_s[par];
                 std::fill(WgT_h.begin(), WgT_h.end(), (unsigned short)0);
@@ -564,12 +576,12 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
                     }
                 _Float16* wg_dev = ix->WgT.p + (size_t)par * 64 * 64;
                 BH_HIP_TRY(hipMemcpyAsync(wg_dev, WgT_h.data(), 64 * 64 * 2, hipMemcpyHostToDevice, st));
-                ma2.entries = ix->stream2.p;
-                ma2.row_ptr = ix->row_ptr2.p;
+                ma2.entries = stream2_v;
+                ma2.row_ptr = rp2_v;
                 ma2.WgT = wg_dev;
                 ma2.head_dwords = BH_CSR_HEAD_DWORDS;
             }
-            ma2.n_rows = ix->n_rows;
+            ma2.n_rows = n_rows_v;
             ma2.bitmap = ix->bitmap.p;
             ma2.prefix = ix->prefix.p;
             ma2.sinfo = ix->sinfo.p;
@@ -611,7 +623,7 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             // slot table (its candidate lists are overwritten by the main launch, which scans the prefix again).
             // 64 workgroups: one per slot of the table (a slot nobody wrote leaves the bound open)
             const long long pre_rows = 64LL * 8 * 2 * 32;  // 64 workgroups x 8 waves x 2 groups
-            if (ix->n_rows > 4 * pre_rows && grid >= 64) {
+            if (n_rows_v > 4 * pre_rows && grid >= 64) {
                 BhCsrMfmaArgs pre = ma2;
                 pre.n_rows = pre_rows;
                 pre.skip_final = 1;
@@ -625,8 +637,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
         ma.partial = ix->partial.p + (size_t)par * partial_elems;
         ma.n_lists = grid;
         ma.entries = ix->entries.p;
-        ma.row_ptr = ix->row_ptr.p;
-        ma.n_rows = ix->n_rows;
+        ma.row_ptr = rp_v;
+        ma.n_rows = n_rows_v;
         ma.q_dense = ix->qdense.p + (size_t)q0 * V;
         ma.vocab = V;
         ma.k = k;
@@ -651,7 +663,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
             }
         }
         // nnz*(2+2) + (N+1)*8 per query-tile pass (+ the tile's results)
-        bytes += (double)ix->nnz * 4.0 + (double)(ix->n_rows + 1) * 8.0 + (double)nt * k * 12.0;
+        // (a view's share of the entries is taken as proportional to its documents: the exact count is on the device)
+        bytes += (double)ix->nnz * 4.0 * ((double)n_rows_v / (double)std::max<int64_t>(1, ix->n_rows)) + (double)(n_rows_v + 1) * 8.0 + (double)nt * k * 12.0;
         ++n_pass;
         q0 += nt;
     }
@@ -666,6 +679,115 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     c.total_ms = scan_ms + merge_ms;
     c.algorithmic_bytes = bytes;
     return BH_OK;
+}
+
+// k > 120 (the reference accepts any top_k_documents, modules/retrieve.py:157): as for the dense index (index.hip,
+// search_large_k) the corpus is cut into contiguous RANGES of 32-document groups small enough that a range is expected to
+// hold ~50 of the top k, every range is searched for its exact top 120 by the ordinary fused search over a view, and the
+// ranges' lists are merged in canonical order (score descending, row ascending).  Exact iff no range holds more than 120 of
+// the true top k — CHECKED: a range whose list came back full and whose last entry still belongs to the merged top k may
+// have dropped a row; it is split in four and searched again, down to single groups (32 documents cannot fill 120 slots).
+// Non-negative data: a range's list continues with its lowest zero-score rows, so a query with fewer than k matching
+// documents drills into the FIRST ranges until the lowest absent rows of the whole corpus are all listed.
+static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                                 float* out_scores, int64_t* out_ids) {
+    constexpr int KK = kSparseListK;
+    struct Range {
+        int64_t g0, g1;  // 32-document groups [g0, g1)
+        std::vector<float> s;
+        std::vector<long long> i;
+    };
+    const int64_t n_rows = ix->n_rows, n_groups = (n_rows + 31) / 32;
+    bh_counters total{};
+    auto search_range = [&](Range& r) -> int {
+        const int64_t lo = r.g0 * 32, hi = std::min<int64_t>(n_rows, r.g1 * 32);
+        r.s.assign((size_t)nq * KK, -INFINITY);
+        r.i.assign((size_t)nq * KK, -1);
+        const int rc = sparse_search_view(ix, lo, hi - lo, q_host, q_dtype, nq, KK, id_offset + lo, r.s.data(), reinterpret_cast<int64_t*>(r.i.data()));
+        if (rc != BH_OK) return rc;
+        const bh_counters& c = ix->counters;
+        total.scan_ms += c.scan_ms;
+        total.merge_ms += c.merge_ms;
+        total.total_ms += c.total_ms;
+        total.algorithmic_bytes += c.algorithmic_bytes;
+        total.n_passes += c.n_passes;
+        total.n_workgroups = c.n_workgroups;
+        total.k_padded = c.k_padded;
+        total.query_tile = c.query_tile;
+        total.dim = c.dim;
+        total.dim_padded = c.dim_padded;
+        return BH_OK;
+    };
+    std::vector<Range> ranges;
+    {
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>(n_groups, (k + 49) / 50));
+        const int64_t per = (n_groups + want - 1) / want;
+        for (int64_t g = 0; g < n_groups; g += per) ranges.push_back(Range{g, std::min(n_groups, g + per), {}, {}});
+    }
+    int rc = BH_OK;
+    for (auto& r : ranges)
+        if ((rc = search_range(r)) != BH_OK) return rc;
+    struct Ent {
+        float s;
+        long long id;
+    };
+    std::vector<Ent> all;
+    for (int round = 0; round < 64; ++round) {
+        std::vector<char> overflow(ranges.size(), 0);
+        bool any = false;
+        for (int q = 0; q < nq; ++q) {
+            all.clear();
+            for (auto& r : ranges)
+                for (int t = 0; t < KK; ++t) {
+                    const long long id = r.i[(size_t)q * KK + t];
+                    if (id >= 0) all.push_back(Ent{r.s[(size_t)q * KK + t], id});
+                }
+            std::sort(all.begin(), all.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s > b.s : a.id < b.id; });
+            const size_t take = std::min<size_t>(all.size(), (size_t)k);
+            for (size_t t = 0; t < (size_t)k; ++t) {
+                out_scores[(size_t)q * k + t] = t < take ? all[t].s : -INFINITY;
+                out_ids[(size_t)q * k + t] = t < take ? all[t].id : -1;
+            }
+            for (size_t j = 0; j < ranges.size(); ++j) {
+                const long long last_id = ranges[j].i[(size_t)q * KK + KK - 1];
+                if (last_id < 0) continue;  // not full: the list holds every document of the range that can matter
+                const float last_s = ranges[j].s[(size_t)q * KK + KK - 1];
+                const bool last_in_topk = take < (size_t)k || last_s > all[take - 1].s || (last_s == all[take - 1].s && last_id <= all[take - 1].id);
+                if (last_in_topk && ranges[j].g1 - ranges[j].g0 > 1) {
+                    overflow[j] = 1;
+                    any = true;
+                }
+            }
+        }
+        if (!any) break;
+        std::vector<Range> next;
+        for (size_t j = 0; j < ranges.size(); ++j) {
+            if (!overflow[j]) {
+                next.push_back(std::move(ranges[j]));
+                continue;
+            }
+            const int64_t span = ranges[j].g1 - ranges[j].g0, per = (span + 3) / 4;
+            for (int64_t g = ranges[j].g0; g < ranges[j].g1; g += per) {
+                Range r{g, std::min(ranges[j].g1, g + per), {}, {}};
+                if ((rc = search_range(r)) != BH_OK) return rc;
+                next.push_back(std::move(r));
+            }
+        }
+        ranges.swap(next);
+    }
+    total.n_rows = n_rows;
+    ix->counters = total;
+    return BH_OK;
+}
+
+int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
+                     float* out_scores, int64_t* out_ids) {
+    if (!ix) return bh_fail(BH_EINVAL, "null index");
+    if (k > BH_MAX_K) return bh_fail(BH_EUNSUPPORTED, "k=%d unsupported for sparse search (max %d)", k, BH_MAX_K);
+    const bool valid = ix->finalized && nq > 0 && (q_dtype == BH_F16 || q_dtype == BH_F32) && q_host && out_scores && out_ids;
+    if (k > kSparseListK && valid) return sparse_search_large_k(ix, q_host, q_dtype, nq, k, id_offset, out_scores, out_ids);
+    // (k <= 120, or a call the view search rejects / answers trivially — incomplete index, bad arguments, nq = 0 — in the usual order)
+    return sparse_search_view(ix, 0, ix->n_rows, q_host, q_dtype, nq, std::min<int32_t>(k, kSparseListK), id_offset, out_scores, out_ids);
 }
 
 int bh_sparse_counters(const bh_sparse_index* ix, bh_counters* out) {

@@ -63,7 +63,8 @@ def _csr_from_any(rows, vocab):
 class SparseIndex:
     """n_rows documents x vocab terms (<= 65535), fp16 weights, resident on one MI355X."""
 
-    MAX_K = 120  # candidate lists of 64 / 128 entries with a margin of 8 (csrc/sparse.hip: pick_kp_sparse)
+    MAX_K = 4096  # k <= 120: one fused search (candidate lists of 64 / 128 entries with a margin of 8, csrc/sparse.hip:
+    #               pick_kp_sparse); above that the documents are searched range by range (sparse_search_large_k)
 
     def __init__(self, n_rows, vocab, device=0):
         self._h = None

@@ -282,7 +282,8 @@ int64_t bh_sparse_nnz(const bh_sparse_index* ix);
  * `load_embeddings(...).to_dense()`, retrieve.py:75-76): for each query the k documents with
  * the largest sparse dot product, canonical order (score desc, row asc).  Canonical score =
  * fp32(RNE) of the fp64 sum over the document's terms, in increasing term id, of
- * q[term] * weight (both as fp16 values).  k <= 120.  Replaces Splade.similarity_fn
+ * q[term] * weight (both as fp16 values).  k <= 4096 (k <= 120: one fused search; above that the
+ * documents are searched range by range and the ranges' exact top-120 lists merged, as for the dense index).  Replaces Splade.similarity_fn
  * (models/retrievers/splade.py:55-56) + torch.topk + host merge (retrieve.py:146-185). */
 int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k,
                      int64_t id_offset, float* out_scores, int64_t* out_ids);

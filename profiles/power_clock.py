@@ -10,13 +10,10 @@ bh_counters.shader_mhz).
 Legs: idle; dense scan production / no filter / MFMA + rendezvous only / stream only (bench-only ablations of the 256-query
 kernel: results invalid, timings meaningful); the BERT-base forward pass of bench.py's encoder leg.
 Prints one JSON object."""
-import glob
 import json
 import os
 import statistics
-import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -29,99 +26,7 @@ import bergen_amd  # noqa: E402
 from bergen_amd import _lib  # noqa: E402
 
 
-def _read(path):
-    try:
-        return open(path).read().strip()
-    except OSError:
-        return None
-
-
-def _pci_address(device):
-    """'0000:bb:dd.f' of HIP device `device` (hipDeviceGetPCIBusId), or None."""
-    import ctypes
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
-            return None
-        return buf.value.decode().lower()
-    except OSError:
-        return None
-
-
-class Sampler:
-    """Side thread: (t, watts, sclk MHz) every `period` s from sysfs, falling back to amd-smi (slower: one process per sample)."""
-
-    def __init__(self, period=0.05):
-        self.period = period
-        # the hwmon node of THIS process's GPU (the box has eight; the HIP device is found by its PCI address)
-        self.hw = None
-        bdf = _pci_address(0)
-        cands = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")) if bdf else []
-        for h in cands:
-            if _read(os.path.join(h, "power1_average")) or _read(os.path.join(h, "power1_input")):
-                self.hw = h
-                break
-        self.pci = bdf
-        self.dev = os.path.dirname(os.path.dirname(self.hw)) if self.hw else None
-        self.source = "hwmon " + self.hw if self.hw else "amd-smi"
-        self.samples = []
-        self._stop = threading.Event()
-        self._thread = None
-
-    def cap_watts(self):
-        v = _read(os.path.join(self.hw, "power1_cap")) if self.hw else None
-        return int(v) / 1e6 if v else None
-
-    def _one(self):
-        if self.hw:
-            p = _read(os.path.join(self.hw, "power1_average")) or _read(os.path.join(self.hw, "power1_input"))
-            f = _read(os.path.join(self.hw, "freq1_input"))
-            mhz = int(f) / 1e6 if f else None
-            if mhz is None:
-                dpm = _read(os.path.join(self.dev, "pp_dpm_sclk")) or ""
-                for line in dpm.splitlines():
-                    if line.endswith("*"):
-                        mhz = float(line.split(":")[1].strip().rstrip("*").strip().lower().rstrip("mhz"))
-            return (int(p) / 1e6 if p else None), mhz
-        try:
-            out = subprocess.run(["amd-smi", "metric", "-g", "0", "-p", "-c", "--json"], capture_output=True, text=True, timeout=5).stdout
-            j = json.loads(out)
-            j = j[0] if isinstance(j, list) else j
-            pw = j.get("power", {}).get("socket_power", {})
-            pw = pw.get("value") if isinstance(pw, dict) else pw
-            clk = j.get("clock", {}).get("gfx_0", {}).get("clk", {})
-            clk = clk.get("value") if isinstance(clk, dict) else clk
-            return (float(pw) if pw not in (None, "N/A") else None), (float(clk) if clk not in (None, "N/A") else None)
-        except Exception:
-            return None, None
-
-    def start(self):
-        self.samples = []
-        self._stop.clear()
-
-        def loop():
-            while not self._stop.is_set():
-                w, f = self._one()
-                self.samples.append((time.perf_counter(), w, f))
-                self._stop.wait(self.period)
-        self._thread = threading.Thread(target=loop, daemon=True)
-        self._thread.start()
-
-    def stop(self, skip_s=0.5):
-        self._stop.set()
-        self._thread.join()
-        if not self.samples:
-            return {}
-        t0 = self.samples[0][0]
-        ws = [w for t, w, f in self.samples if w is not None and t - t0 >= skip_s]
-        fs = [f for t, w, f in self.samples if f is not None and t - t0 >= skip_s]
-        out = {"samples": len(ws)}
-        if ws:
-            out.update(watts_mean=round(statistics.mean(ws), 1), watts_max=round(max(ws), 1))
-        if fs:
-            out.update(sclk_mhz_mean=round(statistics.mean(fs)), sclk_mhz_min=round(min(fs)), sclk_mhz_max=round(max(fs)))
-        return out
+Sampler = bench.PowerSampler
 
 
 def main():

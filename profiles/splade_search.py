@@ -17,7 +17,7 @@ def main():
     sweep = ("", [None])
     for kv in sys.argv[2:]:
         k_, v_ = kv.split("=")
-        if k_ == "distinct":
+        if k_ in ("distinct", "power"):
             continue
         if "," in v_:
             sweep = (k_, [int(x) for x in v_.split(",")])  # e.g. sparse_ablate=0,1,4,16 (bench-only kernel ablations)
@@ -64,7 +64,17 @@ def main():
                 best = (dt, ix.counters())
         dt, c = best
         gbps = c["algorithmic_bytes"] / (c["scan_ms"] * 1e-3) / 1e9
-        print({"docs": docs, "nnz": int(ix.nnz), "gen_s": round(t_gen, 2), "upload_s": round(t_up, 2), "queries_per_s": round(256 / dt, 1),
+        power = None
+        if any(kv == "power=1" for kv in sys.argv[2:]):  # board power / shader clock while the search repeats for ~3 s
+            import bench
+            smp = bench.PowerSampler()
+            smp.start()
+            t1 = time.perf_counter()
+            while time.perf_counter() - t1 < 3.0:
+                ix.search(q, 50)
+            power = smp.stop(skip_s=0.5)
+            power["cap_watts"] = smp.cap_watts()
+        print({"power": power, "docs": docs, "nnz": int(ix.nnz), "gen_s": round(t_gen, 2), "upload_s": round(t_up, 2), "queries_per_s": round(256 / dt, 1),
                "scan_ms_per_pass": round(c["scan_ms"] / c["n_passes"], 3), "passes": c["n_passes"], "GB_per_s": round(gbps, 1), "frac": round(gbps / 8000, 4),
                "wall_ms": round(dt * 1e3, 2), "scan_ms": round(c["scan_ms"], 2), "merge_ms": round(c["merge_ms"], 2)})
     ix.close()

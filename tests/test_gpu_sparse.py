@@ -145,7 +145,7 @@ def test_error_behaviour(amd):
     ix.upload(blk[:2])
     ix.finalize()
     with pytest.raises(Exception):
-        ix.search(np.zeros((1, 100), np.float16), 121)   # k > 120 unsupported
+        ix.search(np.zeros((1, 100), np.float16), 4097)   # k > 4096 unsupported
     s, i = ix.search(np.ones((1, 100), np.float16), 20)  # k > n_rows: tail is (-inf, -1)
     assert np.array_equal(i[0, :10], np.arange(10)) and np.all(i[0, 10:] == -1) and np.all(np.isinf(s[0, 10:]))
     with pytest.raises(ValueError):
@@ -225,3 +225,50 @@ def test_negative_weights_take_the_general_path_and_few_positives_fill_with_low_
             assert 0 < n_pos < 60 and np.all(want_s[0][n_pos:] == 0)
             assert np.array_equal(i[2], np.arange(60))
         ix.close()
+
+
+@pytest.mark.parametrize("n,V,nq,k,signed,cluster", [(20000, 30522, 40, 300, False, 0), (3000, 1200, 6, 500, False, 400), (3000, 1200, 6, 500, True, 0),
+                                                      (700, 400, 3, 1000, False, 0), (6000, 2000, 70, 121, False, 200)])
+def test_large_k_is_searched_range_by_range(amd, n, V, nq, k, signed, cluster):
+    """k > 120 (the reference accepts any top_k_documents, modules/retrieve.py:157): ranges of 32-document groups, each
+    searched for its exact top 120 over a view of the index, merged in canonical order; a range that may have dropped a member
+    of the top k is split and searched again (sparse.hip: sparse_search_large_k).  Covered: `cluster` consecutive copies of
+    one document that scores high for query 0 (far more than 120 members of the top k in ONE range), a query with fewer
+    matching documents than k and an all-zero query (the list continues with the lowest absent rows of the WHOLE corpus),
+    signed weights (general path), k larger than the corpus, ids shifted by id_offset."""
+    dp, dt, dw = synth.random_sparse_corpus(n, V, seed=n + k, mean_nnz=min(60, V // 8), lo=0, hi=min(150, V // 3))
+    dense = synth.csr_to_dense(dp, dt, dw, V)
+    qp, qt, qw = synth.random_sparse_corpus(nq, V, seed=n + 9, mean_nnz=12, lo=1, hi=40)
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    if cluster:
+        src = int(np.argmax(dense @ q[0].astype(np.float32)))
+        dense[n // 2: n // 2 + cluster] = dense[src]
+    df = (dense != 0).sum(0)
+    rare = int(np.argmin(df + 10_000 * (df == 0)))
+    q[1] = 0
+    q[1, rare] = 1.25          # fewer matching documents than k
+    q[2] = 0                   # no matching document at all: rows 0 .. k - 1
+    if signed:
+        dense[3:n:11] *= -1
+        q[-1] *= -1
+    nz = dense != 0
+    p2 = np.zeros(n + 1, np.int64)
+    np.cumsum(nz.sum(1), out=p2[1:])
+    r, c = np.nonzero(nz)
+    vals = dense[r, c].astype(np.float16)
+    ix = amd.SparseIndex(n, V, device=0)
+    half = n // 2
+    ix.upload((p2[:half + 1], c[:p2[half]].astype(np.int32), vals[:p2[half]]))
+    ix.upload((p2[half:] - p2[half], c[p2[half]:].astype(np.int32), vals[p2[half]:]))
+    ix.finalize()
+    s, i = ix.search(q, k, id_offset=11)
+    cnt = ix.counters()
+    kk = min(k, n)
+    want_s, want_i = c_oracle.sparse_canonical_search(p2, c.astype(np.int32), vals, V, q, kk)
+    assert_bit_exact(s[:, :kk], i[:, :kk] - 11, want_s, want_i, f"sparse large k={k} n={n} signed={signed}")
+    if k > n:
+        assert (i[:, n:] == -1).all() and np.isneginf(s[:, n:]).all()
+    assert cnt["n_passes"] >= 2 * -(-nq // 64) and cnt["n_rows"] == n
+    if not signed:
+        assert np.array_equal(i[2, :kk] - 11, np.arange(kk))
+    ix.close()

@@ -496,7 +496,7 @@ def test_k_is_validated_before_the_index_is_built(tmp_path):
     with pytest.raises(ValueError, match=r"top_k_documents=5000 outside 1\.\.4096"):
         r.retrieve(ds, str(tmp_path / "q"), str(tmp_path / "d"), 5000)
     assert not built
-    assert bergen_amd.FlatIndex.MAX_K == 4096 and bergen_amd.SparseIndex.MAX_K == 120
+    assert bergen_amd.FlatIndex.MAX_K == 4096 and bergen_amd.SparseIndex.MAX_K == 4096
 
 
 def test_prefetched_keeps_order_and_forwards_errors():
