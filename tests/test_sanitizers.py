@@ -119,6 +119,11 @@ print("SANITIZED-OK")
 
 
 def test_no_device_api_surface_is_clean_under_asan_ubsan():
+    import torch
+    if torch.cuda.is_available():
+        # ROCm's ASan runtime intercepts the HSA allocator and aborts inside the (uninstrumented) HIP runtime as soon as a
+        # device is there; with a GPU the UBSan build below runs end to end instead
+        pytest.skip("the ASan build covers the no-device API surface; a GPU is present")
     _build()
     _run(CPU_SURFACE)
 
