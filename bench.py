@@ -56,6 +56,7 @@ def parse_args():
     p.add_argument("--full-list-queries", type=int, default=8,
                    help="queries whose COMPLETE top-k lists the parity gate recomputes over the whole corpus (N = 1; 0 = off)")
     p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
+    p.add_argument("--no-larger-k", action="store_true", help="skip the k = 100 / 200 / 1000 legs at the headline geometry")
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
     p.add_argument("--no-certificate-leg", action="store_true", help="skip the certificate / fall-back leg on the clustered, non-unit-norm corpus")
     p.add_argument("--encode-stage-passages", type=int, default=16384, help="passages of the Retrieve.encode_and_save leg (0 = skip)")
@@ -1106,6 +1107,32 @@ def run(args, env):
                 out["secondary_error"] = repr(exc)
             finally:
                 _lib.set_option("scan_kernel", 3)
+        if world == 1 and args.query_split is None and not args.no_larger_k:
+            # secondary figures: larger top_k_documents at the headline geometry — candidate lists of 128 / 256 entries
+            # (k = 100, 200) and the range-by-range search behind k > 248 (k = 1000, 256 queries) — each checked against
+            # complete oracle lists of 4 queries (float64 GEMM over the regenerated corpus, see streamed_full_lists)
+            try:
+                want_s, want_i = streamed_full_lists(4, queries, dim, 1000, plant_rows, n_total, device)
+                out["larger_k"] = []
+                for k2, nq2 in ((100, nq), (200, nq), (1000, min(nq, 256))):
+                    q2 = queries[:nq2]
+                    s2, i2 = ix.search(q2, k2)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    s2, i2 = ix.search(q2, k2)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    cb = ix.counters()
+                    s2n, i2n = torch.as_tensor(s2).cpu().numpy(), torch.as_tensor(i2).cpu().numpy()
+                    exact = bool(np.array_equal(i2n[:4], want_i[:, :k2]) and np.array_equal(s2n[:4].view(np.uint32), want_s[:, :k2].view(np.uint32)))
+                    out["larger_k"].append({"k": k2, "queries": nq2, "queries_per_s": nq2 / dt, "k_padded": cb["k_padded"], "query_tile": cb["query_tile"],
+                                            "passes": cb["n_passes"], "scan_ms_per_pass": cb["scan_ms"] / max(1, cb["n_passes"]),
+                                            "uncertified_queries": cb.get("uncertified_queries", 0),
+                                            "full_lists_of_4_queries_bit_exact": exact})
+                    if not exact:
+                        out["parity_check"] = "FAIL (larger_k leg)"
+            except Exception as exc:
+                out["larger_k"] = {"error": repr(exc)}
         if args.sweep and world == 1:
             out["sweep"] = sweep(ix, queries, k, args)
         if world == 1 and not args.no_config5:

@@ -11,8 +11,8 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
-BENCH_PMC="$BENCH --no-encoder --no-stage --no-certificate-leg"   # the counter passes of the scan kernels (dense and sparse) do not need the encoder legs
-BENCH_ENC="$BENCH --no-other-kernels --no-config5 --no-certificate-leg --no-stage --no-splade --encode-stage-passages 0"
+BENCH_PMC="$BENCH --no-encoder --no-stage --no-certificate-leg --no-larger-k"   # the counter passes of the scan kernels (dense and sparse) do not need the encoder legs
+BENCH_ENC="$BENCH --no-other-kernels --no-larger-k --no-config5 --no-certificate-leg --no-stage --no-splade --encode-stage-passages 0"
 echo "== kernel trace + stats" 
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace.log" 2>&1
 echo "exit $?" >> "$OUT/trace.log"

@@ -20,7 +20,7 @@ def _free_port():
 
 def _run(world, extra):
     flags = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-rows", "30011", "--queries", "37", "--no-encoder",
-             "--no-cpu-baseline", "--no-other-kernels", "--no-config5", "--no-stage", "--no-certificate-leg", "--no-splade"] + extra
+             "--no-cpu-baseline", "--no-other-kernels", "--no-larger-k", "--no-config5", "--no-stage", "--no-certificate-leg", "--no-splade"] + extra
     script = os.path.join(ROOT, "tests", "bench_standin.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
