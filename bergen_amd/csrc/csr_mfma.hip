@@ -201,16 +201,16 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         const uint2 it = Qt[(q_head + lane) & (BH_CSR_MFMA_QUEUE - 1)];
         q_head += n;
         const unsigned p = it.x, ent = it.y;
-        // document of the hit = number of row pointers rel[1..32] (lane l holds rel[l]) that are <= p: a 6-step binary
-        // search with ds_bpermute, all 64 hits at once
+        // document of the hit = number of row pointers rel[1..31] (lane l holds rel[l]) that are <= p — rel[32], the group's
+        // entry count, is above every position —: a 5-step binary search with ds_bpermute, all 64 hits at once (each step is
+        // a dependent LDS-crossbar round trip: the search is most of a drain's latency)
         int dd = 0;
 #pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const int mid = dd + step;
-            const unsigned bv = (unsigned)__shfl((int)rel, mid < 33 ? mid : 32, 64);
-            if (mid <= 32 && bv <= p) dd = mid;
+        for (int step = 16; step >= 1; step >>= 1) {
+            const int mid = dd + step;  // <= 31
+            const unsigned bv = (unsigned)__shfl((int)rel, mid, 64);
+            if (bv <= p) dd = mid;
         }
-        if (dd > 31) dd = 31;
         if ((a.ablate & 16) == 0 && (unsigned)lane < n) {  // (16, bench-only: queue without resolving)
             const unsigned term = ent & 0xffffu;
             const unsigned word = bitmap[term >> 5];
