@@ -21,7 +21,7 @@ with open(os.path.join(out_dir, "scan_launches.csv"), "w") as f:
     f.write("kernel,start_ms,duration_ms\n")
     for t, name, d in rows:
         f.write(f'"{name}",{(t - t0) / 1e6:.3f},{d / 1e6:.4f}\n')
-head = [d for _, name, d in rows if name.startswith("bh_scan_topk256_kernel<24,")]
+head = [d for _, name, d in rows if name.startswith("bh_scan_topk256_kernel<24, 64,")]  # (candidate lists of 64: k <= 56)
 tail = [d for _, name, d in rows if name.startswith("bh_scan_topk_kernel<48,") and ", 5, " not in name]
 n_head = n_search * (n_pass - 1)
 res = {"headline_kernel": "bh_scan_topk256_kernel<24, ...> (d = 768)", "headline_launches": n_head,
