@@ -392,8 +392,8 @@ class Retrieve:
             self.model.model = self.model.model.to('cpu')  # free HBM for the index (retrieve.py:78)
 
         metric = "sparse" if (sparse_queries or getattr(self.model, "sparse", False)) else _metric_of(self.model)
-        # the kernels carry candidate lists of at most 256 (dense) / 128 (sparse) entries: refuse a larger k BEFORE the
-        # index is read and uploaded (the reference accepts any k; INTEGRATION.md "Limits")
+        # k up to 4096 is served (one fused search up to 248 dense / 120 sparse, range by range above that); a larger k is
+        # refused BEFORE the index is read and uploaded (the reference accepts any k; INTEGRATION.md "Limits")
         k_max = self._sparse_index_cls.MAX_K if metric == "sparse" else self._dense_index_cls.MAX_K
         if not 0 < int(top_k_documents) <= k_max:
             raise ValueError(f"top_k_documents={top_k_documents} outside 1..{k_max} supported by the {metric} search kernels")
@@ -560,3 +560,4 @@ class Retrieve:
         for ix, _ in self._resident.values():
             ix.close()
         self._resident.clear()
+        self._searchers.clear()  # (their gather buffers belong to the indexes just closed)
