@@ -148,9 +148,17 @@ struct BhGemmArgs {
     long long ld_seg;
     long long c_block_rows;  // != 0: C is stored blocked by 64 columns with this many rows per block (persistent kernel only)
     int stagger_phases, stagger_unit, stagger_first_round;  // start stagger of the first round of blocks (0 = off)
+    // bh_launch_gemm_f16_batched: `batch` independent problems of one shape in ONE launch of the persistent kernel; problem b
+    // reads A + b * batch_stride_a, B + b * batch_stride_b and writes C + b * batch_stride_c (strides in elements)
+    int batch;
+    long long batch_stride_a, batch_stride_b, batch_stride_c;
 };
 // variant 0 = auto; see gemm_f16.hip for the explicit tile configurations
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a, int variant, hipStream_t stream);
+// C_b = A_b . B_b^T for b < a.batch, whole 256 x 256 tiles only (M, N % 256 == 0, K % 64 == 0), no bias / residual / GELU:
+// the per-head position GEMMs of the disentangled attention (encoder.hip) — 16 heads x 44 tiles fill the chip, one head's
+// 44 tiles (K = 64: a single pipeline stage each) are a launch-latency-bound 8.7 us
+hipError_t bh_launch_gemm_f16_batched(const BhGemmArgs& a, hipStream_t stream);
 hipError_t bh_gemm_probe_permlane(hipStream_t stream);
 int bh_gemm_swap_mode();
 void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of the first round of blocks

@@ -76,6 +76,7 @@ struct bh_encoder {
     // optional disentangled attention (DeBERTa-v2 / v3; option "rel_attention_span" before the weights are set): the
     // relative-position embedding table [2 span][d] with its LayerNorm, the index table t(delta) and per-forward workspace
     int rel_span = 0;
+    int rel_batched = 1;  // option "rel_batched_gemm": the per-head position GEMMs in one launch per term (0: one launch per head)
     _Float16* rel_arena = nullptr;
     _Float16 *rel_emb = nullptr, *rel_g = nullptr, *rel_b = nullptr;
     BhDevBuf<int> rel_idx;
@@ -393,6 +394,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
         e->gemm_variant = (int)value;
         return BH_OK;
     }
+    if (std::string(name) == "rel_batched_gemm") {  // A/B and test knob: 0 = one launch per head for the position GEMMs
+        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "rel_batched_gemm must be 0 or 1");
+        e->rel_batched = (int)value;
+        return BH_OK;
+    }
     if (std::string(name) == "rel_attention_span") {
         // DeBERTa-v2 / v3 disentangled attention with 2 * span relative positions (config.position_buckets); must precede
         // the weights: adds the slots of encoder.rel_embeddings.weight and encoder.LayerNorm.{weight,bias}
@@ -624,7 +630,36 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             if ((rc = gemm(e, e->REL_LN.p, d, L.wqk, d, e->REL_QK.p, 2 * da, rel_n, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
             _Float16* c2p = e->RELB.p;
             _Float16* p2c = e->RELB.p + (size_t)c.n_heads * M * rel_n;
-            for (int hh = 0; hh < c.n_heads; ++hh) {
+            // all heads of a term in ONE launch where the shapes are whole 256 x 256 tiles (deberta-v3: 2 span = 512 columns):
+            // a head's 44 single-stage tiles alone are launch-latency-bound (8.7 us x 2 x 16 heads x 24 layers = 6.7 of the
+            // 17 ms of a 32-pair forward pass at DeBERTa-v3-large's shape)
+            bool batched = e->rel_batched && m_pad % 256 == 0 && rel_n % 256 == 0;
+            if (batched) {
+                BhGemmArgs g{};
+                g.lda = g.ldb = 2 * da;
+                g.ldc = rel_n;
+                g.M = m_pad;
+                g.N = rel_n;
+                g.K = 64;
+                g.batch = c.n_heads;
+                g.batch_stride_a = g.batch_stride_b = 64;
+                g.batch_stride_c = (long long)M * rel_n;
+                g.A = e->QK.p;             // Q_h
+                g.B = e->REL_QK.p + da;    // Kr_h
+                g.C = c2p;
+                hipError_t ge = bh_launch_gemm_f16_batched(g, st);
+                if (ge == hipSuccess) {
+                    g.A = e->QK.p + da;    // K_h
+                    g.B = e->REL_QK.p;     // Qr_h
+                    g.C = p2c;
+                    ge = bh_launch_gemm_f16_batched(g, st);
+                }
+                if (ge == hipErrorNotSupported)
+                    batched = false;
+                else
+                    BH_HIP_TRY(ge);
+            }
+            for (int hh = 0; hh < c.n_heads && !batched; ++hh) {
                 if ((rc = gemm(e, e->QK.p + hh * 64, 2 * da, e->REL_QK.p + da + hh * 64, 2 * da, c2p + (size_t)hh * M * rel_n, rel_n,
                                m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0))) return rc;
                 if ((rc = gemm(e, e->QK.p + da + hh * 64, 2 * da, e->REL_QK.p + hh * 64, 2 * da, p2c + (size_t)hh * M * rel_n, rel_n,

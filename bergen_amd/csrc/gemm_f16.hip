@@ -96,6 +96,20 @@ hipError_t run_cfg(int cfg, const BhGemmArgs& a, int epi, hipStream_t s) {
 
 }  // namespace
 
+hipError_t bh_launch_gemm_f16_batched(const BhGemmArgs& a_in, hipStream_t stream) {
+    BhGemmArgs a = a_in;
+    if (a.batch <= 0 || a.M <= 0 || a.N <= 0) return hipSuccess;
+    if ((a.M & 255) || (a.N & 255) || a.K <= 0 || (a.K & 63) || (a.lda & 7) || (a.ldb & 7) || (a.ldc & 7) || (a.batch_stride_a & 7) ||
+        (a.batch_stride_b & 7) || (a.batch_stride_c & 7) || a.bias || a.residual || a.gelu || a.seg_out || a.c_block_rows)
+        return hipErrorInvalidValue;
+    hipError_t e = bh_gemm_probe_permlane(stream);
+    if (e != hipSuccess) return e;
+    if (g_swap_b != 0) return hipErrorNotSupported;  // (the caller falls back to one launch per problem)
+    a.swap_b = g_swap_b;
+    a.stagger_phases = 0;
+    return bh_gemm_persist(a, BH_EPI_BATCHED, 1, stream);
+}
+
 // variant: 0 = auto; 1..5 = explicit tile configuration (gemm_f16_kernel.h); 6 = generic bounds-checked kernel
 // for everything; 7 = persistent 256x256 kernel (gemm_f16_persist.h; burst stores); 8 = 7 with stores deferred into
 // the next tile's main loop, 9 = 7 with non-temporal stores (both valid results; ablations); 11..28 = bench-only

@@ -26,6 +26,9 @@ int n_cu() {
         case BH_EPI_BIAS_ROW | BH_EPI_SEGMAX:                                                                     \
             if (P == 1) return bh_gemm_launch_persist<BH_EPI_BIAS_ROW | BH_EPI_SEGMAX, 1>(a, n_cu(), s);          \
             break;                                                                                                \
+        case BH_EPI_BATCHED:                                                                                      \
+            if (P == 1) return bh_gemm_launch_persist<BH_EPI_BATCHED, 1>(a, n_cu(), s);                           \
+            break;                                                                                                \
     }                                                                                                             \
     return hipErrorNotSupported;
 

@@ -10,6 +10,7 @@
 #define BH_EPI_RESIDUAL 4  // + residual[m][n]
 #define BH_EPI_GELU 8      // erf-GELU
 #define BH_EPI_SEGMAX 16   // persistent kernel only: no store; relu + per-sequence max into seg_out (SPLADE head)
+#define BH_EPI_BATCHED 32  // persistent kernel only: a.batch problems of one shape in one launch (BhGemmArgs::batch_stride_*)
 
 namespace bh_gemm {
 

@@ -54,8 +54,10 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     // ---- this block's tiles: XCD x (= block % 8) owns a contiguous range of the (m-major, n-minor) tile order;
     // its blocks j = block / 8 take tiles start + j, start + j + G/8, ... so that the XCD's CUs work on
     // neighbouring tiles at the same time
+    constexpr bool BATCHED = (EPI & BH_EPI_BATCHED) != 0;
     const int tiles_n = a.N / BN;
-    const int n_tiles = (a.M / BM) * tiles_n;
+    const int tiles_1 = (a.M / BM) * tiles_n;                   // tiles of one problem
+    const int n_tiles = BATCHED ? tiles_1 * a.batch : tiles_1;  // batched: problem-major tile order
     int t_first, t_step, n_my;
     {
         const int G8 = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -108,10 +110,17 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     int it = 0, ikt = 0, islot = 0;  // tile ordinal, k-stage inside it, ring slot
     const unsigned char *curA, *curB;  // wave-uniform bases of the issue tile's A rows / B rows
     auto set_issue_tile = [&](int ord) {
-        const int t = t_first + ord * t_step;
+        int t = t_first + ord * t_step;
+        const unsigned char *pa = baseA, *pb = baseB;
+        if constexpr (BATCHED) {
+            const int bz = t / tiles_1;
+            t -= bz * tiles_1;
+            pa += (size_t)bz * (size_t)a.batch_stride_a * 2;
+            pb += (size_t)bz * (size_t)a.batch_stride_b * 2;
+        }
         const int tm0 = (t / tiles_n) * BM, tn0 = (t % tiles_n) * BN;
-        curA = baseA + (size_t)tm0 * a.lda * 2;
-        curB = baseB + (size_t)tn0 * a.ldb * 2;
+        curA = pa + (size_t)tm0 * a.lda * 2;
+        curB = pb + (size_t)tn0 * a.ldb * 2;
     };
     set_issue_tile(0);
     auto issue_piece = [&](int i) {
@@ -273,7 +282,13 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     for (int tm = 0; tm < TM; ++tm) read_xa(tm, smem, 0);
 
     for (int ti = 0; ti < n_my; ++ti) {
-        const int t = t_first + ti * t_step;
+        int t = t_first + ti * t_step;
+        _Float16* c_base = a.C;
+        if constexpr (BATCHED) {
+            const int bz = t / tiles_1;
+            t -= bz * tiles_1;
+            c_base += (size_t)bz * (size_t)a.batch_stride_c;
+        }
         const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
         // ---- main loop: the first SLOTS stages are unrolled (static register indices for the deferred stores)
         {
@@ -305,10 +320,10 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
         } else {
             _Float16* tile_ptr;  // per-lane address of this tile's (tm = 0, tn = 0, u = 0) store
             if (a.c_block_rows)  // a wave's 64 output columns are exactly one 64-column block
-                tile_ptr = a.C + (size_t)((n0 + wn * TN * 32) >> 6) * a.c_block_rows * 64 +
+                tile_ptr = c_base + (size_t)((n0 + wn * TN * 32) >> 6) * a.c_block_rows * 64 +
                            (size_t)(m0 + wm * TM * 32 + ql) * 64 + 8 * h;
             else
-                tile_ptr = a.C + (size_t)(m0 + wm * TM * 32 + ql) * a.ldc + n0 + wn * TN * 32 + 8 * h;
+                tile_ptr = c_base + (size_t)(m0 + wm * TM * 32 + ql) * a.ldc + n0 + wn * TN * 32 + 8 * h;
             float bias_row[TM];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -405,7 +420,7 @@ hipError_t bh_gemm_launch_persist(const BhGemmArgs& a, int n_cu, hipStream_t str
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int tiles = (a.M / 256) * (a.N / 256);
+    const int tiles = (a.M / 256) * (a.N / 256) * ((EPI & BH_EPI_BATCHED) != 0 ? a.batch : 1);
     if (tiles <= 0) return hipSuccess;
     int grid = n_cu / 8 * 8;  // one resident workgroup per CU, a multiple of the XCD count
     if (grid < 8) grid = 8;

@@ -70,4 +70,9 @@ def test_deberta_v3_geometry_against_oracle():
     err = np.abs(got - ref).max()
     print(f"deberta-v3 geometry: max abs err {err:.4g}, logits {ref.ravel()[:3]}")
     assert err <= 3e-2
+    # the position GEMMs of all heads in one launch per term (the default at 2 span = 512 columns) and one launch per head
+    # compute the same tiles with the same kernel: identical logits, bit for bit
+    enc.set_option("rel_batched_gemm", 0)
+    per_head = enc.classify(_kw(ids, mask)).cpu().numpy()
+    assert np.array_equal(per_head.view(np.uint32), got.view(np.uint32))
     enc.close()
