@@ -17,11 +17,15 @@ from bergen_amd import _lib  # noqa: E402
 
 def main():
     _lib.init(0)
-    dim, k, nq, n_total = 768, 50, 2837, 21_000_000
+    # python profiles/shard_sweep.py [dim k queries [g ...]]   (defaults: the headline geometry; configs[4]: 1024 200 1000)
+    av = [int(x) for x in sys.argv[1:]]
+    dim, k, nq = (av + [768, 50, 2837][len(av):])[:3] if len(av) < 3 else av[:3]
+    n_total = 21_000_000
+    shards = tuple(av[3:]) or (1, 2, 4, 8)
     dev = torch.device("cuda", 0)
     q = bench.make_queries(nq, dim, dev)
     out = {"workload": f"{nq} queries x (21 M / g) x {dim} fp16, top-{k}, one GPU", "shards": []}
-    for g in (1, 2, 4, 8):
+    for g in shards:
         lo, hi = bergen_amd.shard_range(n_total, 0, g)
         ix = bergen_amd.FlatIndex(hi - lo, dim, metric="ip", device=0)
         bench.fill_shard(ix, lo, hi, dim, q, n_total, dev)
