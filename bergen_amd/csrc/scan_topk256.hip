@@ -751,14 +751,34 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 for (int r = 1; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = 0ull;
             }
             if (__builtin_expect(big, 0)) {
+                // longer buffers, one at a time, with the smallest sort that holds them: lists of 256 end a pass with ~60
+                // (a shard of an eighth of the corpus) to ~150 candidates per query and workgroup, and the 512-key sort of a
+                // full buffer for each of them was 0.11 - 0.24 ms per pass (profiles/scan_phases.py, BH_K=200)
+#pragma unroll 1
                 for (int t = 0; t < 8; ++t) {
                     const int qi = (wave * NB + nb) * 16 + q0 + t;
                     const unsigned n = __builtin_amdgcn_readlane(cnt[nb], q0 + t);
                     if (n <= 64u) continue;
-                    u64 e[EPLC];
-                    sort_candidates256<KP>(e, cand_wg + (size_t)qi * CAP, n, lane);
+                    const u64* src = cand_wg + (size_t)qi * CAP;
+                    u64* dst = part_wg + (size_t)qi * KP;
+                    if (EPLC >= 4 && n <= 128u) {
+                        u64 e[2];
+                        load_list256<2>(e, src, n, lane);
+                        bh_wave_sort_desc<2>(e, lane);
 #pragma unroll
-                    for (int r = 0; r < EPLK; ++r) part_wg[(size_t)qi * KP + r * 64 + lane] = e[r];
+                        for (int r = 0; r < EPLK; ++r) dst[r * 64 + lane] = r < 2 ? e[r < 2 ? r : 0] : 0ull;
+                    } else if (EPLC >= 8 && n <= 256u) {
+                        u64 e[4];
+                        load_list256<4>(e, src, n, lane);
+                        bh_wave_sort_desc<4>(e, lane);
+#pragma unroll
+                        for (int r = 0; r < EPLK; ++r) dst[r * 64 + lane] = r < 4 ? e[r < 4 ? r : 0] : 0ull;
+                    } else {
+                        u64 e[EPLC];
+                        sort_candidates256<KP>(e, src, n, lane);
+#pragma unroll
+                        for (int r = 0; r < EPLK; ++r) dst[r * 64 + lane] = e[r];
+                    }
                 }
             }
         }

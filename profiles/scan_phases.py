@@ -24,7 +24,7 @@ def main():
         k_, v_ = kv.split('=')
         _lib.set_option(k_, int(v_))
         print('option', k_, v_)
-    dim, k, n_total = 768, 50, 21_000_000
+    dim, k, n_total = int(os.environ.get("BH_DIM", "768")), int(os.environ.get("BH_K", "50")), 21_000_000  # (configs[4]: BH_DIM=1024 BH_K=200)
     dev = torch.device("cuda", 0)
     q = bench.make_queries(nq, dim, dev)
     lo, hi = bergen_amd.shard_range(n_total, 0, g)
