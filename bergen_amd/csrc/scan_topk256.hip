@@ -37,8 +37,8 @@
 //
 // Thresholds (filter hints: stale or low means less filtering, never a wrong result — but every bound must be VALID):
 //   * own bound: the workgroup's KP-th best so far (exclusive compare: its rows come in ascending order);
-//   * shared bound of a query: ONE slot per workgroup holds the best score the workgroup has published (RB = KP / 64-th
-//     best of a lane for the longer lists); any T that 64 slots reach is reached by 64 * RB = KP distinct rows of the
+//   * shared bound of a query: ONE slot per workgroup holds the best score the workgroup has published (the RB-th best of a
+//     lane: RB = 1 for lists of 64 / 128, 2 for lists of 256); any T that NS = KP / RB slots reach is reached by KP distinct rows of the
 //     corpus.  At every exchange (geometric schedule) a wave REFINES one of its queries — loads the query's 256 slots,
 //     builds the largest such T bit by bit (radix select on ballots), publishes it with atomicMax to the query's bound
 //     word — and reads the bound words of all its queries (the 256 workgroups cover all queries of the pass at every
@@ -160,7 +160,13 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     // NB = 16-query blocks per wave: 2 (256 queries per workgroup) wherever their fragments fit, 1 at d = 1024
     constexpr int BQ = 8 * 16 * NB;
     constexpr int ROW_BYTES = D * 2;
-    constexpr int RB = KP / 64;
+    // shared bound: NS slots (= workgroups) that each vouch for RB rows at or above T give NS * RB = KP distinct rows.  A lane
+    // tracks its RB best appended scores in registers: lists of 256 use (128 slots, RB = 2), lists of 128 (128 slots, RB = 1:
+    // nothing to track, the slot is fed at append time) — until round 3 both used 64 slots with RB = KP / 64, whose eight
+    // tracking registers pushed the d = 768 instantiations' cold paths into scratch
+    constexpr int RB = KP >= 256 ? KP / 128 : 1;
+    constexpr int NS = KP / RB;
+    static_assert(NS * RB == KP && NS <= BH_SLOTS256, "slots x rows per slot = list length");
     // fragments in the accumulator half of the register file (all 128 of its registers; the MFMA accumulators are VGPRs)
     constexpr int NPIN_A = NB * NK32 < 32 ? NB * NK32 : 32;
 
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 if (boot && row0 + 32u <= n_rows32 && !(ABL & 1)) {
                     // bootstrap tile: this lane's best score of its 8 rows goes to the slot table, nothing else happens
                     // (a tile holding padding rows is skipped: their zero scores are no rows of the corpus)
-                    // (candidate lists of 64 * RB entries: the slot needs a score that RB rows of this lane reach)
+                    // (candidate lists of NS * RB entries: the slot needs a score that RB rows of this lane reach)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         float pubv = tile_max[nb];
@@ -613,8 +619,8 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     }
                     // (a) refine the bound of ONE of this wave's queries (they rotate; the 256 workgroups refine all of them
                     //     at every exchange): the 256 slots of the query are one 16-byte agent-scope load per lane (the
-                    //     per-XCD L2s are not coherent: sc1), and the largest T that 64 slots reach is built bit by bit
-                    //     (bits 31..8: a bound a little low is still a bound).  64 slots = 64 workgroups = 64 * RB distinct
+                    //     per-XCD L2s are not coherent: sc1), and the largest T that NS slots reach is built bit by bit
+                    //     (bits 31..8: a bound a little low is still a bound).  NS slots = NS workgroups = NS * RB = KP distinct
                     //     rows at or above T.  (b) the bounds the other workgroups refined: one word per query.
                     const int sel = (b + i + tj) & (16 * NB - 1);
                     const int qsel = wave * (16 * NB) + sel;
@@ -640,7 +646,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                         const unsigned c = T | (1u << bit);
                         const int n = __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.x >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.y >= c)) +
                                       __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.z >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(sl.w >= c));
-                        if (n >= 64) T = c;
+                        if (n >= NS) T = c;
                     }
                     if (T > BH_ORD_NEG_INF && lane_c == 0)
                         __hip_atomic_fetch_max(gbound + qsel, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
