@@ -86,6 +86,11 @@ struct bh_encoder {
     BhDevBuf<int> ibuf;          // tok | pos | typ | seq_len | slot
     BhDevBuf<long long> seq_off;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the V projection of a layer runs on a side stream beside the Q | K projection (both read the layer input): the two
+    // persistent launches leave their last, partly filled round of tiles to each other (option "vt_side_stream", default 1)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int vt_side_stream = 1;
     bh_encoder_counters counters{};
 };
 
@@ -209,7 +214,7 @@ int build_cls_slots(bh_encoder* e) {
 
 int gemm(bh_encoder* e, const _Float16* A, long long lda, const _Float16* B, long long ldb, _Float16* C, long long ldc,
          int M, int N, int K, const _Float16* bias, int bias_mode, const _Float16* residual, long long ldr, int gelu,
-         long long c_block_rows = 0) {
+         long long c_block_rows = 0, hipStream_t on = nullptr) {
     BhGemmArgs g{};
     g.c_block_rows = c_block_rows;
     g.A = A;
@@ -226,7 +231,7 @@ int gemm(bh_encoder* e, const _Float16* A, long long lda, const _Float16* B, lon
     g.N = N;
     g.K = K;
     g.gelu = gelu;
-    BH_HIP_TRY(bh_launch_gemm_f16(g, e->gemm_variant, e->stream));
+    BH_HIP_TRY(bh_launch_gemm_f16(g, e->gemm_variant, on ? on : e->stream));
     return BH_OK;
 }
 
@@ -263,6 +268,9 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
         hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreate(&e->ev0);
         if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
         if (he != hipSuccess) rc = bh_fail(BH_EHIP, "stream/event create: %s", hipGetErrorString(he));
     }
     if (rc != BH_OK) {
@@ -297,6 +305,9 @@ void bh_encoder_destroy(bh_encoder* e) {
     if (e->cls_arena) (void)hipFree(e->cls_arena);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -392,6 +403,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
     if (std::string(name) == "gemm_variant") {
         if (value < 0 || value > 32) return bh_fail(BH_EINVAL, "gemm_variant must be 0..32");
         e->gemm_variant = (int)value;
+        return BH_OK;
+    }
+    if (std::string(name) == "vt_side_stream") {
+        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "vt_side_stream must be 0 or 1");
+        e->vt_side_stream = (int)value;
         return BH_OK;
     }
     if (std::string(name) == "rel_batched_gemm") {  // A/B and test knob: 0 = one launch per head for the position GEMMs
@@ -609,10 +625,20 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     for (int l = 0; l < c.n_layers; ++l) {
         const Layer& L = e->layers[l];
         // Q | K projections: QK[m][2d] = X Wqk^T + bqk
-        if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * da, m_pad, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
-        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][da][64] = Wv X^T + bv (bias per row)
-        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, da, m_pad, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0)))
+        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][da][64] = Wv X^T + bv (bias per row).  On the side
+        // stream, launched first: its workgroups take the CUs, and the Q | K launch fills them as they leave (and the other
+        // way round at the end) instead of each launch idling most CUs through its last round of tiles
+        const bool fork = e->vt_side_stream && e->side != nullptr;
+        if (fork) {
+            BH_HIP_TRY(hipEventRecord(e->ev_fork, st));  // (the layer input X is final; the previous layer's attention has read VT)
+            BH_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        }
+        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, da, m_pad, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0,
+                       fork ? e->side : nullptr)))
             return rc;
+        if (fork) BH_HIP_TRY(hipEventRecord(e->ev_join, e->side));
+        if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * da, m_pad, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
+        if (fork) BH_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
         BhAttnArgs aa{};
         aa.qk = e->QK.p;
         aa.ldqk = 2 * da;
