@@ -261,12 +261,14 @@ hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int 
 
 // Two launches over a length-bucketed batch: seq_idx_dev holds the n_short sequences of at most 128 tokens first,
 // then the n_long longer ones.
+// stream_long (optional): the launch over the long sequences goes there instead — the two launches touch disjoint sequences,
+// the caller orders both streams against the producers and consumers of Q | K, V^T and the context rows.
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a_in, const int* seq_idx_dev, int n_short, int n_long,
-                                        int max_len_long, int n_heads, hipStream_t stream, int short_max) {
+                                        int max_len_long, int n_heads, hipStream_t stream, int short_max, hipStream_t stream_long) {
     BhAttnArgs a = a_in;
     a.seq_idx = seq_idx_dev;
     hipError_t e = launch_attn<4>(a, n_short, n_heads, short_max, stream);
     if (e != hipSuccess) return e;
     a.seq_idx = seq_idx_dev + n_short;
-    return launch_attn<8>(a, n_long, n_heads, max_len_long > short_max + 1 ? max_len_long : short_max + 1, stream);
+    return launch_attn<8>(a, n_long, n_heads, max_len_long > short_max + 1 ? max_len_long : short_max + 1, stream_long ? stream_long : stream);
 }

@@ -189,7 +189,8 @@ struct BhAttnArgs {
 };
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
-                                        int max_len_long, int n_heads, hipStream_t stream, int short_max = 128);
+                                        int max_len_long, int n_heads, hipStream_t stream, int short_max = 128,
+                                        hipStream_t stream_long = nullptr);
 // attention_rel.hip: DeBERTa-v2/v3 disentangled attention (one launch, 8-wave workgroups)
 hipError_t bh_launch_attention_rel(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 

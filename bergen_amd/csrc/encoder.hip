@@ -91,6 +91,7 @@ struct bh_encoder {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int vt_side_stream = 1;
+    int attn_side_stream = 1;  // the attention launches over the short and the long sequences of a batch side by side
     bh_encoder_counters counters{};
 };
 
@@ -405,6 +406,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
         e->gemm_variant = (int)value;
         return BH_OK;
     }
+    if (std::string(name) == "attn_side_stream") {
+        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "attn_side_stream must be 0 or 1");
+        e->attn_side_stream = (int)value;
+        return BH_OK;
+    }
     if (std::string(name) == "vt_side_stream") {
         if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "vt_side_stream must be 0 or 1");
         e->vt_side_stream = (int)value;
@@ -702,7 +708,18 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             for (int b = 0; b < batch; ++b) max_len_all = std::max(max_len_all, len[b]);
             BH_HIP_TRY(bh_launch_attention_rel(aa, batch, c.n_heads, max_len_all, st));
         } else {
-            BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short));
+            // the launches over the short and the long sequences touch disjoint sequences: side by side (option "attn_side_stream")
+            const bool fork_attn = e->attn_side_stream && e->side != nullptr && n_short > 0 && batch - n_short > 0;
+            if (fork_attn) {
+                BH_HIP_TRY(hipEventRecord(e->ev_fork, st));  // (Q | K and V^T are complete: the V projection was joined above)
+                BH_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            }
+            BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short,
+                                                    fork_attn ? e->side : nullptr));
+            if (fork_attn) {
+                BH_HIP_TRY(hipEventRecord(e->ev_join, e->side));
+                BH_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+            }
         }
         // attention output projection, then LayerNorm(projection + layer input)
         if ((rc = gemm(e, e->CTX.p, da, L.wo, da, e->Y.p, d, m_pad, d, da, L.bo, 1, nullptr, 0, 0))) return rc;
