@@ -288,8 +288,10 @@ int bh_sparse_finalize(bh_sparse_index* ix) {
 // document group), k <= kSparseListK.  Row ids inside the kernels are relative to the view (the row-pointer arrays are
 // passed from view_lo on, entry offsets stay absolute; the corpus-head tile of group g sits HD * g dwords into the tail
 // stream, so that stream is passed from the view's first group on): the caller folds view_lo into id_offset.
+// floor_flags (optional, [nq]): 1 for the queries whose tile took the non-negative path — their lists hold EVERY document of
+// the view with a positive score first and continue with the view's lowest zero-score rows.
 static int sparse_search_view(bh_sparse_index* ix, int64_t view_lo, int64_t view_rows, const void* q_host, int32_t q_dtype, int32_t nq,
-                              int32_t k, int64_t id_offset, float* out_scores, int64_t* out_ids) {
+                              int32_t k, int64_t id_offset, float* out_scores, int64_t* out_ids, char* floor_flags = nullptr) {
     if (!ix) return bh_fail(BH_EINVAL, "null index");
     if (!ix->finalized) {
         if (ix->rows_have != ix->n_rows)
@@ -634,6 +636,8 @@ static int sparse_search_view(bh_sparse_index* ix, int64_t view_lo, int64_t view
         BH_HIP_TRY(hipEventRecord(tev[2], st));
         BhCsrMergeArgs ma{};
         ma.floor_zero = floor_zero ? 1 : 0;
+        if (floor_flags)
+            for (int j = 0; j < nt; ++j) floor_flags[q0 + j] = floor_zero ? 1 : 0;
         ma.partial = ix->partial.p + (size_t)par * partial_elems;
         ma.n_lists = grid;
         ma.entries = ix->entries.p;
@@ -699,11 +703,18 @@ static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_
     };
     const int64_t n_rows = ix->n_rows, n_groups = (n_rows + 31) / 32;
     bh_counters total{};
+    // Non-negative data (the usual SPLADE case; per query tile, see the view search): a range's list holds every document with
+    // a POSITIVE score first and continues with its lowest zero-score rows.  Zero-score rows need no search — they are the
+    // rows that are not positive, in row order — so such a list has dropped something only if its LAST entry is still
+    // positive, and a query with fewer than k matching documents is completed here from the lowest absent rows of the whole
+    // corpus (without this, every range would be drilled down to single groups looking for more zeros).
+    std::vector<char> floor_q((size_t)nq, 0);
     auto search_range = [&](Range& r) -> int {
         const int64_t lo = r.g0 * 32, hi = std::min<int64_t>(n_rows, r.g1 * 32);
         r.s.assign((size_t)nq * KK, -INFINITY);
         r.i.assign((size_t)nq * KK, -1);
-        const int rc = sparse_search_view(ix, lo, hi - lo, q_host, q_dtype, nq, KK, id_offset + lo, r.s.data(), reinterpret_cast<int64_t*>(r.i.data()));
+        const int rc = sparse_search_view(ix, lo, hi - lo, q_host, q_dtype, nq, KK, id_offset + lo, r.s.data(), reinterpret_cast<int64_t*>(r.i.data()),
+                                          floor_q.data());
         if (rc != BH_OK) return rc;
         const bh_counters& c = ix->counters;
         total.scan_ms += c.scan_ms;
@@ -736,11 +747,13 @@ static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_
         std::vector<char> overflow(ranges.size(), 0);
         bool any = false;
         for (int q = 0; q < nq; ++q) {
+            const bool floor = floor_q[(size_t)q] != 0;
             all.clear();
             for (auto& r : ranges)
                 for (int t = 0; t < KK; ++t) {
                     const long long id = r.i[(size_t)q * KK + t];
-                    if (id >= 0) all.push_back(Ent{r.s[(size_t)q * KK + t], id});
+                    const float sc = r.s[(size_t)q * KK + t];
+                    if (id >= 0 && !(floor && !(sc > 0.f))) all.push_back(Ent{sc, id});  // (floor: the zero-score fill is rebuilt below)
                 }
             std::sort(all.begin(), all.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s > b.s : a.id < b.id; });
             const size_t take = std::min<size_t>(all.size(), (size_t)k);
@@ -748,10 +761,27 @@ static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_
                 out_scores[(size_t)q * k + t] = t < take ? all[t].s : -INFINITY;
                 out_ids[(size_t)q * k + t] = t < take ? all[t].id : -1;
             }
+            if (floor && take < (size_t)k) {
+                // fewer than k documents match: the canonical order continues with the zero-score rows by ascending row —
+                // the lowest rows that are not among the positive ones (at most `take` of the first k rows are)
+                std::vector<long long> pos;
+                pos.reserve(take);
+                for (size_t t = 0; t < take; ++t) pos.push_back(all[t].id - id_offset);
+                std::sort(pos.begin(), pos.end());
+                size_t filled = take, pi = 0;
+                for (long long row = 0; row < n_rows && filled < (size_t)k; ++row) {
+                    while (pi < pos.size() && pos[pi] < row) ++pi;
+                    if (pi < pos.size() && pos[pi] == row) continue;
+                    out_scores[(size_t)q * k + filled] = 0.f;
+                    out_ids[(size_t)q * k + filled] = id_offset + row;
+                    ++filled;
+                }
+            }
             for (size_t j = 0; j < ranges.size(); ++j) {
                 const long long last_id = ranges[j].i[(size_t)q * KK + KK - 1];
                 if (last_id < 0) continue;  // not full: the list holds every document of the range that can matter
                 const float last_s = ranges[j].s[(size_t)q * KK + KK - 1];
+                if (floor && !(last_s > 0.f)) continue;  // its positive documents are all listed; zeros are rebuilt above
                 const bool last_in_topk = take < (size_t)k || last_s > all[take - 1].s || (last_s == all[take - 1].s && last_id <= all[take - 1].id);
                 if (last_in_topk && ranges[j].g1 - ranges[j].g0 > 1) {
                     overflow[j] = 1;
