@@ -69,3 +69,29 @@ def test_power_sampler_without_a_sensor_reports_nothing_and_does_not_raise():
     got = smp.stop(skip_s=0.0)
     assert isinstance(got, dict) and got.get("samples", 0) >= 0 and "error" not in got
     assert smp.cap_watts() is None or smp.cap_watts() > 0
+
+
+def test_committed_pmc_traffic_is_reported_only_for_the_kernel_source_it_was_measured_on(tmp_path):
+    """roofline.traffic comes from profiles/hbm_traffic.json (rocprofv3 --pmc, separate passes).  bench.pmc_traffic hands an
+    entry out only for exactly the kernel + geometry asked for and only while the kernel's source file still has the sha256
+    the entry was collected under — a kernel edit without a re-profile must show null, not the old number."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    import bench
+    committed = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    table = json.load(open(committed))["kernels"]
+    assert "bh_scan_topk256_kernel@768" in table and "bh_csr_scan_mfma_kernel@30522" in table
+    for key, ent in table.items():
+        src = os.path.join(ROOT, "bergen_amd", "csrc", bench.KERNEL_SOURCES[ent["kernel"]])
+        fresh = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] == ent["source_sha16"]
+        got = bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"], ent["dim"])
+        assert (got == ent["hbm_bytes_per_launch"]) if fresh else (got is None), key
+        assert bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"] + 1, ent["dim"]) is None      # another corpus size
+        assert bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"], ent["dim"] + 64) is None     # another geometry
+    # a stale hash
+    k0 = "bh_scan_topk256_kernel@768"
+    stale = {"kernels": {k0: dict(table[k0], source_sha16="0" * 16)}}
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(stale))
+    assert bench.pmc_traffic(str(p), "bh_scan_topk256_kernel", table[k0]["n_rows"], 768) is None
+    assert bench.pmc_traffic(str(tmp_path / "missing.json"), "bh_scan_topk256_kernel", 1, 768) is None
