@@ -23,11 +23,16 @@ ALLOW_SCRATCH = re.compile(r"bh_gemm_f16_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi
 
 
 def usage(src):
-    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", os.devnull,
-                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC)
-    assert out.returncode == 0, out.stderr[-2000:]
+    if src == "scan_topk256.hip":  # the slowest file: compiled once for this test and test_scan256_isa.py
+        from hipcc_cache import scan256_asm_and_remarks
+        remarks = scan256_asm_and_remarks()[1]
+    else:
+        out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", os.devnull,
+                              "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC)
+        assert out.returncode == 0, out.stderr[-2000:]
+        remarks = out.stderr
     res, name = {}, None
-    for line in out.stderr.splitlines():
+    for line in remarks.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)

@@ -24,13 +24,11 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 
 @pytest.fixture(scope="module")
-def kernels(tmp_path_factory):
-    out = tmp_path_factory.mktemp("isa") / "scan256.s"
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", str(out),
-                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=os.path.dirname(SRC))
-    assert r.returncode == 0, r.stderr[-2000:]
+def kernels():
+    from hipcc_cache import scan256_asm_and_remarks  # (one compilation shared with test_build_resources.py)
+    out, remarks = scan256_asm_and_remarks()
     global RESOURCE_LOG
-    RESOURCE_LOG = r.stderr
+    RESOURCE_LOG = remarks
     res, name, body = {}, None, []
     for line in open(out):
         m = re.match(r"^(_Z22bh_scan_topk256_kernel\S+):", line)
