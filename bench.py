@@ -896,8 +896,30 @@ class HipEnv:
         torch.cuda.synchronize()
 
 
+def launch_ranks_if_needed(args, script=None):
+    """`python bench.py --gpus N` typed WITHOUT a launcher (N > 1, no WORLD_SIZE in the environment): start the N ranks here —
+    the same `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script>
+    <flags>` command the driver uses, one process per GPU — relay rank 0's JSON line and exit with the launcher's status.
+    Returns False when this process is itself a rank (or N = 1) and should run the bench."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return False
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.path.abspath(script or sys.argv[0])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL's dmabuf IPC; exported on the GPU boxes already)
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
+    launch_ranks_if_needed(args)
     run(args, HipEnv(int(os.environ.get("LOCAL_RANK", "0"))))
 
 
@@ -910,7 +932,9 @@ def run(args, env):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         env.init_dist(rank, world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks "
+                         f"(start it as `python bench.py --gpus N`, or under torch.distributed.run with --nproc-per-node N)")
 
     import bergen_amd
     env.init_library(args)

@@ -13,6 +13,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BERGEN_HIP_LIB", os.path.join(_HERE, "lib", "libbergen_hip.so"))
 
+BH_VERSION = 140  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
+
 BH_OK = 0
 BH_EINVAL = -1
 BH_EHIP = -2
@@ -26,8 +28,18 @@ BH_METRIC_IP = 0
 BH_METRIC_COS = 1
 
 
-class bh_counters(ctypes.Structure):
+class _Sized(ctypes.Structure):
+    """Structs whose first field is `struct_size` (include/bergen_hip.h, BH_VERSION 140): set on construction."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(type(self))
+
+
+class bh_counters(_Sized):
     _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("reserved_head", ctypes.c_int32),
         ("n_rows", ctypes.c_int64),
         ("dim", ctypes.c_int32),
         ("dim_padded", ctypes.c_int32),
@@ -50,8 +62,9 @@ class bh_counters(ctypes.Structure):
     ]
 
 
-class bh_encoder_config(ctypes.Structure):
+class bh_encoder_config(_Sized):
     _fields_ = [
+        ("struct_size", ctypes.c_int32),
         ("n_layers", ctypes.c_int32),
         ("hidden", ctypes.c_int32),
         ("n_heads", ctypes.c_int32),
@@ -66,8 +79,9 @@ class bh_encoder_config(ctypes.Structure):
     ]
 
 
-class bh_encoder_counters(ctypes.Structure):
+class bh_encoder_counters(_Sized):
     _fields_ = [
+        ("struct_size", ctypes.c_int32),
         ("batch", ctypes.c_int32),
         ("seq_len", ctypes.c_int32),
         ("real_tokens", ctypes.c_int64),
@@ -99,6 +113,8 @@ SYMBOLS = {
     "bh_bench_counters": (ctypes.c_int, [_vp, ctypes.POINTER(bh_counters)]),
     "bh_debug_scan_timeline": (_i64, [_vp, _vp, _i64]),
     "bh_set_option": (ctypes.c_int, [ctypes.c_char_p, _i64]),
+    "bh_index_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i64]),
+    "bh_sparse_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i64]),
     "bh_encoder_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(bh_encoder_config)]),
     "bh_encoder_set_tensor": (ctypes.c_int, [_vp, ctypes.c_char_p, _vp, _i32, _i64]),
     "bh_encoder_commit": (ctypes.c_int, [_vp]),
@@ -145,6 +161,10 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
+        # the struct layouts above are those of ONE header version: refuse a library built from another
+        if handle.bh_version() != BH_VERSION:
+            raise ImportError(f"{LIB_PATH} reports ABI version {handle.bh_version()}, this binding is written for {BH_VERSION}: rebuild "
+                              f"(`make -C bergen_amd/csrc`)")
         _lib = handle
     return _lib
 
@@ -175,5 +195,19 @@ def init(device_id=0):
         check(lib().bh_init(device_id))  # cheap: re-selects the device for this thread
 
 
+BH_OPTION_INHERIT = -(1 << 63)
+
+
+def header_version():
+    """BH_VERSION of include/bergen_hip.h as shipped beside this package (None when the header is not there)."""
+    import re
+    path = os.path.join(os.path.dirname(_HERE), "include", "bergen_hip.h")
+    if not os.path.exists(path):
+        return None
+    m = re.search(r"^#define\s+BH_VERSION\s+(\d+)", open(path).read(), re.M)
+    return int(m.group(1)) if m else None
+
+
 def set_option(name, value):
+    """PROCESS-WIDE default of a tuning option (every handle without an override of its own sees it from its next search)."""
     check(lib().bh_set_option(name.encode(), int(value)))

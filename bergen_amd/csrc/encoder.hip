@@ -245,7 +245,12 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
     if (!out) return bh_fail(BH_EINVAL, "null out");
     *out = nullptr;
     if (!cfg) return bh_fail(BH_EINVAL, "null config");
-    const bh_encoder_config& c = *cfg;
+    // the caller's struct may be shorter (older header) or longer (newer) than this build's: read what both sides know
+    if (cfg->struct_size < 40)
+        return bh_fail(BH_EINVAL, "bh_encoder_config.struct_size = %d: set it to sizeof(bh_encoder_config) (BH_VERSION %d)", cfg->struct_size, BH_VERSION);
+    bh_encoder_config c{};
+    memcpy(&c, cfg, std::min<size_t>((size_t)cfg->struct_size, sizeof c));
+    c.struct_size = (int32_t)sizeof c;
     if (c.n_layers <= 0 || c.hidden <= 0 || c.n_heads <= 0 || c.intermediate <= 0 || c.vocab_size <= 0 ||
         c.max_position <= 0 || c.type_vocab_size <= 0)
         return bh_fail(BH_EINVAL, "encoder config has non-positive fields");
@@ -837,7 +842,8 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
 
 int bh_encoder_counters_get(const bh_encoder* e, bh_encoder_counters* out) {
     if (!e || !out) return bh_fail(BH_EINVAL, "null argument");
-    *out = e->counters;
+    if (!bh_copy_sized(out, e->counters, 8))
+        return bh_fail(BH_EINVAL, "bh_encoder_counters.struct_size = %d: set it to sizeof(bh_encoder_counters) before the call (BH_VERSION %d)", out->struct_size, BH_VERSION);
     return BH_OK;
 }
 

@@ -62,7 +62,58 @@ struct Options {
     int certify = 1;  // exactness certificate + exact fall-back scan for the queries it cannot prove (certify.hip)
     int tail128 = 1;  // scan_topk256: a last pass of at most 128 queries runs on the 128-query kernel (5.6 instead of 7.2 ms at 21 M x 768)
     int err_scale = 1;  // test-only: multiplies the certificate's error bound (forces queries through the fall-back)
-} g_opt;
+    int filter256 = 1;  // exact fall-back: filter passes of 256 queries on scan_topk256.hip where it applies (0: 128 queries on scan_topk.hip)
+    int pair256 = 0;    // scan_topk256: workgroups b and b ^ 8 (same XCD) walk the same tiles for different 256-query halves of a 512-query launch
+};
+
+// One row per dense-search option: name, member, accepted values (lo..hi, or a short list), the message of a rejected value.
+struct OptionDef {
+    const char* name;
+    int Options::*member;
+    long long lo, hi;
+    long long only[4];  // when only[0] != -1: the accepted values (terminated by -1)
+    const char* expect;
+};
+const OptionDef g_option_defs[] = {
+    {"query_tile", &Options::query_tile, 0, 0, {128, 256, -1, -1}, "query_tile must be 128 or 256"},
+    {"share_threshold", &Options::share_threshold, 0, 1, {-1, -1, -1, -1}, "share_threshold must be 0 or 1"},
+    {"nontemporal", &Options::nontemporal, 0, 1, {-1, -1, -1, -1}, "nontemporal must be 0 or 1"},
+    {"ablate", &Options::ablate, 0, 63, {-1, -1, -1, -1}, "ablate must be 0..63"},  // bench-only: results are NOT valid search results when != 0
+    {"query_split", &Options::query_split, 1, 2, {-1, -1, -1, -1}, "query_split must be 1 or 2"},
+    {"dma_interleave", &Options::dma_interleave, 0, 1, {-1, -1, -1, -1}, "dma_interleave must be 0 or 1"},
+    {"scan_kernel", &Options::scan_kernel, 0, 0, {0, 2, 3, -1},
+     "scan_kernel must be 0 (128-query tile), 2 (192-query tile) or 3 (256-query tile, two waves per SIMD)"},
+    {"certify", &Options::certify, 0, 1, {-1, -1, -1, -1}, "certify must be 0 or 1"},
+    {"tail128", &Options::tail128, 0, 1, {-1, -1, -1, -1}, "tail128 must be 0 or 1"},
+    // (results stay exact: a looser bound only sends more queries through the fall-back)
+    {"certificate_error_scale", &Options::err_scale, 1, 1 << 24, {-1, -1, -1, -1}, "certificate_error_scale must be 1..2^24"},
+    {"dyn_tiles", &Options::dyn_tiles, 0, 1, {-1, -1, -1, -1}, "dyn_tiles must be 0 or 1"},
+    {"pair_window", &Options::pair_window, 0, 64, {-1, -1, -1, -1}, "pair_window must be 0..64"},
+    {"ring_variant", &Options::ring_variant, 0, 7, {-1, -1, -1, -1}, "ring_variant must be 0..7"},
+    {"workgroups_per_cu", &Options::workgroups_per_cu, 1, 1, {-1, -1, -1, -1}, "workgroups_per_cu must be 1 (LDS ring fills the CU)"},
+    {"filter256", &Options::filter256, 0, 1, {-1, -1, -1, -1}, "filter256 must be 0 or 1"},
+    {"pair256", &Options::pair256, 0, 1, {-1, -1, -1, -1}, "pair256 must be 0 or 1"},
+};
+constexpr int kUnset = INT32_MIN;  // per-handle override table: "inherit the process-wide value"
+
+// The process-wide defaults (bh_set_option).  Plain ints written by one call and read ONCE per search into a snapshot
+// (effective_options): a concurrent toggle cannot change a running search, and a handle's own overrides
+// (bh_index_set_option) are not visible to any other handle.
+Options g_opt;
+
+const OptionDef* find_option(const char* name) {
+    for (const OptionDef& d : g_option_defs)
+        if (strcmp(d.name, name) == 0) return &d;
+    return nullptr;
+}
+bool option_accepts(const OptionDef& d, long long v) {
+    if (d.only[0] != -1) {
+        for (long long o : d.only)
+            if (o != -1 && o == v) return true;
+        return false;
+    }
+    return v >= d.lo && v <= d.hi;
+}
 
 int pad_dim(int dim) {
     static const int sizes[] = {64, 128, 256, 384, 512, 768, 1024};
@@ -114,6 +165,11 @@ struct bh_index {
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> events;
     bh_counters counters{};
+    int opt_override[sizeof(g_option_defs) / sizeof(g_option_defs[0])];  // kUnset = inherit (bh_index_set_option)
+
+    bh_index() {
+        for (int& o : opt_override) o = kUnset;
+    }
 
     hipEvent_t event(size_t i) {
         while (events.size() <= i) {
@@ -126,6 +182,13 @@ struct bh_index {
 };
 
 namespace {
+
+Options effective_options(const bh_index* ix) {
+    Options o = g_opt;
+    for (size_t j = 0; j < sizeof(g_option_defs) / sizeof(g_option_defs[0]); ++j)
+        if (ix->opt_override[j] != kUnset) o.*(g_option_defs[j].member) = ix->opt_override[j];
+    return o;
+}
 
 // Wait for a stream by polling it.  hipStreamSynchronize parks the thread once the wait gets long (tens of milliseconds:
 // every search over a whole corpus) and the wake-up costs 1-2 ms, 2 % of the headline search.  A full-speed spin for the
@@ -276,44 +339,9 @@ int bh_init(int device_id) {
 int bh_set_option(const char* name, int64_t value) {
     if (!name) return fail(BH_EINVAL, "null option name");
     std::string s(name);
-    if (s == "query_tile") {
-        if (value != 128 && value != 256) return fail(BH_EINVAL, "query_tile must be 128 or 256");
-        g_opt.query_tile = (int)value;
-    } else if (s == "share_threshold") {
-        g_opt.share_threshold = value != 0;
-    } else if (s == "nontemporal") {
-        g_opt.nontemporal = value != 0;
-    } else if (s == "ablate") {
-        if (value < 0 || value > 63) return fail(BH_EINVAL, "ablate must be 0..63");
-        g_opt.ablate = (int)value;  // bench-only: results are NOT valid search results when != 0
-    } else if (s == "query_split") {
-        if (value != 1 && value != 2) return fail(BH_EINVAL, "query_split must be 1 or 2");
-        g_opt.query_split = (int)value;
-    } else if (s == "dma_interleave") {
-        if (value != 0 && value != 1) return fail(BH_EINVAL, "dma_interleave must be 0 or 1");
-        g_opt.dma_interleave = (int)value;
-    } else if (s == "scan_kernel") {
-        if (value != 0 && value != 2 && value != 3)
-            return fail(BH_EINVAL, "scan_kernel must be 0 (128-query tile), 2 (192-query tile) or 3 (256-query tile, two waves per SIMD)");
-        g_opt.scan_kernel = (int)value;
-    } else if (s == "certify") {
-        if (value != 0 && value != 1) return fail(BH_EINVAL, "certify must be 0 or 1");
-        g_opt.certify = (int)value;
-    } else if (s == "tail128") {
-        if (value != 0 && value != 1) return fail(BH_EINVAL, "tail128 must be 0 or 1");
-        g_opt.tail128 = (int)value;
-    } else if (s == "certificate_error_scale") {
-        if (value < 1 || value > (1 << 24)) return fail(BH_EINVAL, "certificate_error_scale must be 1..2^24");
-        g_opt.err_scale = (int)value;  // (results stay exact: a looser bound only sends more queries through the fall-back)
-    } else if (s == "dyn_tiles") {
-        if (value != 0 && value != 1) return fail(BH_EINVAL, "dyn_tiles must be 0 or 1");
-        g_opt.dyn_tiles = (int)value;
-    } else if (s == "pair_window") {
-        if (value < 0 || value > 64) return fail(BH_EINVAL, "pair_window must be 0..64");
-        g_opt.pair_window = (int)value;
-    } else if (s == "ring_variant") {
-        if (value < 0 || value > 7) return fail(BH_EINVAL, "ring_variant must be 0..7");
-        g_opt.ring_variant = (int)value;
+    if (const OptionDef* d = find_option(name)) {
+        if (!option_accepts(*d, value)) return fail(BH_EINVAL, "%s", d->expect);
+        g_opt.*(d->member) = (int)value;
     } else if (s == "sparse_kernel") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_kernel must be 0 (broadcast) or 1 (mfma)");
         bh_sparse_set_kernel((int)value);
@@ -329,12 +357,24 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "gemm_stagger_pct") {
         if (value < 1 || value > 400) return fail(BH_EINVAL, "gemm_stagger_pct must be 1..400");
         bh_gemm_set_stagger(-1, (int)value);
-    } else if (s == "workgroups_per_cu") {
-        if (value != 1) return fail(BH_EINVAL, "workgroups_per_cu must be 1 (LDS ring fills the CU)");
-        g_opt.workgroups_per_cu = 1;
     } else {
         return fail(BH_EINVAL, "unknown option '%s'", name);
     }
+    return BH_OK;
+}
+
+int bh_index_set_option(bh_index* ix, const char* name, int64_t value) {
+    if (!ix) return fail(BH_EINVAL, "null index");
+    if (!name) return fail(BH_EINVAL, "null option name");
+    const OptionDef* d = find_option(name);
+    if (!d) return fail(BH_EINVAL, "unknown per-index option '%s'", name);
+    const size_t slot = (size_t)(d - g_option_defs);
+    if (value == BH_OPTION_INHERIT) {
+        ix->opt_override[slot] = kUnset;
+        return BH_OK;
+    }
+    if (!option_accepts(*d, value)) return fail(BH_EINVAL, "%s", d->expect);
+    ix->opt_override[slot] = (int)value;
     return BH_OK;
 }
 
@@ -496,16 +536,17 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     if (!q_dev || !out_scores_dev || !out_ids_dev) return fail(BH_EINVAL, "null buffer");
     HIP_TRY(hipSetDevice(ix->device));
 
+    const Options opt = effective_options(ix);  // one snapshot per search: process-wide values + this handle's overrides
     const int dp = ix->dim_padded;
-    int qw = (g_opt.query_tile == 256 && bh_scan_supports(dp, kp, 2)) ? 2 : 1;
-    const bool use256 = g_opt.scan_kernel == 3 && bh_scan256_supports(dp, kp);
-    const bool use192 = g_opt.scan_kernel == 2 && bh_scan192_supports(dp, kp);
+    int qw = (opt.query_tile == 256 && bh_scan_supports(dp, kp, 2)) ? 2 : 1;
+    const bool use256 = opt.scan_kernel == 3 && bh_scan256_supports(dp, kp);
+    const bool use192 = opt.scan_kernel == 2 && bh_scan192_supports(dp, kp);
     if (use192 || use256) qw = 1;
     const int bq = use256 ? bh_scan256_tile(dp) : use192 ? 192 : 128 * qw;
-    const int grid = ix->n_cu * g_opt.workgroups_per_cu;
+    const int grid = ix->n_cu * opt.workgroups_per_cu;
     // passes: a launch scans for qs * bq queries (qs = 2: paired workgroups share the corpus stream through L2,
     // scan_topk.hip); the last queries run unsplit when no more than bq are left
-    const int qs_max = (g_opt.query_split == 2 && grid % 16 == 0 && !use192 && !use256) ? 2 : 1;
+    const int qs_max = (opt.query_split == 2 && grid % 16 == 0 && !use192 && !use256) ? 2 : 1;
     std::vector<std::pair<int, int>> passes;  // (first query, qs)
     for (int q0 = 0; q0 < nq;) {
         const int qs = (qs_max == 2 && nq - q0 > bq) ? 2 : 1;
@@ -540,7 +581,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     }
     *ix->n_uncert_host = 0u;
     // |mfma - canonical| <= 2 d 2^-24 |q| |x| for any summation order of d exact products in fp32
-    const float err_coef = g_opt.certify ? 2.0f * (float)dp * 5.9604645e-8f * ix->max_norm * (float)g_opt.err_scale : 0.f;
+    const float err_coef = opt.certify ? 2.0f * (float)dp * 5.9604645e-8f * ix->max_norm * (float)opt.err_scale : 0.f;
 
     hipStream_t st = ix->stream;
     if (!ix->merge_stream) HIP_TRY(hipStreamCreateWithFlags(&ix->merge_stream, hipStreamNonBlocking));
@@ -554,7 +595,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     if (!ev_begin || !ev_end) return fail(BH_EHIP, "hipEventCreate failed");
     // scan_topk256: a last pass of at most 128 queries (2 837 = 11 x 256 + 21) runs on the 128-query kernel — the same
     // corpus pass costs 5.6 instead of 7.2 ms there —, as a group of its own (its lists are 128 queries wide)
-    const bool tail128 = grouped && use256 && bq == 256 && g_opt.tail128 && g_opt.ablate == 0 && nq % bq != 0 && nq % bq <= 128;
+    const bool tail128 = grouped && use256 && bq == 256 && opt.tail128 && opt.ablate == 0 && nq % bq != 0 && nq % bq <= 128;
     const int n_main = tail128 ? n_pass - 1 : n_pass;
     const int n_group = grouped ? (n_main + group - 1) / group + (tail128 ? 1 : 0) : n_pass;
     for (int p = 0; p < n_group; ++p)
@@ -576,14 +617,14 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         sa.cand = ix->cand.p;
         sa.partial = partial_p;
         sa.gthr = ix->gthr.p + gthr_pass * (size_t)p;
-        sa.share = g_opt.share_threshold;
-        sa.nontemporal = g_opt.nontemporal;
-        sa.ablate = g_opt.ablate;
-        sa.ring_variant = g_opt.ring_variant;
+        sa.share = opt.share_threshold;
+        sa.nontemporal = opt.nontemporal;
+        sa.ablate = opt.ablate;
+        sa.ring_variant = opt.ring_variant;
         sa.qsplit = qs;
-        sa.dma_interleave = g_opt.dma_interleave;
-        sa.pair_window = g_opt.pair_window;
-        sa.dyn_tiles = g_opt.dyn_tiles;
+        sa.dma_interleave = opt.dma_interleave;
+        sa.pair_window = opt.pair_window;
+        sa.dyn_tiles = opt.dyn_tiles;
         sa.clk = use256 ? ix->clk.p : nullptr;
         sa.progress = ix->gthr.p + gthr_pass * (size_t)n_pass;  // [grid] words behind the threshold blocks
         return sa;
@@ -603,9 +644,9 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         ma.out_scores = out_scores_dev + (size_t)q0 * k;
         ma.out_ids = reinterpret_cast<long long*>(out_ids_dev) + (size_t)q0 * k;
         ma.err_coef = err_coef;
-        ma.uncert = g_opt.certify ? ix->uncert.p + q0 : nullptr;
-        ma.kth_key = g_opt.certify ? ix->kth.p + q0 : nullptr;
-        ma.n_uncert = g_opt.certify ? ix->n_uncert_dev : nullptr;
+        ma.uncert = opt.certify ? ix->uncert.p + q0 : nullptr;
+        ma.kth_key = opt.certify ? ix->kth.p + q0 : nullptr;
+        ma.n_uncert = opt.certify ? ix->n_uncert_dev : nullptr;
         return ma;
     };
     auto launch_scan = [&](const BhScanArgs& sa) {
@@ -631,9 +672,33 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         if (tail128) {
             const int gi = n_group - 1, p = n_pass - 1, q0 = passes[p].first;
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi), st));
-            BhScanArgs sa = scan_args(p, ix->partial.p);  // (stream order: the main groups' merges are done with the lists)
-            sa.clk = nullptr;
+            // The tail pass runs a DIFFERENT kernel (scan_topk.hip, 128 queries) inside buffers sized for the 256-query kernel:
+            // its needs are stated and checked here instead of being implied by the other kernel's layout.
+            //   thresholds  [128][64] words at ordf(-inf): the head of this pass's threshold block, which the fill above set
+            //               — the block's claim counter (the one word that is not ordf(-inf)) sits behind the slot tables
+            //   candidates  [grid][128][2 * kp] keys, result lists [grid][128][kp] keys
+            const size_t tail_gthr = (size_t)128 * 64, tail_cand = (size_t)grid * 128 * 2 * kp, tail_lists = (size_t)grid * 128 * kp;
+            if (tail_gthr > (size_t)bq * (BH_SLOTS256 + 1) || gthr_pass * (size_t)p + tail_gthr > ix->gthr.cap ||
+                tail_cand > ix->cand.cap || tail_lists > ix->partial.cap)
+                return fail(BH_EHIP, "internal: the 128-query tail pass does not fit the 256-query kernel's buffers");
+            BhScanArgs sa{};
+            sa.corpus = ix->rows;
+            sa.n_rows = ix->n_rows;
+            sa.n_tiles = ix->n_tiles;
+            sa.qtile = ix->qbuf.p + (size_t)q0 * dp;
+            sa.cand = ix->cand.p;
+            sa.partial = ix->partial.p;  // (stream order: the main groups' merges are done with the lists)
+            sa.gthr = ix->gthr.p + gthr_pass * (size_t)p;
+            sa.share = opt.share_threshold;
+            sa.nontemporal = opt.nontemporal;
+            sa.ablate = 0;
+            sa.ring_variant = 0;
             sa.qsplit = 1;
+            sa.progress = nullptr;  // (paired workgroups only)
+            sa.dma_interleave = opt.dma_interleave;
+            sa.pair_window = 0;
+            sa.dyn_tiles = 0;
+            sa.clk = nullptr;
             HIP_TRY(bh_launch_scan(sa, dp, kp, 1, grid, st));
             alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + 128.0 * ix->dim * 2.0 + 128.0 * k * 12.0;
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 1), st));
@@ -668,7 +733,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     // ---- exactness: queries the certificate could not prove go through the exact scan (certify.hip)
     int64_t n_uncert = 0, n_filter_passes = 0, n_filter_rows = 0;
     double exact_ms = 0;
-    if (g_opt.certify && *ix->n_uncert_host != 0u) {
+    if (opt.certify && *ix->n_uncert_host != 0u) {
         std::vector<unsigned> flags((size_t)nq);
         HIP_TRY(hipMemcpyAsync(flags.data(), ix->uncert.p, (size_t)nq * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -990,7 +1055,37 @@ int bh_merge_topk_device(const float* scores_dev, const int64_t* ids_dev, int32_
         HIP_TRY(hipStreamSynchronize(nullptr));
         return BH_OK;
     }
-    if (group < 2) return fail(BH_EUNSUPPORTED, "k=%d too large to merge %d lists", k, n_lists);
+    if (group < 2) {
+        // k > 2048: two lists no longer fit one launch of the merge kernel (4096 keys).  The lists are short and few (one per
+        // shard / rank): merge them on the host — a k-way merge of sorted lists in the canonical order, ids < 0 skipped —
+        // exactly like search_large_k merges its ranges.
+        const size_t per = (size_t)nq * k;
+        std::vector<float> hs((size_t)n_lists * per), os(per);
+        std::vector<long long> hi((size_t)n_lists * per), oi(per);
+        HIP_TRY(hipMemcpy(hs.data(), scores_dev, hs.size() * sizeof(float), hipMemcpyDefault));
+        HIP_TRY(hipMemcpy(hi.data(), ids_dev, hi.size() * sizeof(long long), hipMemcpyDefault));
+        std::vector<std::pair<float, long long>> all;
+        for (int q = 0; q < nq; ++q) {
+            all.clear();
+            for (int l = 0; l < n_lists; ++l)
+                for (int t = 0; t < k; ++t) {
+                    const size_t at = (size_t)l * per + (size_t)q * k + t;
+                    if (hi[at] >= 0) all.emplace_back(hs[at], hi[at]);
+                }
+            const size_t take = std::min<size_t>(all.size(), (size_t)k);
+            std::partial_sort(all.begin(), all.begin() + take, all.end(),
+                              [](const std::pair<float, long long>& a, const std::pair<float, long long>& b) {
+                                  return a.first != b.first ? a.first > b.first : a.second < b.second;
+                              });
+            for (size_t t = 0; t < (size_t)k; ++t) {
+                os[(size_t)q * k + t] = t < take ? all[t].first : -INFINITY;
+                oi[(size_t)q * k + t] = t < take ? all[t].second : -1;
+            }
+        }
+        HIP_TRY(hipMemcpy(out_scores_dev, os.data(), os.size() * sizeof(float), hipMemcpyDefault));
+        HIP_TRY(hipMemcpy(out_ids_dev, oi.data(), oi.size() * sizeof(long long), hipMemcpyDefault));
+        return BH_OK;
+    }
     // tree reduction: merge `group` lists at a time into a scratch set of lists
     const int n_mid = (n_lists + group - 1) / group;
     float* mid_s = nullptr;
@@ -1058,7 +1153,8 @@ int64_t bh_debug_scan_timeline(const bh_index* ix, uint64_t* out, int64_t max_wo
 
 int bh_bench_counters(const bh_index* ix, bh_counters* out) {
     if (!ix || !out) return fail(BH_EINVAL, "null argument");
-    *out = ix->counters;
+    if (!bh_copy_sized(out, ix->counters, 16))
+        return fail(BH_EINVAL, "bh_counters.struct_size = %d: set it to sizeof(bh_counters) before the call (BH_VERSION %d)", out->struct_size, BH_VERSION);
     return BH_OK;
 }
 

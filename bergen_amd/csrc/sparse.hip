@@ -54,6 +54,7 @@ struct bh_sparse_index {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_b[4] = {nullptr, nullptr, nullptr, nullptr};  // timing events of odd query tiles (tiles are pipelined in pairs)
     bh_counters counters{};
+    int opt_kernel = -1, opt_head = -1, opt_ablate = -1;  // per-handle overrides (bh_sparse_set_option); -1 = the process-wide value
 };
 
 namespace {
@@ -371,10 +372,14 @@ static int sparse_search_view(bh_sparse_index* ix, int64_t view_lo, int64_t view
             }
         }
     }
-    const bool mfma = g_sparse_kernel == 1;
+    // options: read once per search, this handle's override first
+    const int o_kernel = ix->opt_kernel >= 0 ? ix->opt_kernel : g_sparse_kernel;
+    const int o_head = ix->opt_head >= 0 ? ix->opt_head : g_sparse_head;
+    const int o_ablate = ix->opt_ablate >= 0 ? ix->opt_ablate : g_sparse_ablate;
+    const bool mfma = o_kernel == 1;
     // the MFMA scan on the corpus-head tiles + tail stream: a query's weights of the 64 corpus-head terms go into WgT (matrix
     // cores), only its other terms enter the tile's term set
-    const bool use_head = mfma && ix->has_head && g_sparse_head != 0;
+    const bool use_head = mfma && ix->has_head && o_head != 0;
     std::vector<std::vector<std::pair<int, unsigned short>>> qnz_tail;
     if (use_head) {
         qnz_tail.resize((size_t)nq);
@@ -600,7 +605,7 @@ static int sparse_search_view(bh_sparse_index* ix, int64_t view_lo, int64_t view
             ma2.cand = ix->cand.p;
             ma2.partial = ix->partial.p + (size_t)par * partial_elems;
             ma2.gthr = ix->gthr.p;
-            ma2.ablate = g_sparse_ablate;
+            ma2.ablate = o_ablate;
             // Non-negative corpus and tile: scores are >= 0, a zero-score document can only enter a top-k that has fewer
             // than k positive documents, and then it is simply one of the lowest row ids.  The scan then never collects
             // zero-score documents (threshold floor 0, exclusive) and the merge fills short lists with the lowest absent rows.
@@ -820,9 +825,29 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
     return sparse_search_view(ix, 0, ix->n_rows, q_host, q_dtype, nq, std::min<int32_t>(k, kSparseListK), id_offset, out_scores, out_ids);
 }
 
+int bh_sparse_set_option(bh_sparse_index* ix, const char* name, int64_t value) {
+    if (!ix) return bh_fail(BH_EINVAL, "null index");
+    if (!name) return bh_fail(BH_EINVAL, "null option name");
+    const bool inherit = value == BH_OPTION_INHERIT;
+    if (strcmp(name, "sparse_kernel") == 0) {
+        if (!inherit && value != 0 && value != 1) return bh_fail(BH_EINVAL, "sparse_kernel must be 0 (broadcast) or 1 (mfma)");
+        ix->opt_kernel = inherit ? -1 : (int)value;
+    } else if (strcmp(name, "sparse_head") == 0) {
+        if (!inherit && value != 0 && value != 1) return bh_fail(BH_EINVAL, "sparse_head must be 0 (plain CSR stream) or 1 (corpus-head tiles + tail stream)");
+        ix->opt_head = inherit ? -1 : (int)value;
+    } else if (strcmp(name, "sparse_ablate") == 0) {
+        if (!inherit && (value < 0 || value > 1023)) return bh_fail(BH_EINVAL, "sparse_ablate must be 0..1023");
+        ix->opt_ablate = inherit ? -1 : (int)value;
+    } else {
+        return bh_fail(BH_EINVAL, "unknown per-index sparse option '%s'", name);
+    }
+    return BH_OK;
+}
+
 int bh_sparse_counters(const bh_sparse_index* ix, bh_counters* out) {
     if (!ix || !out) return bh_fail(BH_EINVAL, "null argument");
-    *out = ix->counters;
+    if (!bh_copy_sized(out, ix->counters, 16))
+        return bh_fail(BH_EINVAL, "bh_counters.struct_size = %d: set it to sizeof(bh_counters) before the call (BH_VERSION %d)", out->struct_size, BH_VERSION);
     return BH_OK;
 }
 

@@ -16,6 +16,7 @@ search kernel avoids); `bergen_amd.retrieve.Retrieve` never calls it.
 """
 import logging
 import os
+import threading
 from abc import ABC, abstractmethod
 
 import torch
@@ -118,6 +119,10 @@ class CosineSim:
         return _unit_rows(q) @ _unit_rows(d).transpose(0, 1)
 
 
+_TOKENIZER_CONFIG_LOCK = threading.Lock()
+_FAST_TOKENIZE_WARNED = False
+
+
 def fast_tokenize(tokenizer, texts, max_len):
     """`tokenizer(texts, padding="longest", truncation="longest_first", max_length=max_len, return_tensors='pt')` for a
     Rust-backed (PreTrainedTokenizerFast) tokenizer, without the Python post-processing of that call: HF configures the
@@ -125,8 +130,12 @@ def fast_tokenize(tokenizer, texts, max_len):
     parallel, and releases the GIL — and then rebuilds every Encoding field by field in Python and pads again before the
     tensor conversion, which is 5-10x the encoding time (46 of 50 ms per 512 passages on the GPU box's host).  Here the
     padded ids / type ids / mask are read straight from the backend's Encodings.  Same values as the HF call
-    (tests/test_host.py::test_fast_tokenize_equals_the_hf_call); None for a slow (Python) tokenizer or any surprise — the
-    caller then makes the HF call."""
+    (tests/test_host.py::test_fast_tokenize_equals_the_hf_call); None for a slow (Python) tokenizer — the caller then makes
+    the HF call; any other surprise is logged once and answered the same way.
+    Thread safety (the stage tokenises on `num_workers` threads, retrieve.py `_threaded_batches`): the backend tokenizer is
+    CONFIGURED under a lock — HF's set_truncation_and_padding only mutates it when the requested settings differ from the
+    current ones, so after the first call it is a read — and encode_batch, which borrows the backend immutably and releases
+    the GIL, runs outside the lock.  A mutation while another thread encodes would raise PyO3's "Already borrowed"."""
     try:
         import numpy as np
         from transformers.tokenization_utils_base import BatchEncoding
@@ -135,8 +144,9 @@ def fast_tokenize(tokenizer, texts, max_len):
         backend = getattr(tokenizer, "backend_tokenizer", None)
         if backend is None or not getattr(tokenizer, "is_fast", False) or not hasattr(tokenizer, "set_truncation_and_padding"):
             return None
-        tokenizer.set_truncation_and_padding(padding_strategy=PaddingStrategy.LONGEST, truncation_strategy=TruncationStrategy.LONGEST_FIRST,
-                                             max_length=max_len, stride=0, pad_to_multiple_of=None, padding_side=None)
+        with _TOKENIZER_CONFIG_LOCK:
+            tokenizer.set_truncation_and_padding(padding_strategy=PaddingStrategy.LONGEST, truncation_strategy=TruncationStrategy.LONGEST_FIRST,
+                                                 max_length=max_len, stride=0, pad_to_multiple_of=None, padding_side=None)
         encode = getattr(backend, "encode_batch_fast", None) or backend.encode_batch  # (_fast: no offsets, the fields used here are the same)
         encs = encode(list(texts), add_special_tokens=True)
         names = list(getattr(tokenizer, "model_input_names", ["input_ids", "token_type_ids", "attention_mask"]))
@@ -148,7 +158,11 @@ def fast_tokenize(tokenizer, texts, max_len):
         if "attention_mask" in names:
             out["attention_mask"] = torch.from_numpy(np.array([e.attention_mask for e in encs], dtype=np.int64))
         return BatchEncoding(out)
-    except Exception:
+    except Exception as e:  # noqa: BLE001 — the HF call below is the same tokenisation, only slower; say so once
+        global _FAST_TOKENIZE_WARNED
+        if not _FAST_TOKENIZE_WARNED:
+            _FAST_TOKENIZE_WARNED = True
+            logging.getLogger("bergen_amd").warning("fast_tokenize fell back to the HF tokenizer call: %s: %s", type(e).__name__, e)
         return None
 
 

@@ -158,6 +158,11 @@ class FlatIndex:
         _lib.check(_lib.lib().bh_bench_counters(self._h, ctypes.byref(c)))
         return {name: getattr(c, name) for name, _ in c._fields_}
 
+    def set_option(self, name, value=None):
+        """Override a dense-search option for THIS index only (`_lib.set_option` sets the process-wide default every
+        index without an override follows); `value=None` drops the override."""
+        _lib.check(_lib.lib().bh_index_set_option(self._h, name.encode(), _lib.BH_OPTION_INHERIT if value is None else int(value)))
+
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
         if self._h is not None:

@@ -111,18 +111,32 @@ class ShardedSearcher:
         nbs = nq * k * 4
         buf["all_s"].view(self.world_size, nq * k).copy_(gathered[:, :nbs].view(torch.float32))
         buf["all_i"].view(self.world_size, nq * k).copy_(gathered[:, buf["ids_at"]:].view(torch.int64))
-        if self._merge_takes_out:
-            out_s, out_i = self.merge(buf["all_s"], buf["all_i"], out=buf["out"])
-        else:
-            out_s, out_i = self.merge(buf["all_s"], buf["all_i"])
+        try:
+            if self._merge_takes_out:
+                out_s, out_i = self.merge(buf["all_s"], buf["all_i"], out=buf["out"])
+            else:
+                out_s, out_i = self.merge(buf["all_s"], buf["all_i"])
+        except Exception as e:
+            # the other ranks of a broadcast=True search are already waiting in the broadcast below: send them the failure
+            # instead of leaving them there until the collective times out, then raise here
+            if broadcast:
+                self._broadcast(buf, None, failed=True)
+            raise RuntimeError(f"merge of the {self.world_size} shards' lists failed on rank {self.rank}: {e}") from e
         out_s, out_i = torch.as_tensor(out_s), torch.as_tensor(out_i)
         return self._broadcast(buf, (out_s, out_i)) if broadcast else (out_s, out_i)
 
-    def _broadcast(self, buf, merged):
-        """Merged lists from rank `dst` to every rank, through the packed send buffer (its local lists are spent)."""
+    _FAILED = -(1 << 62)  # id no search produces (row ids are >= -1): rank dst's merge failed
+
+    def _broadcast(self, buf, merged, failed=False):
+        """Merged lists from rank `dst` to every rank, through the packed send buffer (its local lists are spent).  A merge
+        that failed on `dst` travels the same way (the first id holds _FAILED): every rank raises."""
         if merged is not None:
             buf["scores"].copy_(merged[0])
             buf["ids"].copy_(merged[1])
+        elif failed:
+            buf["ids"].fill_(self._FAILED)
         src = dist.get_global_rank(self.group, self.dst) if self.group is not None else self.dst
         dist.broadcast(buf["packed"], src=src, group=self.group)
+        if not failed and buf["ids"].numel() and int(buf["ids"].view(-1)[0]) == self._FAILED:
+            raise RuntimeError(f"sharded search: the merge of the shards' lists failed on rank {self.dst} (see its error)")
         return buf["scores"], buf["ids"]

@@ -133,6 +133,10 @@ class SparseIndex:
         _lib.check(_lib.lib().bh_sparse_counters(self._h, ctypes.byref(c)))
         return {name: getattr(c, name) for name, _ in c._fields_}
 
+    def set_option(self, name, value=None):
+        """Override "sparse_kernel" / "sparse_head" / "sparse_ablate" for THIS index only; `value=None` drops the override."""
+        _lib.check(_lib.lib().bh_sparse_set_option(self._h, name.encode(), _lib.BH_OPTION_INHERIT if value is None else int(value)))
+
     def close(self):
         if self._h is not None:
             _lib.lib().bh_sparse_destroy(self._h)

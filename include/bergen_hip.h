@@ -25,7 +25,15 @@
 extern "C" {
 #endif
 
-#define BH_VERSION 130 /* 0.1.3: + 256-query-tile scan (two waves per SIMD), clock / timeline diagnostics */
+/* ABI version = major * 1000 + minor * 10 + patch.  It is bumped whenever a struct of this header changes size or layout or an
+ * entry point changes meaning; a caller compares bh_version() with the BH_VERSION it was compiled against before any other
+ * call.  History: 130 = 0.1.3 (round 2: 256-query-tile scan, clock / timeline diagnostics); 140 = 0.1.4 (round 4): every
+ * struct the library WRITES or READS through a caller's pointer now starts with `struct_size` (the caller's sizeof — the
+ * library never touches bytes beyond it, so a caller built against an older, shorter struct stays memory-safe and a newer,
+ * longer one gets zeros in the fields this build does not know); bh_counters grew the fall-back / tail-pass fields (they were
+ * added under 130 without a bump: VERDICT r3); + bh_index_set_option / bh_sparse_set_option (per-handle options),
+ * bh_encoder_set_rel_index (DeBERTa). */
+#define BH_VERSION 140
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -47,6 +55,8 @@ typedef struct bh_index bh_index;
 /* Kernel-time / traffic counters of the most recent bh_search* call on an index
  * (consumed by bench.py's `roofline` object). */
 typedef struct bh_counters {
+    int32_t struct_size;      /* IN: sizeof(bh_counters) as the CALLER was compiled; the library writes at most that many bytes */
+    int32_t reserved_head;
     int64_t n_rows;           /* rows resident in this index */
     int32_t dim;              /* logical dim */
     int32_t dim_padded;       /* row stride in elements (multiple of 64) */
@@ -131,7 +141,9 @@ int bh_merge_topk(const float* scores, const int64_t* ids, int32_t n_lists, int3
 int bh_merge_topk_device(const float* scores_dev, const int64_t* ids_dev, int32_t n_lists,
                          int32_t nq, int32_t k, float* out_scores_dev, int64_t* out_ids_dev);
 
-/* Counters of the last search on this index. */
+/* Counters of the last search on this index.  `out->struct_size` must hold the caller's sizeof(bh_counters) on entry
+ * (BH_EINVAL when it is smaller than the round-2 prefix of the struct, 16 bytes); the library fills min(that, its own
+ * sizeof) bytes and leaves the rest untouched. */
 int bh_bench_counters(const bh_index* ix, bh_counters* out);
 
 /* Diagnostics: copies up to max_words 64-bit words of the last scan launch's record (scan_topk256.hip: 8 words per
@@ -140,17 +152,30 @@ int bh_bench_counters(const bh_index* ix, bh_counters* out);
  * `out`; returns the number of words written or a negative error code. */
 int64_t bh_debug_scan_timeline(const bh_index* ix, uint64_t* out, int64_t max_words);
 
-/* Tuning knobs (process-wide; bench sweeps and A/B comparisons; results are identical for every valid setting).
+/* Tuning knobs; results are identical for every valid setting.  TWO LEVELS:
+ *   bh_set_option        PROCESS-WIDE defaults.  Every handle that has no override of its own sees the new value from its
+ *                        next search on; a running search is not affected (each search reads the options once, up front).
+ *                        Not meant to be toggled concurrently with searches of OTHER threads' handles that rely on a
+ *                        particular value: give those handles their own value with the per-handle call.
+ *   bh_index_set_option  (and bh_sparse_set_option): PER-HANDLE override of the dense-search (sparse-search) options, visible to
+ *                        that handle only — the independence of handles per GPU / thread SURVEY section 8b promises.
+ *                        BH_OPTION_INHERIT as the value drops the override.
+ * The encoder's options have always been per handle (bh_encoder_set_option); "gemm_stagger_*" are process-wide only.
+ * Names (bench sweeps and A/B comparisons):
  * Dense scan: "query_tile" (128|256), "share_threshold" (0|1), "nontemporal" (0|1), "dma_interleave" (0|1, default 1),
  * "query_split" (1|2: paired workgroups share the corpus stream through L2), "pair_window" (0..64), "scan_kernel"
  * (3 = 256-query tile [128 at d = 1024], two waves per SIMD, where it applies [d in {384, 512, 768, 1024}] else the
  * 4-wave kernel, default; 2 = 192-query tile where it applies [d = 768, k <= 56]; 0 = 4-wave kernel, 128-query tile),
  * "dyn_tiles" (0|1, default 1: the last eighth of the corpus is handed out by a claim counter), "certify" (0|1, default
- * 1: exactness certificate + exact fall-back scan), "ring_variant" (0..7: bench-only variants of the selected kernel).
+ * 1: exactness certificate + exact fall-back scan), "ring_variant" (0..7: bench-only variants of the selected kernel),
+ * "tail128" (0|1, default 1), "filter256" (0|1, default 1: the exact fall-back's filter passes take 256 queries on the
+ * 256-query kernel where it applies), "pair256" (0|1: paired workgroups for the 256-query kernel), "certificate_error_scale" (tests).
  * Sparse scan: "sparse_kernel"
  * (1 = csr_mfma.hip, default; 0 = csr_topk.hip).  Encoder GEMM: "gemm_stagger_phases", "gemm_stagger_pct".
  * "ablate" / "sparse_ablate" switch parts of the kernels OFF for profiling: results are INVALID while they are set. */
 int bh_set_option(const char* name, int64_t value);
+#define BH_OPTION_INHERIT INT64_MIN
+int bh_index_set_option(bh_index* ix, const char* name, int64_t value);
 
 /* Bi-encoder forward pass (BERT-architecture dense retrievers) ------------------------------ */
 
@@ -158,6 +183,7 @@ int bh_set_option(const char* name, int64_t value);
  * (models/retrievers/dense.py:16): post-LN transformer encoder, absolute position embeddings,
  * head dim 64.  RetroMAE / contriever / e5 / bge checkpoints are all of this class. */
 typedef struct bh_encoder_config {
+    int32_t struct_size;     /* sizeof(bh_encoder_config) as the caller was compiled; fields beyond it read as 0 */
     int32_t n_layers;        /* num_hidden_layers */
     int32_t hidden;          /* hidden_size (multiple of 64; = n_heads * head_dim) */
     int32_t n_heads;         /* num_attention_heads */
@@ -180,6 +206,7 @@ typedef struct bh_encoder bh_encoder;
 
 /* Counters of the most recent bh_encoder_forward (encoder roofline = MFMA). */
 typedef struct bh_encoder_counters {
+    int32_t struct_size;  /* IN: sizeof(bh_encoder_counters) as the caller was compiled; the library writes at most that many bytes */
     int32_t batch;        /* sequences */
     int32_t seq_len;      /* padded length of the input matrix */
     int64_t real_tokens;  /* tokens with attention_mask != 0 */
@@ -289,6 +316,8 @@ int bh_sparse_search(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, i
                      int64_t id_offset, float* out_scores, int64_t* out_ids);
 /* Counters of the last bh_sparse_search (dim = vocab; algorithmic_bytes = passes * (nnz*4 + (N+1)*8)). */
 int bh_sparse_counters(const bh_sparse_index* ix, bh_counters* out);
+/* Per-handle override of "sparse_kernel" / "sparse_head" / "sparse_ablate" (see bh_set_option). */
+int bh_sparse_set_option(bh_sparse_index* ix, const char* name, int64_t value);
 void bh_sparse_destroy(bh_sparse_index* ix);
 
 #ifdef __cplusplus

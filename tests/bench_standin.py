@@ -86,4 +86,6 @@ class OracleEnv:
 
 
 if __name__ == "__main__":
-    bench.run(bench.parse_args(), OracleEnv(int(os.environ.get("LOCAL_RANK", "0"))))
+    _args = bench.parse_args()
+    bench.launch_ranks_if_needed(_args, script=__file__)  # `--gpus N` without a launcher starts its own ranks (bench.main does the same)
+    bench.run(_args, OracleEnv(int(os.environ.get("LOCAL_RANK", "0"))))

@@ -18,14 +18,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, extra):
+def _run(world, extra, launcher=True):
     flags = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-rows", "30011", "--queries", "37", "--no-encoder",
              "--no-cpu-baseline", "--no-other-kernels", "--no-larger-k", "--no-config5", "--no-stage", "--no-certificate-leg", "--no-splade"] + extra
     script = os.path.join(ROOT, "tests", "bench_standin.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    if world == 1:
+    if world == 1 or not launcher:
         cmd = [sys.executable, script] + flags
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -48,6 +48,13 @@ def test_bench_line_of_a_multi_rank_run(world):
     assert f"row-shard x{world}" in r["config"]["parallelism"]
     for key in ("roofline", "kernel_ms_per_step", "uncertified_queries", "vs_baseline", "dtype", "data", "metric"):
         assert key in r
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` typed by hand (no torchrun, no WORLD_SIZE): bench.launch_ranks_if_needed starts the ranks with
+    the driver's own command instead of dying on an assert (VERDICT r3 weak #7)."""
+    r = _run(2, [], launcher=False)
+    assert r["n_gpus"] == 2 and r["parity_check"] == "pass" and "row-shard x2" in r["config"]["parallelism"]
 
 
 def test_single_rank_standin_agrees():
