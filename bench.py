@@ -53,11 +53,12 @@ def parse_args():
     p.add_argument("--share-threshold", type=int, default=None)
     p.add_argument("--nontemporal", type=int, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--full-list-queries", type=int, default=8,
-                   help="queries whose COMPLETE top-k lists the parity gate recomputes over the whole corpus (N = 1; 0 = off)")
+    p.add_argument("--full-list-queries", type=int, default=32,
+                   help="queries whose COMPLETE top-k lists the parity gate recomputes over the whole corpus, spread over the first, a middle, the last full and the tail pass (N = 1; 0 = off)")
     p.add_argument("--no-other-kernels", action="store_true", help="skip the secondary figures of the earlier scan kernels")
     p.add_argument("--no-larger-k", action="store_true", help="skip the k = 100 / 200 / 1000 legs at the headline geometry")
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
+    p.add_argument("--no-real-size", action="store_true", help="skip the headline search at KILT-100w's real row count (24 853 637 rows)")
     p.add_argument("--no-certificate-leg", action="store_true", help="skip the certificate / fall-back leg on the clustered, non-unit-norm corpus")
     p.add_argument("--encode-stage-passages", type=int, default=16384, help="passages of the Retrieve.encode_and_save leg (0 = skip)")
     p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg at the headline size (resident index -> doc-id strings)")
@@ -95,9 +96,10 @@ def plant_table(nq, n_total):
     return torch.randint(0, n_total, (nq, 5), generator=gp)  # global rows, same on every rank
 
 
-def corpus_block(b, dim, queries, plant_rows, n_total, device):
+def corpus_block(b, dim, queries, plant_rows, n_total, device, scaled=False):
     """Block b (rows [b * BLOCK, ...)) of the synthetic corpus as fp16 device rows, plus the (query, j) plants inside it —
-    the one recipe behind the index fill, the re-scoring gate and the streaming full-list gate."""
+    the one recipe behind the index fill, the re-scoring gate and the streaming full-list gate.  scaled: every row is
+    stretched by its own factor in [0.25, 4.25) (a cosine index has to undo that at finalize)."""
     b0 = b * BLOCK
     m = min(BLOCK, n_total - b0)
     g = torch.Generator(device=device).manual_seed(1000 + b)
@@ -107,11 +109,28 @@ def corpus_block(b, dim, queries, plant_rows, n_total, device):
         r = int(plant_rows[qi, j])
         gn = torch.Generator(device=device).manual_seed(7_000_000 + qi * 5 + j)
         noise = torch.randn(dim, generator=gn, device=device) * (0.3 / dim ** 0.5)
-        rows[r - b0] = torch.nn.functional.normalize(queries[qi].float() + noise, dim=0)
+        base = queries[qi].float()
+        if scaled:  # (the cosine legs' queries are not unit length; the headline recipe is unchanged)
+            base = torch.nn.functional.normalize(base, dim=0)
+        rows[r - b0] = torch.nn.functional.normalize(base + noise, dim=0)
+    if scaled:
+        rows = rows * (0.25 + 4.0 * torch.rand(m, 1, generator=g, device=device))
     return rows.half(), sel
 
 
-def fill_shard(ix, lo, hi, dim, queries, n_total, device):
+def canonical_unit_rows(x):
+    """The library's cosine normalisation (bergen_amd/csrc/convert.hip, restating CosineSim of reference dense.py:87-88) in plain
+    torch IEEE operations, no kernel of this repository: n2 = sum of x_j^2 in fp64 (exact in any order: fp16 squares are
+    multiples of 2^-48 and the sum stays far below 2^5, so no addition rounds), inv = 1 / sqrt(n2) (two correctly rounded fp64
+    operations), y_j = fp16(fp32(fp64(x_j) * inv)) — product rounded to fp64, then to fp32, then to fp16, each to nearest even.
+    Zero rows stay zero."""
+    x64 = x.double()
+    n2 = (x64 * x64).sum(dim=1, keepdim=True)
+    inv = torch.where(n2 > 0, 1.0 / torch.sqrt(n2), torch.zeros_like(n2))
+    return (x64 * inv).float().half()
+
+
+def fill_shard(ix, lo, hi, dim, queries, n_total, device, scaled=False):
     """Upload rows [lo, hi) of the synthetic corpus into ix (local row = global row - lo)."""
     nq = queries.shape[0]
     plant_rows = plant_table(nq, n_total)
@@ -121,7 +140,7 @@ def fill_shard(ix, lo, hi, dim, queries, n_total, device):
         b0 = b * BLOCK
         if n_total - b0 <= 0:
             break
-        rows, sel = corpus_block(b, dim, queries, plant_rows, n_total, device)
+        rows, sel = corpus_block(b, dim, queries, plant_rows, n_total, device, scaled=scaled)
         a, e = max(lo, b0), min(hi, b0 + rows.shape[0])
         if e > a:
             ix.upload(rows[a - b0:e - b0].contiguous(), row0=a - lo)
@@ -133,19 +152,27 @@ def fill_shard(ix, lo, hi, dim, queries, n_total, device):
     return planted, plant_rows
 
 
-def streamed_full_lists(n_check, queries, dim, k, plant_rows, n_total, device):
-    """The COMPLETE top-k lists of the first n_check queries, computed without any of this repository's kernels: the
-    corpus is regenerated block by block, every block is scored with a float64 matrix product (torch / rocBLAS), rounded to
-    fp32, and the rows that can still be in the top k are kept; the union is ordered (score desc, row asc) at the end.
+def streamed_full_lists(check, queries, dim, k, plant_rows, n_total, device, metric="ip", scaled=False):
+    """The COMPLETE top-k lists of the queries `check` (an int n = the first n, or a list of query indices), computed without
+    any of this repository's kernels: the corpus is regenerated block by block, every block is scored with a float64 matrix
+    product (torch / rocBLAS), rounded to fp32, and the rows that can still be in the top k are kept; the union is ordered
+    (score desc, row asc) at the end.  metric "cos": queries and rows first go through canonical_unit_rows (plain torch).
     Why a float64 GEMM in ANY summation order gives the canonical score (= fp32 of the sequential fp64 sum) here: fp16
     values are multiples of 2^-24, so every product and every partial sum is a multiple of 2^-48; with
     sum_j |q_j x_j| <= |q| |x| < 16 (checked below; the rows are unit-norm) every partial sum has fewer than 53
     significant bits — no fp64 operation rounds, whatever its order."""
-    q64 = queries[:n_check].double()
+    idx = list(range(check)) if isinstance(check, int) else [int(c) for c in check]
+    n_check = len(idx)
+    qsel = queries[torch.as_tensor(idx, device=queries.device)]
+    if metric == "cos":
+        qsel = canonical_unit_rows(qsel)
+    q64 = qsel.double()
     q_norm = float(q64.norm(dim=1).max())
     keep_s, keep_i = [[] for _ in range(n_check)], [[] for _ in range(n_check)]
     for b in range((n_total + BLOCK - 1) // BLOCK):
-        rows, _ = corpus_block(b, dim, queries, plant_rows, n_total, device)
+        rows, _ = corpus_block(b, dim, queries, plant_rows, n_total, device, scaled=scaled)
+        if metric == "cos":
+            rows = canonical_unit_rows(rows)
         x64 = rows.double()
         assert q_norm * float(x64.norm(dim=1).max()) < 16.0, "exactness argument of the float64 gate does not hold"
         sc = (q64 @ x64.T).float()  # [n_check, m], fp32 (RNE) of the exact sum
@@ -163,6 +190,34 @@ def streamed_full_lists(n_check, queries, dim, k, plant_rows, n_total, device):
         order = np.lexsort((ci, -cs.astype(np.float64)))[:k]
         want_s[a], want_i[a] = cs[order], ci[order]
     return want_s, want_i
+
+
+def gate_queries(nq, counters, n_check):
+    """Query indices for the full-list gate, spread over the passes of the search that `counters` describes: the first pass, a
+    middle one, the last full pass of the main kernel and the LAST pass (the 128-query tail kernel when the search had one) —
+    both ends of each tile."""
+    tile = int(counters["query_tile"])
+    n_pass = int(counters["n_passes"])
+    starts = sorted({0, (n_pass // 2) * tile, max(0, n_pass - 2) * tile, (n_pass - 1) * tile})
+    starts = [s0 for s0 in starts if s0 < nq]
+    per = max(1, n_check // len(starts))
+    idx = []
+    for s0 in starts:
+        e0 = min(nq, s0 + tile)
+        span = list(range(s0, min(e0, s0 + (per + 1) // 2))) + list(range(max(s0, e0 - per // 2), e0))
+        idx += span
+    return sorted(set(idx))[:max(n_check, len(starts))]
+
+
+def full_list_gate_fn(check, res_s, res_i, queries, dim, k, plant_rows, n_total, device, metric="ip", scaled=False):
+    """-> (ok, record): the search's lists of the queries `check` against streamed_full_lists, ids and fp32 scores bit for bit."""
+    t0 = time.perf_counter()
+    full_s, full_i = streamed_full_lists(check, queries, dim, k, plant_rows, n_total, device, metric=metric, scaled=scaled)
+    ok = bool(np.array_equal(full_i, res_i[check]) and np.array_equal(full_s.view(np.uint32), res_s[check].view(np.uint32)))
+    return ok, {"queries": len(check), "query_indices": [int(c) for c in check], "rows": n_total,
+                "ids_and_fp32_scores_bit_exact": ok, "seconds": time.perf_counter() - t0,
+                "how": ("float64 GEMM per 1M-row block (exact for unit-norm fp16 data), fp32 round, (score desc, row asc)"
+                        + ("; rows and queries normalised by plain torch fp64 / fp32 / fp16 operations first" if metric == "cos" else ""))}
 
 
 def cpu_baseline(args, dim, k):
@@ -413,16 +468,22 @@ def retrieve_stage_leg(args, device_index):
 
 
 def config5_leg(args, local_rank, device):
-    """BASELINE configs[4] geometry on ONE GPU: e5-large-v2-sized vectors (d = 1024, config/retriever/e5-large-v2.yaml:5-10),
-    top-200, a 21 M-row synthetic datastore (the stated configuration shards it over 8 GPUs).  Same data recipe
-    and parity gate as the headline."""
+    """BASELINE configs[4] geometry on ONE GPU: e5-large-v2-sized vectors (d = 1024) under the similarity that model's yaml
+    names — CosineSim (config/retriever/e5-large-v2.yaml:5-10; the index normalises every row once at finalize) —, top-200, a
+    21 M-row synthetic datastore (the stated configuration shards it over 8 GPUs).  The rows and queries are NOT
+    unit length (each stretched by its own factor), so the finalize-time normalisation does real work at full size.  Parity gate
+    as for the headline: planted positives on top, sorted lists, and the COMPLETE top-200 lists of queries from every pass
+    against the kernel-free float64 recomputation (streamed_full_lists, metric "cos")."""
     import bergen_amd
     dim, k, nq, n = 1024, 200, 1000, args.n_rows
-    queries = make_queries(nq, dim, device)
-    ix = bergen_amd.FlatIndex(n, dim, metric="ip", device=local_rank)
-    planted, plant_rows = fill_shard(ix, 0, n, dim, queries, n, device)
+    gq = torch.Generator(device=device).manual_seed(12)
+    queries = (make_queries(nq, dim, device).float() * (0.5 + 3.0 * torch.rand(nq, 1, generator=gq, device=device))).half()
+    ix = bergen_amd.FlatIndex(n, dim, metric="cos", device=local_rank)
+    planted, plant_rows = fill_shard(ix, 0, n, dim, queries, n, device, scaled=True)
+    t0 = time.perf_counter()
     ix.finalize()
     torch.cuda.synchronize()
+    finalize_s = time.perf_counter() - t0
     res = ix.search(queries, k)
     torch.cuda.synchronize()
     steps = max(1, min(args.steps, 3))
@@ -445,21 +506,74 @@ def config5_leg(args, local_rank, device):
     for qi in range(nq):
         mine = set(r for r in (int(v) for v in plant_rows[qi].tolist()) if owner[r] == qi)
         ok &= set(i_np[qi, :len(mine)].tolist()) == mine
-    got_rows = _regenerate_rows(i_np[:2].reshape(-1), dim, queries, plant_rows, n, device)
-    qf = queries[:2].cpu().numpy().astype(np.float64)
-    want = np.cumsum(qf[:, None, :] * got_rows.astype(np.float64).reshape(2, k, dim), axis=-1)[..., -1].astype(np.float32)
-    ok &= bool(np.array_equal(want.view(np.uint32), s_np[:2].view(np.uint32)))
+    gate = None
+    if args.full_list_queries > 0:
+        check = gate_queries(nq, c, min(16, args.full_list_queries))
+        gate_ok, gate = full_list_gate_fn(check, s_np, i_np, queries, dim, k, plant_rows, n, device, metric="cos", scaled=True)
+        ok &= gate_ok
     per_launch = c["algorithmic_bytes"] / c["n_passes"]
     avg = scan_ms / (steps * c["n_passes"])
     ix.close()
-    return {"workload": f"configs[4] geometry: {nq} queries x {n} x {dim} fp16, top-{k}, one GPU", "queries_per_s": nq / dt,
+    return {"workload": f"configs[4] geometry: {nq} queries x {n} x {dim} fp16, cosine (rows normalised once at finalize), top-{k}, one GPU",
+            "queries_per_s": nq / dt, "finalize_seconds": finalize_s,
             "ms_per_step": dt * 1e3, "query_tile": c["query_tile"], "passes_per_step": c["n_passes"], "k_padded": c["k_padded"],
             "roofline": {"bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]) if c["query_tile"] != 128 or c.get("shader_mhz", 0) == 0
                          else "bh_scan_topk256_kernel", "achieved": per_launch / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": per_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(args.traffic_json, "bh_scan_topk256_kernel", n, dim),
                          "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg},
-            "uncertified_queries": c.get("uncertified_queries", 0), "parity_check": "pass" if ok else "FAIL"}
+            "uncertified_queries": c.get("uncertified_queries", 0), "full_list_gate": gate, "parity_check": "pass" if ok else "FAIL"}
+
+
+def real_size_leg(args, local_rank, device):
+    """The headline search at the REAL row count of KILT-100w: 24 853 637 passages (BASELINE's "21M" is nominal) —
+    38.2 GB of fp16 rows, same queries / k / data recipe / parity gate as the headline (complete lists of queries from the
+    first, a middle, the last full and the tail pass)."""
+    import bergen_amd
+    dim, k, nq, n = args.dim, args.k, args.queries, 24_853_637
+    queries = make_queries(nq, dim, device)
+    ix = bergen_amd.FlatIndex(n, dim, metric="ip", device=local_rank)
+    planted, plant_rows = fill_shard(ix, 0, n, dim, queries, n, device)
+    ix.finalize()
+    torch.cuda.synchronize()
+    res = ix.search(queries, k, host=True)
+    steps = max(1, min(args.steps, 3))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scan_ms = tail_ms = 0.0
+    for _ in range(steps):
+        res = ix.search(queries, k, host=True)
+        cc = ix.counters()
+        scan_ms += cc["scan_ms"]
+        tail_ms += cc.get("tail_scan_ms", 0.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    c = ix.counters()
+    s_np, i_np = res[0].numpy().copy(), res[1].numpy().copy()
+    ok = bool((np.diff(s_np, axis=1) <= 0).all())
+    owner = {}
+    for qi in range(nq):
+        for j in range(5):
+            owner[int(plant_rows[qi, j])] = qi
+    for qi in range(nq):
+        mine = set(r for r in (int(v) for v in plant_rows[qi].tolist()) if owner[r] == qi)
+        ok &= set(i_np[qi, :len(mine)].tolist()) == mine
+    gate = None
+    if args.full_list_queries > 0:
+        check = gate_queries(nq, c, min(16, args.full_list_queries))
+        gate_ok, gate = full_list_gate_fn(check, s_np, i_np, queries, dim, k, plant_rows, n, device)
+        ok &= gate_ok
+    has_tail = c.get("tail_query_tile", 0) != 0 and c["n_passes"] > 1
+    n_launch = (c["n_passes"] - (1 if has_tail else 0)) * steps
+    per_launch = n * dim * 2.0 + c["query_tile"] * dim * 2.0 + c["query_tile"] * k * 12.0
+    avg = (scan_ms - (tail_ms if has_tail else 0.0)) / n_launch
+    ix.close()
+    return {"workload": f"configs[1] at KILT-100w's real row count: {nq} queries x {n} x {dim} fp16, top-{k}, one GPU",
+            "queries_per_s": nq / dt, "ms_per_step": dt * 1e3, "query_tile": c["query_tile"], "passes_per_step": c["n_passes"],
+            "roofline": {"bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]), "achieved": per_launch / (avg * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": per_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg},
+            "uncertified_queries": c.get("uncertified_queries", 0), "full_list_gate": gate, "parity_check": "pass" if ok else "FAIL"}
 
 
 def retrieve_stage_full_leg(args, stage, index, queries, want_scores, want_rows, n_total, k):
@@ -1034,15 +1148,9 @@ def run(args, env):
             ok &= bool(np.array_equal(want.view(np.uint32), s_np[:4].view(np.uint32)))
             # ... and the COMPLETE lists of the first queries against a kernel-free recomputation over all n_total rows
             if args.full_list_queries > 0:
-                t0 = time.perf_counter()
-                n_chk = min(args.full_list_queries, nq)
-                full_s, full_i = streamed_full_lists(n_chk, queries, dim, k, plant_rows, n_total, device)
-                full_ok = bool(np.array_equal(full_i, i_np[:n_chk]) and
-                               np.array_equal(full_s.view(np.uint32), s_np[:n_chk].view(np.uint32)))
+                check = gate_queries(nq, c, min(args.full_list_queries, nq))
+                full_ok, full_list_gate = full_list_gate_fn(check, s_np, i_np, queries, dim, k, plant_rows, n_total, device)
                 ok &= full_ok
-                full_list_gate = {"queries": n_chk, "rows": n_total, "ids_and_fp32_scores_bit_exact": full_ok,
-                                  "seconds": time.perf_counter() - t0,
-                                  "how": "float64 GEMM per 1M-row block (exact for unit-norm fp16 data), fp32 round, (score desc, row asc)"}
         parity = "pass" if ok else "FAIL"
 
     if rank == 0:
@@ -1163,8 +1271,18 @@ def run(args, env):
             ix.close()
             try:
                 out["config5"] = config5_leg(args, local_rank, device)
+                if out["config5"]["parity_check"] != "pass":
+                    out["parity_check"] = "FAIL (config5 leg)"
             except Exception as exc:
                 out["config5"] = {"error": repr(exc)}
+        if world == 1 and not args.no_real_size:
+            ix.close()
+            try:
+                out["real_size"] = real_size_leg(args, local_rank, device)
+                if out["real_size"]["parity_check"] != "pass":
+                    out["parity_check"] = "FAIL (real_size leg)"
+            except Exception as exc:
+                out["real_size"] = {"error": repr(exc)}
         if world == 1 and not args.no_certificate_leg:
             ix.close()
             try:

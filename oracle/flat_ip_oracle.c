@@ -283,6 +283,8 @@ int oracle_ref_chunked_search(const float* q, const float* x, int64_t nq, int d,
 /* ---- cosine: canonical row normalisation (restates CosineSim.sim's x / ||x||, dense.py:87-88;
  * definition shared with bergen_amd/csrc/convert.hip) ---------------------------------------- */
 void oracle_l2_normalize_rows(uint16_t* x, int64_t n, int d) {
+    /* rows are independent (threads over rows change no arithmetic): the full-size cosine check normalises 21 M x 1024 */
+#pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < n; ++r) {
         uint16_t* xr = x + r * d;
         double n2 = 0.0;

@@ -1,0 +1,182 @@
+// ubench_l2_lds.hip — how fast can ONE CU pull GEMM operand tiles out of L2 / Infinity Cache into LDS, and by which path?
+//
+// VERDICT r3 (encoder item): DESIGN's "three ceilings" reading rests on an LDS-DMA rate of ~29 B/clk/CU that was never
+// compared with a register-staged load path.  This measures both on the GEMM's own access pattern, with nothing else in the
+// loop: a 512-thread workgroup per CU walks 256 x 256 output tiles of an (M x N x K) problem in the persistent kernel's
+// XCD-aware order and, per K-stage of 64, moves the stage's 256 A rows + 256 B rows x 128 bytes (64 KiB) into an LDS ring.
+//   mode 0  LDS-DMA (global_load_lds_dwordx4), ring of 2, s_waitcnt vmcnt(0) + s_barrier per stage   (the production loop)
+//   mode 1  LDS-DMA, ring of 3, two whole stages left in flight across the barrier (vmcnt(16))
+//   mode 2  global_load_dwordx4 -> VGPRs -> ds_write_b128, loads of stage i + 1 issued before stage i is written
+//   mode 3  as mode 2 but half of each stage by LDS-DMA and half through registers (both paths at once)
+//   mode 4  mode 0 with only FOUR of the eight waves issuing (16 DMA instructions each): is it the issue or the path?
+// Build:  hipcc --offload-arch=gfx950 -O3 -o profiles/bin/ubench_l2_lds profiles/ubench_l2_lds.hip
+// Run:    profiles/bin/ubench_l2_lds [M N K]      (default 68608 3072 768 = the FFN-up GEMM of the bench batch)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                         \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                          \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                     \
+        }                                                                                \
+    } while (0)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) pull_kernel(const _Float16* A, const _Float16* B, int M, int N, int K, unsigned* sink,
+                                                       unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int STAGE = 64 * 1024;
+    constexpr int R = MODE == 1 ? 3 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = N / 256, n_tiles = (M / 256) * tiles_n;
+    const int G8 = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int q = n_tiles >> 3, r = n_tiles & 7;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const int cnt = q + (x < r ? 1 : 0);
+    const int n_my = cnt > j ? (cnt - j + G8 - 1) / G8 : 0;
+    const int KT = K / 64;
+    const size_t ld = (size_t)K * 2;  // bytes per row
+    // instruction i of wave w fetches 8 rows x 128 B: rows (i * 8 + w) * 8 .. + 8 of the 512-row (A | B) stage
+    const int row_in_piece = lane >> 3, chunk = lane & 7;
+    unsigned acc = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    half8 regs[8];
+    int slot = 0;
+    auto src_of = [&](int t, int kt, int i) -> const unsigned char* {
+        const int tm0 = (t / tiles_n) * 256, tn0 = (t % tiles_n) * 256;
+        const int row = (i * 8 + wave) * 8 + row_in_piece;  // 0..511
+        const unsigned char* base = row < 256 ? (const unsigned char*)A + (size_t)(tm0 + row) * ld
+                                              : (const unsigned char*)B + (size_t)(tn0 + row - 256) * ld;
+        return base + (size_t)kt * 128 + chunk * 16;
+    };
+    auto dma = [&](int t, int kt, int i, int s) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_of(t, kt, i),
+                                         (__attribute__((address_space(3))) void*)(smem + s * STAGE + (i * 8 + wave) * 1024), 16, 0, 0);
+    };
+    const int total = n_my * KT;
+    auto tile_of = [&](int it) { return start + j + (it / KT) * G8; };
+    if (MODE == 0 || MODE == 1 || MODE == 4) {
+        auto issue = [&](int it, int s) {
+            const int t = tile_of(it), kt = it % KT;
+            if (MODE == 4) {
+                if (wave < 4)
+                    for (int i = 0; i < 16; ++i) {  // 4 waves x 16 pieces: piece index p = i * 4 + wave
+                        const int p = i * 4 + wave, row = p * 8 + row_in_piece;
+                        const int tm0 = (t / tiles_n) * 256, tn0 = (t % tiles_n) * 256;
+                        const unsigned char* base = row < 256 ? (const unsigned char*)A + (size_t)(tm0 + row) * ld
+                                                              : (const unsigned char*)B + (size_t)(tn0 + row - 256) * ld;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)kt * 128 + chunk * 16),
+                                                         (__attribute__((address_space(3))) void*)(smem + s * STAGE + p * 1024), 16, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dma(t, kt, i, s);
+            }
+        };
+        for (int p = 0; p < R - 1 && p < total; ++p) issue(p, p);
+        for (int it = 0; it < total; ++it) {
+            if (it + R - 1 < total) issue(it + R - 1, (it + R - 1) % R);
+            if (MODE == 1 || MODE == 4)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // mode 1: the two younger stages stay in flight; mode 4: 16 per stage
+            else
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (it + R - 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            acc += *(volatile unsigned*)(smem + (it % R) * STAGE + tid * 4);  // one dword per lane: the stage was really there
+            asm volatile("s_barrier" ::: "memory");  // (slot reuse: everyone has read)
+        }
+    } else {
+        auto load = [&](int it) {
+            const int t = tile_of(it), kt = it % KT;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (MODE == 3 && (i & 1)) continue;
+                regs[i] = *reinterpret_cast<const half8*>(src_of(t, kt, i));
+            }
+        };
+        if (total > 0) load(0);
+        for (int it = 0; it < total; ++it) {
+            const int s = it & 1;
+            if (MODE == 3) {
+                const int t = tile_of(it), kt = it % KT;
+#pragma unroll
+                for (int i = 1; i < 8; i += 2) dma(t, kt, i, s);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (MODE == 3 && (i & 1)) continue;
+                *reinterpret_cast<half8*>(smem + s * STAGE + (i * 8 + wave) * 1024 + lane * 16) = regs[i];
+            }
+            if (it + 1 < total) load(it + 1);  // next stage's loads fly while this one is handed over
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            acc += *(volatile unsigned*)(smem + s * STAGE + tid * 4);
+            asm volatile("s_barrier" ::: "memory");
+        }
+        (void)slot;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (acc == 0x12345678u) sink[0] = acc;
+    if (tid == 0) clk[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* what, const _Float16* A, const _Float16* B, int M, int N, int K, unsigned* sink, unsigned long long* clk) {
+    const size_t smem = (MODE == 1 ? 3 : 2) * 64 * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pull_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f, sum = 0;
+    const int reps = 6;
+    for (int rep = 0; rep < reps; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(pull_kernel<MODE>, dim3(256), dim3(512), smem, 0, A, B, M, N, K, sink, clk);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) {
+            sum += ms;
+            best = ms < best ? ms : best;
+        }
+    }
+    std::vector<unsigned long long> h(256);
+    CHECK(hipMemcpy(h.data(), clk, 256 * 8, hipMemcpyDeviceToHost));
+    double cyc = 0;
+    for (auto c : h) cyc += (double)c;
+    cyc /= 256;
+    const double bytes = (double)(M / 256) * (N / 256) * (K / 64) * 65536.0;
+    const double ms = sum / (reps - 1);
+    printf("{\"mode\": %d, \"what\": \"%s\", \"ms\": %.4f, \"ms_min\": %.4f, \"agg_TBps\": %.2f, \"per_cu_GBps\": %.1f, "
+           "\"bytes_per_clk_per_cu\": %.1f, \"eff_MHz\": %.0f}\n",
+           MODE, what, ms, best, bytes / (ms * 1e-3) / 1e12, bytes / 256 / (ms * 1e-3) / 1e9, bytes / 256 / cyc,
+           cyc / (ms * 1e-3) / 1e6);
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 3 ? atoi(argv[1]) : 68608, N = argc > 3 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
+    _Float16 *A, *B;
+    unsigned* sink;
+    unsigned long long* clk;
+    CHECK(hipMalloc(&A, (size_t)M * K * 2));
+    CHECK(hipMalloc(&B, (size_t)N * K * 2));
+    CHECK(hipMalloc(&sink, 64));
+    CHECK(hipMalloc(&clk, 256 * 8));
+    CHECK(hipMemset(A, 0x3c, (size_t)M * K * 2));
+    CHECK(hipMemset(B, 0x3c, (size_t)N * K * 2));
+    printf("{\"M\": %d, \"N\": %d, \"K\": %d, \"stage_bytes\": 65536, \"note\": \"no MFMA, no fragment reads: the load path alone\"}\n", M, N, K);
+    run<0>("LDS-DMA ring 2, vmcnt(0) per stage (production loop)", A, B, M, N, K, sink, clk);
+    run<1>("LDS-DMA ring 3, two stages in flight across the barrier", A, B, M, N, K, sink, clk);
+    run<2>("global_load_dwordx4 -> ds_write_b128, next stage's loads in flight", A, B, M, N, K, sink, clk);
+    run<3>("half LDS-DMA + half through registers", A, B, M, N, K, sink, clk);
+    run<4>("LDS-DMA ring 2, four issuing waves x 16", A, B, M, N, K, sink, clk);
+    return 0;
+}

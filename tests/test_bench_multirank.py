@@ -20,7 +20,7 @@ def _free_port():
 
 def _run(world, extra, launcher=True):
     flags = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--n-rows", "30011", "--queries", "37", "--no-encoder",
-             "--no-cpu-baseline", "--no-other-kernels", "--no-larger-k", "--no-config5", "--no-stage", "--no-certificate-leg", "--no-splade"] + extra
+             "--no-cpu-baseline", "--no-other-kernels", "--no-larger-k", "--no-config5", "--no-real-size", "--no-stage", "--no-certificate-leg", "--no-splade"] + extra
     script = os.path.join(ROOT, "tests", "bench_standin.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -61,7 +61,7 @@ def test_single_rank_standin_agrees():
     r = _run(1, [])
     assert r["n_gpus"] == 1 and r["parity_check"] == "pass"
     # the streaming full-list gate (a float64 GEMM per block, no oracle) agrees with the oracle-backed index on complete lists
-    assert r["full_list_gate"]["ids_and_fp32_scores_bit_exact"] is True and r["full_list_gate"]["queries"] == 8
+    assert r["full_list_gate"]["ids_and_fp32_scores_bit_exact"] is True and r["full_list_gate"]["queries"] == 32
 
 
 def test_power_sampler_without_a_sensor_reports_nothing_and_does_not_raise():

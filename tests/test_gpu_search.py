@@ -275,29 +275,36 @@ def test_repeatability(amd):
     ix.close()
 
 
-def test_full_size_properties(amd):
-    """BASELINE configs[1] size: 21M x 768 fp16 resident (32 GB).  Size-independent properties:
-    planted positives come back on top with their oracle scores, lists are canonically sorted,
+def _full_size_case(amd, n, d, nq, k, metric, checked, seed):
+    """One full-size corpus, generated on the device in 1 M-row blocks and streamed through the oracle as it is generated.
+
+    Size-independent properties: planted positives come back on top with their oracle scores, lists are canonically sorted,
     and a 2-way row split merged by the HIP kernel equals the single-index result.
-    And the FULL lists of the first 16 queries against the oracle, bit for bit: the corpus blocks are copied to the host as
-    they are generated, the oracle keeps a running top-50 per block (`c_oracle.canonical_search` with the block's row
-    offset) and the per-block lists are merged by the oracle's own merge — ranks 1..50 at 21 M x 768 are then the oracle's
-    word, not the kernel's certificate vouching for itself."""
+    And the FULL lists of the `checked` queries against the oracle, bit for bit: every corpus block is copied to the host as
+    it is generated, the oracle keeps a running top-k per block (`c_oracle.canonical_search` with the block's row offset;
+    cosine: on the block normalised by the oracle's own `l2_normalize_rows`) and the per-block lists are merged by the
+    oracle's own merge — ranks 1..k at full size are then the oracle's word, not the kernel's certificate vouching for
+    itself.  `checked` names queries of EVERY pass of the search, the last (tail) pass included."""
     free, total = torch.cuda.mem_get_info()
-    n, d, nq, k = 21_000_000, 768, 200, 50
     if free < (n * d * 2) * 2.2:
         pytest.skip("not enough free HBM for the full-size case")
     dev = torch.device("cuda:0")
-    gen = torch.Generator(device=dev).manual_seed(1234)
-    ix = amd.FlatIndex(n, d)
-    half_lo = amd.FlatIndex(n // 2, d)
-    half_hi = amd.FlatIndex(n - n // 2, d)
-    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=gen, device=dev), dim=1).half()
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    cos = metric == "cos"
+    ix = amd.FlatIndex(n, d, metric=metric)
+    half_lo = amd.FlatIndex(n // 2, d, metric=metric)
+    half_hi = amd.FlatIndex(n - n // 2, d, metric=metric)
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=gen, device=dev), dim=1)
+    if cos:
+        q = q * (0.5 + 3.0 * torch.rand(nq, 1, generator=gen, device=dev))  # cosine ignores the length: make it matter if it does not
+    q = q.half()
     plant_rows = torch.randint(0, n, (nq, 5), generator=gen, device=dev)
     block = 1_000_000
-    planted = {}
-    n_streamed = 16
-    q_head = q[:n_streamed].cpu().numpy()
+    planted, row_owner = {}, {}
+    checked = sorted(set(int(c) for c in checked))
+    q_np = q.cpu().numpy()
+    q_canon = c_oracle.l2_normalize_rows(q_np) if cos else q_np  # what the index scores with (bh_search normalises the queries)
+    q_head = np.ascontiguousarray(q_canon[checked])
     part_s, part_i = [], []
     for b0 in range(0, n, block):
         m = min(block, n - b0)
@@ -307,12 +314,19 @@ def test_full_size_properties(amd):
             r = int(plant_rows[qi, j])
             noise = torch.randn(d, generator=gen, device=dev) * (0.3 / d ** 0.5)
             rows[r - b0] = torch.nn.functional.normalize(q[qi].float() + noise, dim=0)
+        if cos:  # row lengths all over the place: the finalize-time normalisation has real work to do
+            rows = rows * (0.25 + 4.0 * torch.rand(m, 1, generator=gen, device=dev))
         rows = rows.half()
-        for qi, j in sel.tolist():
+        host = rows.cpu().numpy()
+        canon = c_oracle.l2_normalize_rows(host) if cos else host
+        for qi, j in sel.tolist():  # (two queries may plant on the same row: the later write is what the row holds)
             r = int(plant_rows[qi, j])
-            planted[(qi, r)] = rows[r - b0].cpu().numpy()
+            if r in row_owner:
+                del planted[(row_owner[r], r)]
+            row_owner[r] = qi
+            planted[(qi, r)] = canon[r - b0].copy()
         ix.upload(rows, row0=b0)
-        bs, bi = c_oracle.canonical_search(q_head, rows.cpu().numpy(), k, id_offset=b0)  # the streaming oracle's block step
+        bs, bi = c_oracle.canonical_search(q_head, canon, k, id_offset=b0)  # the streaming oracle's block step
         part_s.append(bs)
         part_i.append(bi)
         lo_n = n // 2
@@ -324,11 +338,12 @@ def test_full_size_properties(amd):
             cut = lo_n - b0
             half_lo.upload(rows[:cut].contiguous(), row0=b0)
             half_hi.upload(rows[cut:].contiguous(), row0=0)
-        del rows
+        del rows, host, canon
     for h in (ix, half_lo, half_hi):
         h.finalize()
     s, i = ix.search(q, k)
-    s_np, i_np, q_np = s.cpu().numpy(), i.cpu().numpy(), q.cpu().numpy()
+    counters = ix.counters()
+    s_np, i_np = s.cpu().numpy(), i.cpu().numpy()
     # canonical sortedness
     assert (np.diff(s_np, axis=1) <= 0).all()
     ties = np.diff(s_np, axis=1) == 0
@@ -337,15 +352,15 @@ def test_full_size_properties(amd):
     for (qi, r), row in planted.items():
         pos = np.where(i_np[qi] == r)[0]
         assert len(pos) == 1, f"planted row {r} of query {qi} missing"
-        want = c_oracle.canonical_scores(q_np[qi:qi + 1], row[None], np.zeros((1, 1), np.int64))[0, 0]
+        want = c_oracle.canonical_scores(q_canon[qi:qi + 1], row[None], np.zeros((1, 1), np.int64))[0, 0]
         assert s_np[qi, pos[0]].view(np.uint32) == want.view(np.uint32)
     for qi in range(nq):
         mine = sorted(r for (a, r) in planted if a == qi)
         assert sorted(i_np[qi, :len(mine)].tolist()) == mine
-    # the complete top-50 lists of the first queries vs the streaming oracle
+    # the complete top-k lists of the checked queries vs the streaming oracle
     ws, wi = c_oracle.merge_topk(np.stack(part_s), np.stack(part_i))
     assert wi.min() >= 0 and len(set(wi[0].tolist())) == k
-    compare.assert_bit_exact(s_np[:n_streamed], i_np[:n_streamed], ws, wi, "full lists at 21M x 768 vs the streaming oracle")
+    compare.assert_bit_exact(s_np[checked], i_np[checked], ws, wi, f"full lists at {n} x {d} ({metric}, top-{k}) vs the streaming oracle")
     # shard invariance at full size
     s1, i1 = half_lo.search(q, k, id_offset=0)
     s2, i2 = half_hi.search(q, k, id_offset=n // 2)
@@ -353,6 +368,28 @@ def test_full_size_properties(amd):
     compare.assert_bit_exact(ms.cpu().numpy(), mi.cpu().numpy(), s_np, i_np, "2 shards at full size")
     for h in (ix, half_lo, half_hi):
         h.close()
+    return counters
+
+
+def test_full_size_properties(amd):
+    """BASELINE configs[1] size: 21M x 768 fp16 resident (32 GB), top-50; 612 queries = two passes of the 256-query kernel and
+    a 100-query TAIL pass on the 128-query kernel.  Complete oracle lists of 32 queries: 12 of pass 0, 10 of pass 1 (both ends
+    and the middle of each tile), 10 of the tail pass."""
+    checked = [0, 1, 2, 3, 100, 101, 127, 128, 200, 253, 254, 255,          # pass 0
+               256, 257, 258, 300, 383, 384, 400, 509, 510, 511,            # pass 1
+               512, 513, 514, 550, 575, 576, 600, 609, 610, 611]            # tail pass (128-query kernel)
+    c = _full_size_case(amd, 21_000_000, 768, 612, 50, "ip", checked, seed=1234)
+    assert c["n_passes"] == 3 and c["query_tile"] == 256 and c["tail_query_tile"] == 128 and c["tail_scan_ms"] > 0
+
+
+def test_full_size_config5_cosine(amd):
+    """BASELINE configs[4] at its stated size: 21 M x 1024 fp16 (43 GB), top-200, COSINE (config/retriever/e5-large-v2.yaml:
+    similarity CosineSim) — the d = 1024 instantiation of the scan (128 queries per pass, static tile distribution, candidate
+    lists of 256) and the finalize-time row normalisation, both at full size.  300 queries = three passes; complete oracle
+    lists of 14 queries from all three."""
+    checked = [0, 1, 2, 64, 127, 128, 129, 200, 255, 256, 257, 280, 298, 299]
+    c = _full_size_case(amd, 21_000_000, 1024, 300, 200, "cos", checked, seed=4321)
+    assert c["n_passes"] == 3 and c["query_tile"] == 128 and c["k_padded"] == 256 and c["dim_padded"] == 1024
 
 
 @pytest.mark.parametrize("kern", [0, 2, 3])
