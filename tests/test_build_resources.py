@@ -13,10 +13,13 @@ CSRC = os.path.join(ROOT, "bergen_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 # kernels that are bench-only ablations (results invalid by design) may spill
-# (scan_topk256: the bench-only ablation / variant instantiations, and the candidate lists of 128 / 256 at d = 768, whose
-# COLD paths keep up to 32 bytes in scratch; their tile loop is checked instruction by instruction in test_scan256_isa.py)
+# (scan_topk256: the bench-only ablation / variant instantiations, and ONE production instantiation: candidate lists of 256
+# (k = 121..248) at d = 768, whose COLD path (append / compaction / bound exchange) keeps 32 bytes per lane in scratch — the two
+# tracked scores per query block of its shared bound (RB = 2) do not fit beside 24 x 2 pinned query fragments; the variant
+# without tracking (256 slots of one row) would loosen the bound from rank ~430 to rank ~1 570 and quadruple the candidates.
+# Its tile loop is checked instruction by instruction in test_scan256_isa.py; lists of 64 and 128 are spill-free and checked here)
 ALLOW_SCRATCH = re.compile(r"bh_gemm_f16_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi[1-9]"
-                           r"|bh_scan_topk256_kernelILi24ELi(128|256)E"
+                           r"|bh_scan_topk256_kernelILi24ELi256E"
                            r"|bh_scan_topk256_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi[1-9]"
                            r"|bh_scan_topk256_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi0ELi(0|2|3)E"
                            r"|bh_scan_topk256_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi0ELi1ELi(0|2)E")
@@ -46,9 +49,9 @@ def usage(src):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_production_kernels_do_not_spill():
-    srcs = ["scan_topk.hip", "scan_topk192.hip", "scan_topk256.hip", "gemm_f16_c.hip", "gemm_f16.hip", "attention.hip", "csr_topk.hip", "csr_mfma.hip", "merge_rescore.hip",
-            "encoder_ops.hip"]
-    with ThreadPoolExecutor(len(srcs)) as ex:
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))  # EVERY translation unit of the library
+    assert {"scan_topk256.hip", "attention_rel.hip", "csr_head.hip", "certify.hip", "sparse.hip", "index.hip", "encoder.hip", "convert.hip"} <= set(srcs)
+    with ThreadPoolExecutor(min(8, len(srcs))) as ex:
         results = dict(zip(srcs, ex.map(usage, srcs)))
     seen = 0
     for src, kernels in results.items():
@@ -57,7 +60,11 @@ def test_production_kernels_do_not_spill():
             if ALLOW_SCRATCH.search(name):
                 continue
             assert u.get("ScratchSize", 0) == 0, f"{src}: {name} spills {u.get('ScratchSize')} bytes/lane"
-    assert seen >= 20
+    assert seen >= 200
+    # the one whitelisted production instantiation: no more than the 32 bytes the comment above accounts for
+    for name, u in results["scan_topk256.hip"].items():
+        if re.search(r"bh_scan_topk256_kernelILi24ELi256ELi12ELi3ELi4ELb[01]ELi0E", name):
+            assert u.get("ScratchSize", 0) <= 32, f"{name}: {u.get('ScratchSize')} bytes/lane of scratch"
     # occupancy assumptions of the launch geometry
     pk = {n: u for n, u in results["gemm_f16_c.hip"].items() if "pkernel" in n}
     assert pk and all(u["Occupancy"] >= 2 for u in pk.values())          # 8 waves per CU on 4 SIMDs
