@@ -5,7 +5,10 @@
 // loop: a 512-thread workgroup per CU walks 256 x 256 output tiles of an (M x N x K) problem in the persistent kernel's
 // XCD-aware order and, per K-stage of 64, moves the stage's 256 A rows + 256 B rows x 128 bytes (64 KiB) into an LDS ring.
 //   mode 0  LDS-DMA (global_load_lds_dwordx4), ring of 2, s_waitcnt vmcnt(0) + s_barrier per stage   (the production loop)
-//   mode 1  LDS-DMA, ring of 3, two whole stages left in flight across the barrier (vmcnt(16))
+//   mode 1  (removed: a ring of 3 x 64 KiB does not fit the 160 KiB of LDS)
+//   mode 5  mode 0 with the A operand stored K-BLOCKED, [K / 64][M][64] (the 256 rows x 128 B of a stage are one contiguous
+//           32 KiB block instead of 256 lines `row stride` apart): does the L2 / HBM side care about the stride?
+//   mode 6  mode 5 with B blocked too
 //   mode 2  global_load_dwordx4 -> VGPRs -> ds_write_b128, loads of stage i + 1 issued before stage i is written
 //   mode 3  as mode 2 but half of each stage by LDS-DMA and half through registers (both paths at once)
 //   mode 4  mode 0 with only FOUR of the eight waves issuing (16 DMA instructions each): is it the issue or the path?
@@ -33,7 +36,8 @@ __global__ void __launch_bounds__(512, 2) pull_kernel(const _Float16* A, const _
                                                        unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE = 64 * 1024;
-    constexpr int R = MODE == 1 ? 3 : 2;
+    constexpr int R = 2;
+    constexpr bool ABLK = MODE == 5 || MODE == 6, BBLK = MODE == 6;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = N / 256, n_tiles = (M / 256) * tiles_n;
     const int G8 = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -52,9 +56,12 @@ __global__ void __launch_bounds__(512, 2) pull_kernel(const _Float16* A, const _
     auto src_of = [&](int t, int kt, int i) -> const unsigned char* {
         const int tm0 = (t / tiles_n) * 256, tn0 = (t % tiles_n) * 256;
         const int row = (i * 8 + wave) * 8 + row_in_piece;  // 0..511
-        const unsigned char* base = row < 256 ? (const unsigned char*)A + (size_t)(tm0 + row) * ld
-                                              : (const unsigned char*)B + (size_t)(tn0 + row - 256) * ld;
-        return base + (size_t)kt * 128 + chunk * 16;
+        if (row < 256) {
+            if (ABLK) return (const unsigned char*)A + ((size_t)kt * M + tm0 + row) * 128 + chunk * 16;
+            return (const unsigned char*)A + (size_t)(tm0 + row) * ld + (size_t)kt * 128 + chunk * 16;
+        }
+        if (BBLK) return (const unsigned char*)B + ((size_t)kt * N + tn0 + row - 256) * 128 + chunk * 16;
+        return (const unsigned char*)B + (size_t)(tn0 + row - 256) * ld + (size_t)kt * 128 + chunk * 16;
     };
     auto dma = [&](int t, int kt, int i, int s) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_of(t, kt, i),
@@ -62,7 +69,7 @@ __global__ void __launch_bounds__(512, 2) pull_kernel(const _Float16* A, const _
     };
     const int total = n_my * KT;
     auto tile_of = [&](int it) { return start + j + (it / KT) * G8; };
-    if (MODE == 0 || MODE == 1 || MODE == 4) {
+    if (MODE == 0 || MODE == 4 || MODE == 5 || MODE == 6) {
         auto issue = [&](int it, int s) {
             const int t = tile_of(it), kt = it % KT;
             if (MODE == 4) {
@@ -83,8 +90,8 @@ __global__ void __launch_bounds__(512, 2) pull_kernel(const _Float16* A, const _
         for (int p = 0; p < R - 1 && p < total; ++p) issue(p, p);
         for (int it = 0; it < total; ++it) {
             if (it + R - 1 < total) issue(it + R - 1, (it + R - 1) % R);
-            if (MODE == 1 || MODE == 4)
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // mode 1: the two younger stages stay in flight; mode 4: 16 per stage
+            if (MODE == 4)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // mode 4: 16 per stage and issuing wave
             else
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             if (it + R - 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -128,8 +135,8 @@ __global__ void __launch_bounds__(512, 2) pull_kernel(const _Float16* A, const _
 }
 
 template <int MODE>
-void run(const char* what, const _Float16* A, const _Float16* B, int M, int N, int K, unsigned* sink, unsigned long long* clk) {
-    const size_t smem = (MODE == 1 ? 3 : 2) * 64 * 1024;
+void run(const char* what, const _Float16* A, const _Float16* B, int M, int N, int K, unsigned* sink, unsigned long long* clk, int grid = 256) {
+    const size_t smem = 2 * 64 * 1024;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pull_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -138,7 +145,7 @@ void run(const char* what, const _Float16* A, const _Float16* B, int M, int N, i
     const int reps = 6;
     for (int rep = 0; rep < reps; ++rep) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(pull_kernel<MODE>, dim3(256), dim3(512), smem, 0, A, B, M, N, K, sink, clk);
+        hipLaunchKernelGGL(pull_kernel<MODE>, dim3(grid), dim3(512), smem, 0, A, B, M, N, K, sink, clk);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -148,16 +155,16 @@ void run(const char* what, const _Float16* A, const _Float16* B, int M, int N, i
             best = ms < best ? ms : best;
         }
     }
-    std::vector<unsigned long long> h(256);
-    CHECK(hipMemcpy(h.data(), clk, 256 * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(grid);
+    CHECK(hipMemcpy(h.data(), clk, (size_t)grid * 8, hipMemcpyDeviceToHost));
     double cyc = 0;
     for (auto c : h) cyc += (double)c;
-    cyc /= 256;
+    cyc /= grid;
     const double bytes = (double)(M / 256) * (N / 256) * (K / 64) * 65536.0;
     const double ms = sum / (reps - 1);
-    printf("{\"mode\": %d, \"what\": \"%s\", \"ms\": %.4f, \"ms_min\": %.4f, \"agg_TBps\": %.2f, \"per_cu_GBps\": %.1f, "
+    printf("{\"mode\": %d, \"grid\": %d, \"what\": \"%s\", \"ms\": %.4f, \"ms_min\": %.4f, \"agg_TBps\": %.2f, \"per_cu_GBps\": %.1f, "
            "\"bytes_per_clk_per_cu\": %.1f, \"eff_MHz\": %.0f}\n",
-           MODE, what, ms, best, bytes / (ms * 1e-3) / 1e12, bytes / 256 / (ms * 1e-3) / 1e9, bytes / 256 / cyc,
+           MODE, grid, what, ms, best, bytes / (ms * 1e-3) / 1e12, bytes / grid / (ms * 1e-3) / 1e9, bytes / grid / cyc,
            cyc / (ms * 1e-3) / 1e6);
 }
 
@@ -174,9 +181,14 @@ int main(int argc, char** argv) {
     CHECK(hipMemset(B, 0x3c, (size_t)N * K * 2));
     printf("{\"M\": %d, \"N\": %d, \"K\": %d, \"stage_bytes\": 65536, \"note\": \"no MFMA, no fragment reads: the load path alone\"}\n", M, N, K);
     run<0>("LDS-DMA ring 2, vmcnt(0) per stage (production loop)", A, B, M, N, K, sink, clk);
-    run<1>("LDS-DMA ring 3, two stages in flight across the barrier", A, B, M, N, K, sink, clk);
     run<2>("global_load_dwordx4 -> ds_write_b128, next stage's loads in flight", A, B, M, N, K, sink, clk);
     run<3>("half LDS-DMA + half through registers", A, B, M, N, K, sink, clk);
     run<4>("LDS-DMA ring 2, four issuing waves x 16", A, B, M, N, K, sink, clk);
+    run<5>("LDS-DMA ring 2, A stored K-blocked [K/64][M][64]", A, B, M, N, K, sink, clk);
+    run<6>("LDS-DMA ring 2, A and B stored K-blocked", A, B, M, N, K, sink, clk);
+    // per-CU or chip-level limit?  the same walk on a quarter / an eighth of the CUs (8 XCDs x 8 and x 4 workgroups)
+    run<0>("LDS-DMA ring 2 on 64 workgroups", A, B, M, N, K, sink, clk, 64);
+    run<0>("LDS-DMA ring 2 on 32 workgroups", A, B, M, N, K, sink, clk, 32);
+    run<5>("A K-blocked on 64 workgroups", A, B, M, N, K, sink, clk, 64);
     return 0;
 }
