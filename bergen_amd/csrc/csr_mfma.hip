@@ -46,9 +46,18 @@ __device__ __forceinline__ void load_keys_m(u64 (&e)[EPL], const u64* buf, unsig
         e[r] = idx < n ? buf[idx] : 0ull;
     }
 }
+// the 32-bit LDS byte address of a pointer into dynamic shared memory
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
 }  // namespace
 
-template <int KP>
+// HOT = 1 (production): the entry test and the hit queue of the scatter phase are hand-written (inline asm: 4 + 13 instructions
+// per 64-entry chunk instead of the ~32 hipcc makes of the C++ form, which stays selectable — HOT = 0, option sparse_ablate
+// bit 1024 — as the reference the asm is A/B-ed and bit-compared against).  The kernel is instruction-bound (PMC, round 3:
+// two waves per SIMD, each active 45 % of its cycles), so instructions per entry are what a pass costs beyond its 2.4 ms
+// of stream.
+template <int KP, int HOT = 1>
 __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWV = 8;
@@ -71,6 +80,9 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     float* St = reinterpret_cast<float*>(Dt + 4096);
     uint2* Qt = reinterpret_cast<uint2*>(Dt + 12288);  // ring of BH_CSR_MFMA_QUEUE pending hits: (position in the group, entry)
     const unsigned HD = (unsigned)a.head_dwords;       // 0, or 1024: dwords of the corpus-head tile in front of every group's entries
+    if constexpr (HOT == 1) {  // the asm entry test reads the bitmap by its LDS byte address, which it takes to be the word offset
+        if (lds_address(smem) != 0u) __builtin_trap();
+    }
     for (int i = tid; i < a.n_words; i += 512) {
         bitmap[i] = a.bitmap[i];
         prefix[i] = a.prefix[i];
@@ -165,10 +177,16 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     // never changes, chunk offset in a scalar) — with one dword load per lane and chunk the refill was a third of the
     // vector instructions of the entry loop.  Register j of quad c4 holds entry 256 c4 + 4 lane + j of the super-chunk.
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // (pointer and extent are wave-uniform by construction; saying so — v_readfirstlane — keeps the descriptor in scalar
+    // registers: without it hipcc wraps EVERY buffer load in a 12-instruction waterfall loop over "the lanes' descriptors")
     auto group_rsrc = [&](const unsigned* eb, unsigned total) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)eb, 0, (int)(total * 4u), 0x00020000);
+        const unsigned long long v = (unsigned long long)eb;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                                 (int)(__builtin_amdgcn_readfirstlane(total) * 4u), 0x00020000);
     };
     const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned lane4 = (unsigned)lane * 4u;
     auto load_quad = [&](unsigned (&buf)[SC], int c4, __amdgpu_buffer_rsrc_t rs, unsigned sc) {
         const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, (sc * SC + c4 * 4) * 256u, 0);
         buf[c4 * 4 + 0] = t4[0];
@@ -253,6 +271,81 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                 if (a.ablate & 1) {     // bench-only: stream the entries, no scatter
                     #pragma unroll
                     for (int c = 0; c < ST; ++c) asm volatile("" ::"v"(buf[step * ST + c]));
+                } else if constexpr (HOT == 1) {
+                    // ---- hand-written entry test + hit queue (see the kernel's header).  Phase A, all eight chunks of the
+                    // step: word address of the entry's term in the bitmap (the bitmap sits at LDS address 0: checked at
+                    // kernel start), the eight LDS gathers issued together, each tested as it lands (LDS returns in order:
+                    // lgkmcnt(7 - c) covers chunk c) — t[c] = 1 where the entry's term is in the tile's term set.
+                    static_assert(BH_CSR_MFMA_QUEUE == 256 && ST == 8, "the asm below masks ring positions with 0xff and tests eight chunks");
+                    unsigned t[ST];
+                    asm volatile(
+                        "v_lshrrev_b32 %0, 3, %8\n\tv_lshrrev_b32 %1, 3, %9\n\tv_lshrrev_b32 %2, 3, %10\n\tv_lshrrev_b32 %3, 3, %11\n\t"
+                        "v_lshrrev_b32 %4, 3, %12\n\tv_lshrrev_b32 %5, 3, %13\n\tv_lshrrev_b32 %6, 3, %14\n\tv_lshrrev_b32 %7, 3, %15\n\t"
+                        "v_and_b32 %0, 0x1ffc, %0\n\tv_and_b32 %1, 0x1ffc, %1\n\tv_and_b32 %2, 0x1ffc, %2\n\tv_and_b32 %3, 0x1ffc, %3\n\t"
+                        "v_and_b32 %4, 0x1ffc, %4\n\tv_and_b32 %5, 0x1ffc, %5\n\tv_and_b32 %6, 0x1ffc, %6\n\tv_and_b32 %7, 0x1ffc, %7\n\t"
+                        "ds_read_b32 %0, %0\n\tds_read_b32 %1, %1\n\tds_read_b32 %2, %2\n\tds_read_b32 %3, %3\n\t"
+                        "ds_read_b32 %4, %4\n\tds_read_b32 %5, %5\n\tds_read_b32 %6, %6\n\tds_read_b32 %7, %7\n\t"
+                        "s_waitcnt lgkmcnt(7)\n\tv_bfe_u32 %0, %0, %8, 1\n\t"
+                        "s_waitcnt lgkmcnt(6)\n\tv_bfe_u32 %1, %1, %9, 1\n\t"
+                        "s_waitcnt lgkmcnt(5)\n\tv_bfe_u32 %2, %2, %10, 1\n\t"
+                        "s_waitcnt lgkmcnt(4)\n\tv_bfe_u32 %3, %3, %11, 1\n\t"
+                        "s_waitcnt lgkmcnt(3)\n\tv_bfe_u32 %4, %4, %12, 1\n\t"
+                        "s_waitcnt lgkmcnt(2)\n\tv_bfe_u32 %5, %5, %13, 1\n\t"
+                        "s_waitcnt lgkmcnt(1)\n\tv_bfe_u32 %6, %6, %14, 1\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\tv_bfe_u32 %7, %7, %15, 1"
+                        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                        : "v"(buf[step * ST + 0]), "v"(buf[step * ST + 1]), "v"(buf[step * ST + 2]), "v"(buf[step * ST + 3]),
+                          "v"(buf[step * ST + 4]), "v"(buf[step * ST + 5]), "v"(buf[step * ST + 6]), "v"(buf[step * ST + 7])
+                        : "memory");
+                    // (hazards minded by hand — the hazard recognizer does not look into inline asm: gfx950 wants 2 wait states between
+                    // a VALU write of an SGPR / vcc and a VALU read of it: the branch and the v_add3 stand between v_cmp and v_mbcnt)
+                    // Phase B, two chunks per block: a chunk WITHOUT a hit (one in nine) skips its 11 instructions; with hits, lane's
+                    // slot in the ring = q_tail + hits in lower lanes (v_mbcnt over vcc), (position in the group, entry) written by
+                    // ONE ds_write2_b32 under exec = vcc, q_tail += popcount.  The ring holds BH_CSR_MFMA_QUEUE = 256 hits: checked
+                    // (and drained 64 at a time) after every two chunks — at most 63 + 2 x 64 pending in between.
+                    const unsigned qbase = lds_address(Qt);
+#pragma unroll
+                    for (int c2 = 0; c2 < ST; c2 += 2) {
+                        // p = position among the group's tail entries = ppos + 4 lane + (chunk & 3), ppos = start of the chunk's quad
+                        const unsigned ppos = cbase - HD + (unsigned)(c2 >> 2) * 256u;
+                        unsigned x, pp;
+                        unsigned long long sv;
+                        unsigned nh;
+                        asm volatile(
+                            "v_cmp_ne_u32_e32 vcc, 0, %[t0]\n\t"
+                            "s_cbranch_vccz .Lcsrq%=_a\n\t"
+                            "v_add3_u32 %[pp], %[ppos], %[l4], %[j0]\n\t"  // (also the 2nd wait state between the VALU write of vcc and its VALU read: gfx950)
+                            "v_mbcnt_lo_u32_b32 %[x], vcc_lo, 0\n\t"
+                            "v_mbcnt_hi_u32_b32 %[x], vcc_hi, %[x]\n\t"
+                            "v_add_u32_e32 %[x], %[qt], %[x]\n\t"
+                            "v_and_b32_e32 %[x], 0xff, %[x]\n\t"
+                            "v_lshl_add_u32 %[x], %[x], 3, %[qb]\n\t"
+                            "s_and_saveexec_b64 %[sv], vcc\n\t"
+                            "ds_write2_b32 %[x], %[pp], %[e0] offset1:1\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            "s_bcnt1_i32_b64 %[nh], vcc\n\t"
+                            "s_add_u32 %[qt], %[qt], %[nh]\n"
+                            ".Lcsrq%=_a:\n\t"
+                            "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"
+                            "s_cbranch_vccz .Lcsrq%=_b\n\t"
+                            "v_add3_u32 %[pp], %[ppos], %[l4], %[j1]\n\t"  // (also the 2nd wait state between the VALU write of vcc and its VALU read: gfx950)
+                            "v_mbcnt_lo_u32_b32 %[x], vcc_lo, 0\n\t"
+                            "v_mbcnt_hi_u32_b32 %[x], vcc_hi, %[x]\n\t"
+                            "v_add_u32_e32 %[x], %[qt], %[x]\n\t"
+                            "v_and_b32_e32 %[x], 0xff, %[x]\n\t"
+                            "v_lshl_add_u32 %[x], %[x], 3, %[qb]\n\t"
+                            "s_and_saveexec_b64 %[sv], vcc\n\t"
+                            "ds_write2_b32 %[x], %[pp], %[e1] offset1:1\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            "s_bcnt1_i32_b64 %[nh], vcc\n\t"
+                            "s_add_u32 %[qt], %[qt], %[nh]\n"
+                            ".Lcsrq%=_b:"
+                            : [x] "=&v"(x), [pp] "=&v"(pp), [sv] "=&s"(sv), [nh] "=&s"(nh), [qt] "+s"(q_tail)
+                            : [t0] "v"(t[c2]), [t1] "v"(t[c2 + 1]), [e0] "v"(buf[step * ST + c2]), [e1] "v"(buf[step * ST + c2 + 1]),
+                              [qb] "s"(qbase), [ppos] "s"(ppos), [l4] "v"(lane4), [j0] "n"(c2 & 3), [j1] "n"((c2 + 1) & 3)
+                            : "vcc", "scc", "memory");
+                        while (q_tail - q_head >= 64u) drain(64u, rel);
+                    }
                 } else {
                     // the term-set lookups of the step first (entries past the group's end are 0: the reserved id): their LDS
                     // latencies overlap instead of adding up —
@@ -573,20 +666,26 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
 }
 
 hipError_t bh_launch_csr_scan_mfma(const BhCsrMfmaArgs& a, int kp, int grid, size_t smem, hipStream_t stream) {
-    static size_t attr[2] = {0, 0};
-    const void* fn = kp == 64 ? reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<64>)
-                              : reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<128>);
-    size_t& done = attr[kp == 64 ? 0 : 1];
+    static size_t attr[4] = {0, 0, 0, 0};
+    // the hand-written hot path is the production kernel; the C++ form serves the bench-only ablations of the entry loop
+    // (bits 1, 4) and the explicit A/B switch (bit 1024)
+    const bool cxx = (a.ablate & (1 | 4 | 1024)) != 0;
+    if (kp != 64 && kp != 128) return hipErrorInvalidValue;
+    const void* fn = kp == 64 ? (cxx ? reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<64, 0>) : reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<64, 1>))
+                              : (cxx ? reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<128, 0>) : reinterpret_cast<const void*>(bh_csr_scan_mfma_kernel<128, 1>));
+    size_t& done = attr[(kp == 64 ? 0 : 1) + (cxx ? 2 : 0)];
     if (smem > done) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         done = smem;
     }
-    if (kp == 64)
-        hipLaunchKernelGGL(bh_csr_scan_mfma_kernel<64>, dim3(grid), dim3(512), smem, stream, a);
-    else if (kp == 128)
-        hipLaunchKernelGGL(bh_csr_scan_mfma_kernel<128>, dim3(grid), dim3(512), smem, stream, a);
+    if (kp == 64 && !cxx)
+        hipLaunchKernelGGL((bh_csr_scan_mfma_kernel<64, 1>), dim3(grid), dim3(512), smem, stream, a);
+    else if (kp == 64)
+        hipLaunchKernelGGL((bh_csr_scan_mfma_kernel<64, 0>), dim3(grid), dim3(512), smem, stream, a);
+    else if (!cxx)
+        hipLaunchKernelGGL((bh_csr_scan_mfma_kernel<128, 1>), dim3(grid), dim3(512), smem, stream, a);
     else
-        return hipErrorInvalidValue;
+        hipLaunchKernelGGL((bh_csr_scan_mfma_kernel<128, 0>), dim3(grid), dim3(512), smem, stream, a);
     return hipGetLastError();
 }

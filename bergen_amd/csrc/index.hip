@@ -349,7 +349,7 @@ int bh_set_option(const char* name, int64_t value) {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "sparse_head must be 0 (plain CSR stream) or 1 (corpus-head tiles + tail stream)");
         bh_sparse_set_head((int)value);
     } else if (s == "sparse_ablate") {
-        if (value < 0 || value > 1023) return fail(BH_EINVAL, "sparse_ablate must be 0..1023");
+        if (value < 0 || value > 2047) return fail(BH_EINVAL, "sparse_ablate must be 0..2047");
         bh_sparse_set_ablate((int)value);
     } else if (s == "gemm_stagger_phases") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");

@@ -836,7 +836,7 @@ int bh_sparse_set_option(bh_sparse_index* ix, const char* name, int64_t value) {
         if (!inherit && value != 0 && value != 1) return bh_fail(BH_EINVAL, "sparse_head must be 0 (plain CSR stream) or 1 (corpus-head tiles + tail stream)");
         ix->opt_head = inherit ? -1 : (int)value;
     } else if (strcmp(name, "sparse_ablate") == 0) {
-        if (!inherit && (value < 0 || value > 1023)) return bh_fail(BH_EINVAL, "sparse_ablate must be 0..1023");
+        if (!inherit && (value < 0 || value > 2047)) return bh_fail(BH_EINVAL, "sparse_ablate must be 0..2047");
         ix->opt_ablate = inherit ? -1 : (int)value;
     } else {
         return bh_fail(BH_EINVAL, "unknown per-index sparse option '%s'", name);
