@@ -39,6 +39,9 @@ bool bh_scan_supports(int dim_padded, int kp, int qw);
 // scan_topk192.hip (192 queries per pass on v_mfma_f32_16x16x32_f16; d = 768, k <= 56 only)
 hipError_t bh_launch_scan192(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan192_supports(int dim_padded, int kp);
+// scan_topk256.hip in filter mode (the exact fall-back's filter pass, 256 queries per corpus pass)
+hipError_t bh_launch_filter_scan256(const BhScanArgs& a, int dim_padded, int grid, hipStream_t stream);
+bool bh_filter256_supports(int dim_padded);
 // timeline diagnostics of scan_topk256.hip (ablate 5): workgroup 0 records, for BH_TL_TILES tiles from ordinal BH_TL_TILE0,
 // per wave and stage five s_memtime values (before the vmcnt wait, after it, after the barrier, stage end, cycles spent in
 // LDS-DMA issue) behind the [grid][8] phase stamps of BhScanArgs::clk
@@ -97,7 +100,7 @@ hipError_t bh_launch_merge_lists(const float* scores, const long long* ids, int 
 
 // certify.hip: largest row norm of the corpus (for the certificate's error bound) and the exact fall-back scan
 hipError_t bh_launch_row_norm_max(const _Float16* rows, long long n, int dim_padded, unsigned* out_max_bits, hipStream_t stream);
-#define BH_EXACT_BATCH 128      /* uncertified queries per filter pass (one query tile of the 128-query scan kernel) */
+#define BH_EXACT_BATCH 256      /* most uncertified queries per filter pass: one query tile of the 256-query kernel (scan_topk256.hip, d <= 768); 128 on scan_topk.hip */
 #define BH_EXACT_CAP 65536      /* qualifying rows kept per query */
 struct BhExactArgs {
     const _Float16* corpus;   // [n_rows][D]
@@ -112,9 +115,14 @@ struct BhExactArgs {
 };
 // canonical (sequential fp64) score of every row the filter pass let through
 hipError_t bh_launch_exact_rescore(const BhExactArgs& a, hipStream_t stream);
-// gathers a batch of uncertified queries: rows -> q_out [BH_EXACT_BATCH][D] (zero beyond nb), k-th keys, filter thresholds
-hipError_t bh_launch_exact_prepare(const _Float16* qbuf, const int* todo, int nb, const bh_u64* kth_all, float err_coef, int dim_padded,
+// gathers a batch of uncertified queries: rows -> q_out [tile][D] (zero beyond nb), k-th keys, filter thresholds (tile = the
+// filter kernel's query tile, 128 or 256 <= BH_EXACT_BATCH)
+hipError_t bh_launch_exact_prepare(const _Float16* qbuf, const int* todo, int nb, int tile, const bh_u64* kth_all, float err_coef, int dim_padded,
                                    _Float16* q_out, bh_u64* kth_out, float* thr_out, hipStream_t stream);
+
+// list j of (src_s, src_i) [n][k] -> row todo[j] of (out_s, out_i) [.][k] (device or pinned host memory)
+hipError_t bh_launch_scatter_lists(const float* src_s, const long long* src_i, const int* todo, int n, int k, float* out_s, long long* out_i,
+                                   hipStream_t stream);
 
 // convert.hip: dtype conversion / padding / normalisation
 hipError_t bh_launch_convert_rows(const void* src, int src_dtype /*0=f16,1=f32*/, long long n, int dim,

@@ -48,7 +48,8 @@ hipError_t bh_launch_row_norm_max(const _Float16* rows, long long n, int dim_pad
 // A row x can belong to the true top-k of query q only if its canonical key reaches the k-th kept one, and
 // canonical(x) <= mfma(x) + err_coef |q| (the certificate's own bound), so every such row has
 //     mfma(x) >= score(k-th canonical key) - err_coef |q|  =: fix_thr[q].
-// The FILTER PASS (scan_topk.hip, ABL = 5: the 128-query scan's stream + MFMA loop with that fixed threshold) lists these
+// The FILTER PASS (scan_topk256.hip, ABL bit 64: the 256-query scan's stream + MFMA loop with that fixed threshold — 7.5 ms per
+// pass at 21 M x 768; where that kernel's tile is no wider, d = 1024, and for the other dims: scan_topk.hip, ABL = 5, 128 queries) lists these
 // rows — the top k and whatever lies within rounding error of the k-th score — for up to BH_EXACT_BATCH queries per
 // corpus pass, at the speed of a normal pass; bh_exact_rescore_kernel then gives each listed row its canonical score
 // (sequential fp64 sum in dimension order -> fp32: the arithmetic of merge_rescore.hip and of the oracle's plain C loop)
@@ -56,7 +57,7 @@ hipError_t bh_launch_row_norm_max(const _Float16* rows, long long n, int dim_pad
 // BH_EXACT_CAP rows per query).  (Round 2 ran an fp64 scan of EVERY row for 8 queries at a time: one thread per row,
 // uncoalesced, ~fp64-peak-bound at best — a corpus pass per 8 queries; the matrix cores do the same filtering for 128.)
 
-// Gathers the batch: query rows, k-th keys, thresholds.  One workgroup per slot of the 128-query tile.
+// Gathers the batch: query rows, k-th keys, thresholds.  One workgroup per slot of the filter kernel's query tile (128 or 256).
 __global__ void __launch_bounds__(256) bh_exact_prepare_kernel(const _Float16* qbuf, const int* todo, int nb, const bh_u64* kth_all,
                                                                float err_coef, int dim_padded, _Float16* q_out, bh_u64* kth_out,
                                                                float* thr_out) {
@@ -91,9 +92,10 @@ __global__ void __launch_bounds__(256) bh_exact_prepare_kernel(const _Float16* q
     }
 }
 
-hipError_t bh_launch_exact_prepare(const _Float16* qbuf, const int* todo, int nb, const bh_u64* kth_all, float err_coef, int dim_padded,
+hipError_t bh_launch_exact_prepare(const _Float16* qbuf, const int* todo, int nb, int tile, const bh_u64* kth_all, float err_coef, int dim_padded,
                                    _Float16* q_out, bh_u64* kth_out, float* thr_out, hipStream_t stream) {
-    hipLaunchKernelGGL(bh_exact_prepare_kernel, dim3(BH_EXACT_BATCH), dim3(256), 0, stream, qbuf, todo, nb, kth_all, err_coef, dim_padded,
+    if (tile <= 0 || tile > BH_EXACT_BATCH || nb > tile) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bh_exact_prepare_kernel, dim3((unsigned)tile), dim3(256), 0, stream, qbuf, todo, nb, kth_all, err_coef, dim_padded,
                        q_out, kth_out, thr_out);
     return hipGetLastError();
 }
@@ -129,5 +131,23 @@ __global__ void __launch_bounds__(256) bh_exact_rescore_kernel(BhExactArgs a) {
 hipError_t bh_launch_exact_rescore(const BhExactArgs& a, hipStream_t stream) {
     if (a.nqf <= 0 || a.nqf > BH_EXACT_BATCH || a.n_rows <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bh_exact_rescore_kernel, dim3(32, (unsigned)a.nqf), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// The fall-back's re-done lists -> their rows of the result buffers: list j of `src` goes to row todo[j] (the buffers may be
+// device memory or pinned host memory: the kernel writes either).
+__global__ void __launch_bounds__(256) bh_scatter_lists_kernel(const float* src_s, const long long* src_i, const int* todo, int k,
+                                                               float* out_s, long long* out_i) {
+    const int j = blockIdx.x, q = todo[j];
+    for (int t = threadIdx.x; t < k; t += 256) {
+        out_s[(size_t)q * k + t] = src_s[(size_t)j * k + t];
+        out_i[(size_t)q * k + t] = src_i[(size_t)j * k + t];
+    }
+}
+
+hipError_t bh_launch_scatter_lists(const float* src_s, const long long* src_i, const int* todo, int n, int k, float* out_s, long long* out_i,
+                                   hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_scatter_lists_kernel, dim3((unsigned)n), dim3(256), 0, stream, src_s, src_i, todo, k, out_s, out_i);
     return hipGetLastError();
 }

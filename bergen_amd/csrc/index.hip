@@ -745,9 +745,12 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
             hipEvent_t x0 = ix->event(2 + 4 * (size_t)n_group), x1 = ix->event(3 + 4 * (size_t)n_group);
             if (!x0 || !x1) return fail(BH_EHIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(x0, st));
-            // one FILTER PASS per BH_EXACT_BATCH (128) uncertified queries: the 128-query scan's stream + MFMA loop with the
-            // fixed threshold  k-th canonical score - error bound  lists every row that can still belong to the top k
-            // (scan_topk.hip ABL 5), bh_exact_rescore_kernel gives the listed rows their canonical scores, the host sorts
+            // one FILTER PASS per batch of uncertified queries: the scan's stream + MFMA loop with the fixed threshold
+            // k-th canonical score - error bound  lists every row that can still belong to the top k — 256 queries per pass on
+            // scan_topk256.hip (ABL bit 64) where it applies (option filter256; d = 384 / 512 / 768), else 128 on scan_topk.hip
+            // (ABL 5) —, bh_exact_rescore_kernel gives the listed rows their canonical scores, the host sorts
+            const bool f256 = opt.filter256 != 0 && bh_filter256_supports(dp) && grid % 8 == 0;
+            const int ftile = f256 ? 256 : 128;
             if ((rc = ix->exact_q.ensure((size_t)BH_EXACT_BATCH * dp))) return rc;
             if ((rc = ix->exact_keys.ensure((size_t)BH_EXACT_BATCH * BH_EXACT_CAP + BH_EXACT_BATCH))) return rc;
             if ((rc = ix->exact_rows.ensure((size_t)BH_EXACT_BATCH * BH_EXACT_CAP))) return rc;
@@ -757,13 +760,13 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
             float* thr_dev = reinterpret_cast<float*>(ix->exact_cnt.p + BH_EXACT_BATCH);
             int* todo_dev = reinterpret_cast<int*>(ix->exact_cnt.p + 2 * BH_EXACT_BATCH);
             std::vector<bh_u64> keys;
-            std::vector<float> row_s((size_t)k);
-            std::vector<long long> row_i((size_t)k);
-            for (size_t b0 = 0; b0 < todo.size(); b0 += BH_EXACT_BATCH) {
-                const int nb = (int)std::min<size_t>(BH_EXACT_BATCH, todo.size() - b0);
+            std::vector<float> st_s(todo.size() * (size_t)k);       // the re-done lists, in `todo` order
+            std::vector<long long> st_i(todo.size() * (size_t)k);
+            for (size_t b0 = 0; b0 < todo.size(); b0 += (size_t)ftile) {
+                const int nb = (int)std::min<size_t>((size_t)ftile, todo.size() - b0);
                 HIP_TRY(hipMemcpyAsync(todo_dev, todo.data() + b0, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, st));
                 HIP_TRY(hipMemsetAsync(cnt_dev, 0, BH_EXACT_BATCH * sizeof(unsigned), st));
-                HIP_TRY(bh_launch_exact_prepare(ix->qbuf.p, todo_dev, nb, ix->kth.p, err_coef, dp, ix->exact_q.p, kth_dev, thr_dev, st));
+                HIP_TRY(bh_launch_exact_prepare(ix->qbuf.p, todo_dev, nb, ftile, ix->kth.p, err_coef, dp, ix->exact_q.p, kth_dev, thr_dev, st));
                 BhScanArgs fa = scan_args(0, nullptr);
                 fa.qtile = ix->exact_q.p;
                 fa.cand = nullptr;
@@ -778,7 +781,21 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
                 fa.fix_cnt = cnt_dev;
                 fa.fix_rows = ix->exact_rows.p;
                 fa.fix_cap = BH_EXACT_CAP;
-                HIP_TRY(bh_launch_filter_scan(fa, dp, grid, st));
+                fa.dyn_tiles = 0;
+                fa.pair_window = 0;
+                fa.progress = nullptr;
+                if (f256 && use256 && bq == 256 && opt.dyn_tiles != 0) {
+                    // the claimed tail of the corpus (scan_topk256's dynamic tile distribution): the filter pass borrows the first
+                    // threshold block of the search — its passes are over (stream order) — for the claim counter
+                    HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)gthr_pass, 0x007fffffu, st, (long long)gthr_pass, (long long)bq * (BH_SLOTS256 + 1),
+                                               bh_scan256_first_claimed_tile((int)ix->n_tiles, grid, dp)));
+                    fa.gthr = ix->gthr.p;
+                    fa.dyn_tiles = 1;
+                }
+                if (f256)
+                    HIP_TRY(bh_launch_filter_scan256(fa, dp, grid, st));
+                else
+                    HIP_TRY(bh_launch_filter_scan(fa, dp, grid, st));
                 BhExactArgs ea;
                 ea.corpus = ix->rows;
                 ea.n_rows = ix->n_rows;
@@ -793,31 +810,53 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
                 unsigned cnt[BH_EXACT_BATCH];
                 HIP_TRY(hipMemcpyAsync(cnt, cnt_dev, sizeof cnt, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
+                unsigned max_cnt = 0;
                 for (int j = 0; j < nb; ++j) {
-                    const int q = todo[b0 + j];
                     if (cnt[j] > BH_EXACT_CAP)
                         return fail(BH_EUNSUPPORTED, "query %d: more than %d rows reach its k-th score within rounding error "
-                                    "(%u): exact fall-back list overflow", q, BH_EXACT_CAP, cnt[j]);
+                                    "(%u): exact fall-back list overflow", todo[b0 + j], BH_EXACT_CAP, cnt[j]);
+                    max_cnt = std::max(max_cnt, cnt[j]);
+                }
+                // the batch's key lists in ONE strided copy (a copy per query cost ~10 us each: 3 of them per uncertified query
+                // were a third of the fall-back's time on the clustered corpus)
+                keys.resize((size_t)nb * max_cnt);
+                if (max_cnt > 0)
+                    HIP_TRY(hipMemcpy2D(keys.data(), (size_t)max_cnt * sizeof(bh_u64), ix->exact_keys.p, (size_t)BH_EXACT_CAP * sizeof(bh_u64),
+                                        (size_t)max_cnt * sizeof(bh_u64), (size_t)nb, hipMemcpyDeviceToHost));
+                for (int j = 0; j < nb; ++j) {
                     n_filter_rows += cnt[j];
-                    keys.resize(cnt[j]);
-                    HIP_TRY(hipMemcpy(keys.data(), ix->exact_keys.p + (size_t)j * BH_EXACT_CAP, (size_t)cnt[j] * sizeof(bh_u64), hipMemcpyDeviceToHost));
-                    std::sort(keys.begin(), keys.end(), std::greater<bh_u64>());  // canonical order: score desc, row asc (0 = did not qualify: last)
+                    bh_u64* kq = keys.data() + (size_t)j * max_cnt;
+                    const size_t take = std::min<size_t>((size_t)k, cnt[j]);
+                    // canonical order: score desc, row asc (0 = did not qualify: last)
+                    std::partial_sort(kq, kq + take, kq + cnt[j], std::greater<bh_u64>());
+                    float* rs = st_s.data() + (b0 + (size_t)j) * k;
+                    long long* ri = st_i.data() + (b0 + (size_t)j) * k;
                     for (int t = 0; t < k; ++t) {
-                        if ((size_t)t < keys.size() && keys[(size_t)t] != 0ull) {
-                            const unsigned o = (unsigned)(keys[(size_t)t] >> 32);
+                        if ((size_t)t < take && kq[(size_t)t] != 0ull) {
+                            const unsigned o = (unsigned)(kq[(size_t)t] >> 32);
                             const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-                            memcpy(&row_s[(size_t)t], &u, 4);
-                            row_i[(size_t)t] = id_offset + (long long)(unsigned)~(unsigned)keys[(size_t)t];
+                            memcpy(&rs[t], &u, 4);
+                            ri[t] = id_offset + (long long)(unsigned)~(unsigned)kq[(size_t)t];
                         } else {
-                            row_s[(size_t)t] = -INFINITY;
-                            row_i[(size_t)t] = -1;
+                            rs[t] = -INFINITY;
+                            ri[t] = -1;
                         }
                     }
-                    HIP_TRY(hipMemcpy(out_scores_dev + (size_t)q * k, row_s.data(), (size_t)k * sizeof(float), hipMemcpyDefault));  // (the result buffers may be pinned host memory)
-                    HIP_TRY(hipMemcpy(reinterpret_cast<long long*>(out_ids_dev) + (size_t)q * k, row_i.data(), (size_t)k * sizeof(long long),
-                                      hipMemcpyDefault));
                 }
                 ++n_filter_passes;
+            }
+            // the re-done lists go to their rows of the result buffers (device memory or pinned host memory alike) in one launch
+            {
+                const size_t nt = todo.size();
+                const size_t bytes_s = nt * k * sizeof(float), bytes_i = nt * k * sizeof(long long), off_i = (bytes_s + 15) & ~(size_t)15,
+                             off_t = off_i + ((bytes_i + 15) & ~(size_t)15);
+                if ((rc = ix->staging.ensure(off_t + nt * sizeof(int)))) return rc;
+                HIP_TRY(hipMemcpyAsync(ix->staging.p, st_s.data(), bytes_s, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(ix->staging.p + off_i, st_i.data(), bytes_i, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(ix->staging.p + off_t, todo.data(), nt * sizeof(int), hipMemcpyHostToDevice, st));
+                HIP_TRY(bh_launch_scatter_lists(reinterpret_cast<const float*>(ix->staging.p), reinterpret_cast<const long long*>(ix->staging.p + off_i),
+                                                reinterpret_cast<const int*>(ix->staging.p + off_t), (int)nt, k, out_scores_dev,
+                                                reinterpret_cast<long long*>(out_ids_dev), st));
             }
             HIP_TRY(hipEventRecord(x1, st));
             HIP_TRY(hipStreamSynchronize(st));

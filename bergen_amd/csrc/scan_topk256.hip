@@ -232,9 +232,21 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     unsigned cnt[NB];    // entries in the query's candidate buffer (identical in the four lanes of a query)
     float best[NB][RB];  // this lane's RB best appended scores, descending
     int next_poll = 0;
+    // ABL bit 64 is not an ablation but the FILTER PASS of the exactness fall-back (certify.hip, index.hip; the 128-query
+    // kernel's ABL = 5 on this kernel's 256-query tile): the same stream, fragment pipeline and MFMA loop, but a FIXED
+    // threshold per query (a.fix_thr: a row qualifies iff its MFMA score >= it) and no top-k state — no bootstrap, no bounds,
+    // no candidate buffers, no lists: every qualifying row index is appended to the query's list a.fix_rows (few rows: the
+    // top k and whatever lies within rounding error of the k-th score).
+    constexpr bool FILT = (ABL & 64) != 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         thr[nb] = -__builtin_inff();
+        if constexpr (FILT) {
+            // the scan's compare is exclusive: the next float below the inclusive threshold (+inf = unused query of the tile:
+            // nothing qualifies; -inf = the query's list was not full: every row does)
+            const float x = a.fix_thr[(wave * NB + nb) * 16 + q16];
+            thr[nb] = (x > -__builtin_inff() && x < __builtin_inff()) ? bh_unordf(bh_ordf(x) - 1u) : x;
+        }
         cnt[nb] = 0;
 #pragma unroll
         for (int r = 0; r < RB; ++r) best[nb][r] = -__builtin_inff();
@@ -309,7 +321,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     // 1.166 ms per pass over an eighth of the corpus, 7.22 / - / 7.21 / 7.23 / 7.29 ms over all of it): a slot's value
     // is the score of a row that this workgroup — and no other — appends when the scan proper comes by, so distinct slots
     // still stand for distinct rows and the bound stays valid.
-    const int nboot = !a.share ? 0 : run_len < BH_BOOT_TILES ? run_len : BH_BOOT_TILES;
+    const int nboot = (!a.share || FILT) ? 0 : run_len < BH_BOOT_TILES ? run_len : BH_BOOT_TILES;
     const int boot_step = (run_len / BH_BOOT_TILES > 1 ? run_len / BH_BOOT_TILES : 1) * run_stride;  // in tiles
     unsigned* lds_claim = reinterpret_cast<unsigned*>(smem + R * STAGE_BYTES);
     if (run_len > 0) {
@@ -543,7 +555,26 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if (any_hit) {
+                if constexpr (FILT) {
+                    if (any_hit) {  // filter pass: list the qualifying rows of this tile (rare: one atomic per listed row)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int qi = (wave * NB + nb) * 16 + q16;
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    const float sv = acc[rb][nb][v];
+                                    const unsigned row = row0 + (unsigned)(rb * 16 + v) + 4u * (unsigned)lg;
+                                    if (sv > thr[nb] && row < n_rows32) {
+                                        const unsigned slot = atomicAdd(a.fix_cnt + qi, 1u);
+                                        if (slot < a.fix_cap) a.fix_rows[(size_t)qi * a.fix_cap + slot] = row;
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                        }
+                    }
+                } else if (any_hit) {
                     // (1) append survivors (room for 32 entries per query is guaranteed by (2) of the previous visit);
                     //     slot = count + hits of the same query in the lower lane groups.  Hits are rare: the per-row test is
                     //     a fall-through branch, the work sits out of line.
@@ -730,6 +761,8 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         a.clk[8 * b + 5] = __builtin_readcyclecounter();
     }
 
+    if constexpr (FILT) return;  // (a filter pass has no lists to publish)
+
     // ---- final: every wave sorts its queries' buffers and publishes the best KP.  Once the bounds work a buffer holds a
     // handful of candidates: eight buffers of up to 64 entries are loaded together and sorted side by side (the 21 stages
     // of a 64-key sort are a chain of LDS-crossbar shuffles; eight independent chains hide each other's latency)
@@ -838,6 +871,20 @@ bool bh_scan256_supports(int dim_padded, int kp) {
     return (dim_padded == 1024 || dim_padded == 768 || dim_padded == 512 || dim_padded == 384) && (kp == 64 || kp == 128 || kp == 256);
 }
 int bh_scan256_tile(int dim_padded) { return dim_padded == 1024 ? 128 : 256; }
+
+// the exact fall-back's filter pass on the 256-query tile (d = 384 / 512 / 768; at d = 1024 this kernel's tile is 128 queries
+// wide, no wider than scan_topk.hip's filter pass, which serves it)
+bool bh_filter256_supports(int dim_padded) { return dim_padded == 768 || dim_padded == 512 || dim_padded == 384; }
+hipError_t bh_launch_filter_scan256(const BhScanArgs& a, int dim_padded, int grid, hipStream_t stream) {
+    if (!bh_filter256_supports(dim_padded) || a.qsplit != 1 || !a.fix_thr || !a.fix_cnt || !a.fix_rows || a.share != 0 || (a.dyn_tiles != 0 && !a.gthr))
+        return hipErrorInvalidValue;
+    switch (dim_padded) {
+        case 384: return launch256_one<12, 64, 6, 6, 4, 64>(a, grid, stream);
+        case 512: return launch256_one<16, 64, 4, 9, 4, 64>(a, grid, stream);
+        case 768: return launch256_one<24, 64, 12, 3, 4, 64, 0>(a, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
 
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream) {
     if (!bh_scan256_supports(dim_padded, kp) || a.qsplit != 1) return hipErrorInvalidValue;

@@ -61,6 +61,12 @@ def test_production_kernels_do_not_spill():
                 continue
             assert u.get("ScratchSize", 0) == 0, f"{src}: {name} spills {u.get('ScratchSize')} bytes/lane"
     assert seen >= 200
+    # the filter-pass instantiations (ABL bit 64: the exact fall-back's production path, not an ablation) match the bench-only
+    # pattern above: checked by name
+    filt = [n for n in results["scan_topk256.hip"] if re.search(r"bh_scan_topk256_kernelILi\d+ELi64ELi\d+ELi\d+ELi\d+ELb1ELi64E", n)]
+    assert len(filt) == 3, filt
+    for n in filt:
+        assert results["scan_topk256.hip"][n].get("ScratchSize", 0) == 0, n
     # the one whitelisted production instantiation: no more than the 32 bytes the comment above accounts for
     for name, u in results["scan_topk256.hip"].items():
         if re.search(r"bh_scan_topk256_kernelILi24ELi256ELi12ELi3ELi4ELb[01]ELi0E", name):

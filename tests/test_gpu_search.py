@@ -510,15 +510,19 @@ def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
         ix.close()
 
 
+@pytest.mark.parametrize("filter256", [1, 0])
 @pytest.mark.parametrize("n,d,nq,k", [(30_011, 768, 300, 50), (9_000, 1024, 130, 200), (5_000, 384, 70, 100), (3_000, 100, 40, 10),
-                                      (2_000, 64, 9, 5), (4_000, 512, 129, 120), (4_001, 200, 5, 248)])
-def test_fall_back_filter_pass_is_exact_for_every_query(amd, n, d, nq, k):
+                                      (2_000, 64, 9, 5), (4_000, 512, 129, 120), (4_001, 200, 5, 248), (20_000, 768, 600, 50),
+                                      (6_000, 512, 257, 50)])
+def test_fall_back_filter_pass_is_exact_for_every_query(amd, n, d, nq, k, filter256):
     """The exact fall-back on its own: with the certificate's error bound scaled up (test option
     certificate_error_scale) NO query can be certified, so every result comes from the MFMA filter pass (fixed threshold =
-    k-th canonical score - bound; scan_topk.hip ABL 5) + canonical re-scoring of the rows it lets through + the host sort.
-    Bit-exact against the oracle at every padded dim, across the 128-query batches of the fall-back, with exact duplicates
-    straddling the k-th rank."""
+    k-th canonical score - bound) + canonical re-scoring of the rows it lets through + the host sort.  The filter pass takes
+    256 queries on scan_topk256.hip (ABL bit 64) at d = 384 / 512 / 768 (option filter256, default) and 128 on scan_topk.hip
+    (ABL 5) elsewhere or with the option off.  Bit-exact against the oracle at every padded dim, across the batches of the
+    fall-back (600 queries = three batches of 256 / five of 128), with exact duplicates straddling the k-th rank."""
     from bergen_amd import _lib
+    ftile = 256 if (filter256 and d in (384, 512, 768)) else 128
     rng = np.random.default_rng(n + d + k)
     x = rng.standard_normal((n, d)).astype(np.float16)
     q = rng.standard_normal((nq, d)).astype(np.float16)
@@ -527,18 +531,19 @@ def test_fall_back_filter_pass_is_exact_for_every_query(amd, n, d, nq, k):
     ix = amd.FlatIndex(n, d, metric="ip")
     ix.upload(x)
     ix.finalize()
+    ix.set_option("filter256", filter256)
     try:
         _lib.set_option("certificate_error_scale", 32)   # a bound a little wider than the gaps: most queries, short lists
         s, i = ix.search(q, k)
         c = ix.counters()
-        assert c["uncertified_queries"] <= nq and c["exact_passes"] == -(-c["uncertified_queries"] // 128)  # (none on a small corpus: wide gaps)
+        assert c["uncertified_queries"] <= nq and c["exact_passes"] == -(-c["uncertified_queries"] // ftile)  # (none on a small corpus: wide gaps)
         compare.assert_bit_exact(s, i, ws, wi, f"fall-back for most queries n={n} d={d} nq={nq} k={k}")
         _lib.set_option("certificate_error_scale", 1 << 12)  # a bound wider than the score range: every query, every row listed
         s, i = ix.search(q, k)
         c = ix.counters()
         # (a query whose per-workgroup lists never filled is certified whatever the bound — nothing was dropped —, and at small
         # d the scaled bound still sits below the score gaps: the "every query" claim is for the wide shapes)
-        assert c["exact_passes"] == -(-c["uncertified_queries"] // 128)
+        assert c["exact_passes"] == -(-c["uncertified_queries"] // ftile)
         if d >= 200:
             assert c["uncertified_queries"] == nq and c["exact_ms"] > 0 and c["exact_rows_rescored"] >= nq * k
         compare.assert_bit_exact(s, i, ws, wi, f"fall-back only n={n} d={d} nq={nq} k={k}")
