@@ -186,6 +186,12 @@ class Retrieve:
         direct = (self.resident_on_encode and query_or_doc == 'doc' and self.encode_world == 1 and self.continue_batch is None
                   and torch.cuda.is_available() and not getattr(self.model, 'sparse', False) and 'splade' not in self.model.model_name)
         resident, row = None, 0
+        # chunk files are written BEHIND the encoder: torch.cat + torch.save of a 150 k-row chunk (230 MB) takes a few tenths of a
+        # second in which the GPU would idle every 5 s of encoding; one writer thread (chunks stay in order), joined before the
+        # call returns — a chunk's existence still means "complete" (temporary name + rename in _flush_chunk)
+        from concurrent.futures import ThreadPoolExecutor
+        writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="bergen-chunk-writer")
+        writes = []
         try:
             for i, batch in progress:
                 if self.continue_batch is not None and i <= self.continue_batch:
@@ -198,8 +204,10 @@ class Retrieve:
                     row += emb.shape[0]
                 pieces.append(emb.cpu())
                 if (i != 0 and i % cadence == 0) or i == b_hi - 1:
-                    self._flush_chunk(save_path, i, pieces)
+                    writes.append(writer.submit(self._flush_chunk, save_path, i, pieces))
                     pieces = []
+            for w in writes:
+                w.result()  # (re-raises a failed write here)
             if resident is not None:
                 if row != len(dataset):
                     raise IOError(_INCOMPLETE.format(len(dataset) - row))
@@ -212,6 +220,7 @@ class Retrieve:
                 self._resident[save_path] = (resident, signature)
                 resident = None
         finally:
+            writer.shutdown(wait=True)
             if resident is not None:
                 resident.close()
         self.model.model = self.model.model.to('cpu')
@@ -231,18 +240,27 @@ class Retrieve:
                 rows = [dict(zip(names, vals)) for vals in zip(*(cols[c] for c in names))]
             return self.model.collate_fn(rows, query_or_doc)
 
-        with ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="bergen-tokenize") as pool:
-            pending, starts = deque(), iter(range(0, n, bs))
-            for b0 in starts:
-                pending.append(pool.submit(make, b0))
-                if len(pending) >= 2 * self.num_workers:
-                    break
-            while pending:
-                batch = pending.popleft().result()
-                nxt = next(starts, None)
-                if nxt is not None:
-                    pending.append(pool.submit(make, nxt))
-                yield batch
+        # The tokeniser threads hold the GIL while they turn token ids into Python objects; the thread that drives the GPU
+        # needs it for microseconds between two forward passes (the ctypes call itself runs without it).  CPython hands the
+        # GIL over only every `switchinterval` (5 ms by default): a quarter of a 17 ms forward pass lost per hand-over, and more
+        # tokeniser threads meant more of them (round 3: 16 threads slower than 4).  0.2 ms while the loader runs.
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 2e-4))
+        try:
+            with ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="bergen-tokenize") as pool:
+                pending, starts = deque(), iter(range(0, n, bs))
+                for b0 in starts:
+                    pending.append(pool.submit(make, b0))
+                    if len(pending) >= 2 * self.num_workers:
+                        break
+                while pending:
+                    batch = pending.popleft().result()
+                    nxt = next(starts, None)
+                    if nxt is not None:
+                        pending.append(pool.submit(make, nxt))
+                    yield batch
+        finally:
+            sys.setswitchinterval(old_interval)
 
     def _batch_range(self, n_batches, rank=None):
         """Contiguous range of batches [b_lo, b_hi) that process `rank` of `encode_world` encodes."""
