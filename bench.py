@@ -60,7 +60,7 @@ def parse_args():
     p.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] geometry (d = 1024, top-200) search leg")
     p.add_argument("--no-real-size", action="store_true", help="skip the headline search at KILT-100w's real row count (24 853 637 rows)")
     p.add_argument("--no-certificate-leg", action="store_true", help="skip the certificate / fall-back leg on the clustered, non-unit-norm corpus")
-    p.add_argument("--encode-stage-passages", type=int, default=16384, help="passages of the Retrieve.encode_and_save leg (0 = skip)")
+    p.add_argument("--encode-stage-passages", type=int, default=32768, help="passages of the Retrieve.encode_and_save leg (0 = skip)")
     p.add_argument("--no-stage", action="store_true", help="skip the Retrieve.retrieve-level leg at the headline size (resident index -> doc-id strings)")
     p.add_argument("--folder-stage", action="store_true",
                    help="also run Retrieve.retrieve on a reference-layout folder of --stage-rows documents (first call loads the folder); off by "
@@ -681,10 +681,17 @@ def encode_stage_leg(args, device_index):
         for b0 in range(0, n_pass, 512):
             dense.collate_fn([{"content": x} for x in texts[b0:b0 + 512]], "doc")
         res["tokenizer_only_passages_per_s_one_process"] = n_pass / (time.perf_counter() - t0)
-        for loader, workers in (("threads", 4), ("threads", 16), ("processes", 4), ("inline", 0)):
+        # "threads": the stage's default loader — on a many-core host every batch is tokenised in eight pieces by up to 32 threads,
+        # each piece serially; "threads_whole": whole batches on 4 / 16 threads that share the tokenizer's own thread pool (the
+        # round-3 loader, BERGEN_AMD_TOKENIZER_PIECES=0); "processes": the reference's DataLoader workers; "inline": none
+        for loader, workers in (("threads", 4), ("threads_whole", 4), ("threads_whole", 16), ("processes", 4), ("inline", 0)):
             stage = bergen_amd.Retrieve(init_args=dense, batch_size=512, num_workers=workers, device=device_index,
-                                        loader="threads" if loader == "inline" else loader)
+                                        loader="processes" if loader == "processes" else "threads")
             path = os.path.join(root, f"idx_{loader}{workers}")
+            if loader == "threads_whole":
+                os.environ["BERGEN_AMD_TOKENIZER_PIECES"] = "0"
+            else:
+                os.environ.pop("BERGEN_AMD_TOKENIZER_PIECES", None)
             try:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -692,11 +699,16 @@ def encode_stage_leg(args, device_index):
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 rows = sum(int(torch.load(os.path.join(path, f)).shape[0]) for f in os.listdir(path))
+                st = getattr(stage, "last_encode_stats", None) or {}
                 res[f"workers_{loader}_{workers}"] = {"passages_per_s": n_pass / dt, "seconds": dt, "rows_written": rows,
-                                                      "chunk_files": len(os.listdir(path))}
+                                                      "chunk_files": len(os.listdir(path)),
+                                                      "steady_state_passages_per_s": st.get("steady_state_rows_per_s"),
+                                                      "first_batch_seconds": st.get("first_batch_seconds"),
+                                                      "last_chunk_write_seconds": st.get("last_chunk_write_seconds")}
             except Exception as exc:
                 res[f"workers_{loader}_{workers}"] = {"error": repr(exc)}
             shutil.rmtree(path, ignore_errors=True)
+        os.environ.pop("BERGEN_AMD_TOKENIZER_PIECES", None)
         good = [v["passages_per_s"] for kk, v in res.items() if kk.startswith("workers_") and "passages_per_s" in v]
         res["passages_per_s"] = max(good) if good else None
         return res

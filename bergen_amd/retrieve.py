@@ -193,10 +193,18 @@ class Retrieve:
         writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="bergen-chunk-writer")
         writes = []
         try:
+            import time as _time
+            t_start = _time.perf_counter()
+            t_first = t_last = None
+            rows_first = rows_done = 0
             for i, batch in progress:
                 if self.continue_batch is not None and i <= self.continue_batch:
                     continue  # resume: batches up to continue_batch were saved by an earlier run
                 emb = self.model(query_or_doc, batch)['embedding'].detach()
+                t_last = _time.perf_counter()
+                rows_done += int(emb.shape[0])
+                if t_first is None:
+                    t_first, rows_first = t_last, rows_done
                 if direct and emb.is_cuda and emb.ndim == 2:
                     if resident is None:
                         resident = FlatIndex(len(dataset), emb.shape[1], metric=_metric_of(self.model), device=self.device)
@@ -208,6 +216,15 @@ class Retrieve:
                     pieces = []
             for w in writes:
                 w.result()  # (re-raises a failed write here)
+            # where the call's time went (bench.py's encode_stage leg reads it): the rate between the first and the last batch
+            # leaving the encoder is the pipeline's steady state; what surrounds it — tokenising the first batch, writing the last
+            # chunk — is paid once per call, whatever the corpus size
+            t_end = _time.perf_counter()
+            self.last_encode_stats = {
+                "rows": rows_done, "seconds": t_end - t_start,
+                "first_batch_seconds": (t_first - t_start) if t_first is not None else None,
+                "last_chunk_write_seconds": (t_end - t_last) if t_last is not None else None,
+                "steady_state_rows_per_s": ((rows_done - rows_first) / (t_last - t_first)) if t_first is not None and t_last > t_first else None}
             if resident is not None:
                 if row != len(dataset):
                     raise IOError(_INCOMPLETE.format(len(dataset) - row))
@@ -232,13 +249,27 @@ class Retrieve:
         from concurrent.futures import ThreadPoolExecutor
         n, bs = len(source), self.batch_size
 
-        def make(b0):
-            rows = [source[j] for j in range(b0, min(n, b0 + bs))] if not hasattr(source, "select") else None
+        def make(lo, hi):  # rows [lo, hi) of the source through the model's collate_fn (tokeniser)
+            rows = [source[j] for j in range(lo, hi)] if not hasattr(source, "select") else None
             if rows is None:
-                cols = source[b0:min(n, b0 + bs)]  # HF Dataset slice: dict of column lists
+                cols = source[lo:hi]  # HF Dataset slice: dict of column lists
                 names = list(cols)
                 rows = [dict(zip(names, vals)) for vals in zip(*(cols[c] for c in names))]
             return self.model.collate_fn(rows, query_or_doc)
+
+        pad_id = getattr(getattr(self.model, "tokenizer", None), "pad_token_id", None)
+
+        def merge(parts):
+            """Pieces of ONE batch, each padded to its own longest row, as the batch padded to ITS longest row — what
+            collate_fn over the whole batch returns (padding="longest", right side)."""
+            if len(parts) == 1:
+                return parts[0]
+            width = max(int(p["input_ids"].shape[1]) for p in parts)
+            out = {}
+            for key in parts[0].keys():
+                fill = int(pad_id) if key == "input_ids" else 0
+                out[key] = torch.cat([torch.nn.functional.pad(p[key], (0, width - int(p[key].shape[1])), value=fill) for p in parts])
+            return type(parts[0])(out)
 
         # The tokeniser threads hold the GIL while they turn token ids into Python objects; the thread that drives the GPU
         # needs it for microseconds between two forward passes (the ctypes call itself runs without it).  CPython hands the
@@ -246,21 +277,60 @@ class Retrieve:
         # tokeniser threads meant more of them (round 3: 16 threads slower than 4).  0.2 ms while the loader runs.
         old_interval = sys.getswitchinterval()
         sys.setswitchinterval(min(old_interval, 2e-4))
+        # How many threads, and who parallelises.  A Rust tokenizer's encode_batch spreads ONE call over every core (rayon); a few
+        # callers at once then share that pool and trip over each other (round 3 / 4 on the 256-core GPU host: 4 callers 26 k
+        # passages/s, 16 callers 19 k, one caller 13.6 k).  With enough cores the stage parallelises itself instead: every batch
+        # is cut into PIECES, each tokenised serially by one of many threads (TOKENIZERS_PARALLELISM=false is read per call) and
+        # merged back in order — throughput = threads x one core's ~2.9 k passages/s, no shared pool, and a batch is ready after
+        # an eighth of its serial time.  Few cores (or a model without a right-padding tokenizer): whole batches, the tokenizer's
+        # own pool.
+        n_threads = max(int(self.num_workers), min(32, (os.cpu_count() or 4) // 4))
+        tok = getattr(self.model, "tokenizer", None)
+        serial = (n_threads >= 8 and pad_id is not None and getattr(tok, "padding_side", "right") == "right"
+                  and os.environ.get("BERGEN_AMD_TOKENIZER_PIECES", "1") != "0")  # (0: whole batches on num_workers threads, for A/B)
+        n_pieces = 8 if serial else 1
+        old_par = os.environ.get("TOKENIZERS_PARALLELISM")
+        if serial:
+            os.environ["TOKENIZERS_PARALLELISM"] = "false"
+        else:
+            n_threads = int(self.num_workers)
+
+        pieces = [n_pieces]  # (1 from the moment a batch's pieces turn out not to be mergeable)
+
+        def submit(pool, b0):
+            hi = min(n, b0 + bs)
+            step = -(-(hi - b0) // pieces[0])
+            return b0, [pool.submit(make, lo, min(hi, lo + step)) for lo in range(b0, hi, step)]
+
+        def mergeable(parts):
+            return all(hasattr(p, "keys") and "input_ids" in p and all(torch.is_tensor(p[k_]) and p[k_].ndim == 2 for k_ in p.keys())
+                       for p in parts)
+
         try:
-            with ThreadPoolExecutor(max_workers=self.num_workers, thread_name_prefix="bergen-tokenize") as pool:
+            with ThreadPoolExecutor(max_workers=n_threads, thread_name_prefix="bergen-tokenize") as pool:
                 pending, starts = deque(), iter(range(0, n, bs))
+                ahead = max(2, 2 * n_threads // n_pieces)  # batches in flight
                 for b0 in starts:
-                    pending.append(pool.submit(make, b0))
-                    if len(pending) >= 2 * self.num_workers:
+                    pending.append(submit(pool, b0))
+                    if len(pending) >= ahead:
                         break
                 while pending:
-                    batch = pending.popleft().result()
+                    b0, futures = pending.popleft()
+                    parts = [f.result() for f in futures]
+                    if len(parts) > 1 and not mergeable(parts):  # (a collate_fn of another kind: whole batches from here on)
+                        pieces[0] = 1
+                        parts = [make(b0, min(n, b0 + bs))]
                     nxt = next(starts, None)
                     if nxt is not None:
-                        pending.append(pool.submit(make, nxt))
-                    yield batch
+                        pending.append(submit(pool, nxt))
+                    yield merge(parts)
         finally:
             sys.setswitchinterval(old_interval)
+            if serial:
+                if old_par is None:
+                    os.environ.pop("TOKENIZERS_PARALLELISM", None)
+                else:
+                    os.environ["TOKENIZERS_PARALLELISM"] = old_par
 
     def _batch_range(self, n_batches, rank=None):
         """Contiguous range of batches [b_lo, b_hi) that process `rank` of `encode_world` encodes."""

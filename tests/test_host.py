@@ -181,6 +181,50 @@ def test_fast_tokenize_equals_the_hf_call():
     assert fast_tokenize(object(), texts, 16) is None  # not a fast tokenizer: the caller falls back to the HF call
 
 
+def test_piecewise_tokeniser_threads_give_the_whole_batch_result(monkeypatch):
+    """On a many-core host the stage cuts every batch into eight pieces, each tokenised serially by one of many threads
+    (Retrieve._threaded_batches), and pads the pieces back to the batch's longest row: the batches must equal collate_fn over the
+    whole batch — values, shapes, order — and the process-wide settings it borrows (tokenizer parallelism, GIL switch interval)
+    must be back afterwards.  A collate_fn whose output is not a set of [B, T] tensors falls back to whole batches."""
+    import sys
+    from bergen_amd import retrieve as R
+    from bergen_amd.dense import fast_tokenize
+    from tests import ut1_fixture
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ut1.npz"))
+    tok, _ = ut1_fixture.tokenizer_for([str(w) for w in z["words"]])
+    texts = [str(t) for t in z["doc_texts"]] * 3 + ["", "the " * 300]
+    monkeypatch.setattr(os, "cpu_count", lambda: 64)
+    monkeypatch.delenv("TOKENIZERS_PARALLELISM", raising=False)
+
+    class Model:
+        model_name = "piecewise"
+        tokenizer = tok
+
+        def collate_fn(self, rows, query_or_doc):
+            return fast_tokenize(tok, [r["content"] for r in rows], 32)
+
+    class Odd(Model):
+        def collate_fn(self, rows, query_or_doc):
+            return [r["content"] for r in rows]  # not tensors
+
+    src = [{"content": t} for t in texts]
+    for model in (Model(), Odd()):
+        stage = R.Retrieve.__new__(R.Retrieve)
+        stage.model, stage.batch_size, stage.num_workers = model, 64, 4
+        before = sys.getswitchinterval()
+        got = list(stage._threaded_batches(src, "doc"))
+        assert sys.getswitchinterval() == before and "TOKENIZERS_PARALLELISM" not in os.environ
+        assert len(got) == -(-len(src) // 64)
+        for j, batch in enumerate(got):
+            want = model.collate_fn(src[j * 64:(j + 1) * 64], "doc")
+            if isinstance(want, list):
+                assert batch == want
+            else:
+                assert list(batch.keys()) == list(want.keys())
+                for key in want.keys():
+                    assert torch.equal(batch[key], want[key]), (j, key)
+
+
 def test_retrieve_defaults_match_reference_signature():
     import inspect
     sig = inspect.signature(Retrieve.__init__)
