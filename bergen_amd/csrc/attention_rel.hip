@@ -14,8 +14,12 @@
 // (2 span columns), produced per layer and head by the MFMA GEMM (encoder.hip); this kernel is bh_attention_kernel
 // (attention.hip: K and V^T of the (sequence, head) staged in LDS once, S^T = K Q^T on the matrix cores, a lane owns one
 // query and 16 of a block's 32 key scores, online softmax in fp32, O^T += V^T P) with the two gathered terms added to the
-// scores before the softmax — 32 two-byte gathers per lane and 32 x 32 block, from L2.  Correctness first: the gathers
-// dominate its run time (a cross-encoder batch is 32 pairs: small next to the bi-encoder's 512 passages).
+// scores before the softmax.  Round 3 gathered them straight from L2 (32 two-byte loads per lane and 32 x 32 block, every one of
+// a wave's load instructions touching up to 64 cache lines: 127 us per launch at DeBERTa-v3-large's shape, plain attention 46-77).
+// Round 4 (WIN = true, sequences up to 320 tokens): t(delta) is monotone, so a (query block, key block) pair only needs the
+// columns [t(delta_min), t(delta_max)] — at most 63 — of 32 rows of c2p and 32 rows of p2c: two 32 x 72 windows (the range
+// aligned down to 8 columns) are fetched with coalesced 16-byte loads issued BEFORE the block's QK^T MFMAs, parked in the wave's
+// own 9 KiB of LDS behind them, and the per-score lookups become two-byte LDS reads.
 #include "bh_device.h"
 #include "bh_kernels.h"
 
@@ -30,6 +34,7 @@ __device__ __forceinline__ float rel_half_lanes_sum(float v) {
 }
 }  // namespace
 
+template <bool WIN>
 __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWV = 8, NT = 512;
@@ -109,6 +114,10 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
     }
     const _Float16* c2p_h = a.c2p + (size_t)head * a.rel_head_stride;
     const _Float16* p2c_h = a.p2c + (size_t)head * a.rel_head_stride;
+    // position windows of this wave: [0] c2p rows of the query block, [1] p2c rows of the key block; 32 rows x 72 halfs each
+    constexpr int WCOLS = 72, WCH = WCOLS / 8;           // 9 chunks of 16 bytes per row
+    constexpr int WITEMS = 32 * WCH, WIT = (WITEMS + 63) / 64;  // 288 (row, chunk) items per window: 5 rounds of 64 lanes
+    _Float16* win = reinterpret_cast<_Float16*>(smem + a.win_lds_off + wave * (2 * 32 * WCOLS * 2));
 
     for (int qb = wave; qb * 32 < len; qb += NWV) {
         const int q0 = qb * 32;
@@ -126,6 +135,35 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
         for (int kb = 0; kb < nkb; ++kb) {
             const unsigned char* kt = smK + kb * 4096;
             const unsigned char* vt = smV + kb * 4096;
+            // ---- position windows: columns [tlo8, tlo8 + 72) of the block pair's rows, loads issued now, parked in LDS behind
+            // the QK^T MFMAs (t is monotone in delta: every t of the pair lies in [t(delta_min), t(delta_max)], <= 63 wide)
+            int tlo8 = 0;
+            half8 wreg[2][WIT];
+            if constexpr (WIN) {
+                int dmin = q0 - (kb * 32 + 31), dmax = q0 + 31 - kb * 32;
+                dmin = dmin > -(len - 1) ? dmin : -(len - 1);
+                dmax = dmax < len - 1 ? dmax : len - 1;
+                tlo8 = __builtin_amdgcn_readfirstlane(ridx[dmin + len - 1]) & ~7;
+                // (rows are rel_ld = 2 span columns, a multiple of 8 like tlo8: a window chunk lies inside the row or wholly beyond it
+                // — then it is fetched from the row's last chunk instead and never asked for, t <= 2 span - 1)
+                const int last = a.rel_ld - 8;
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int item = it * 64 + lane;
+                    const int r = item / WCH, ch = item - r * WCH;
+                    int col = tlo8 + ch * 8;
+                    col = col < last ? col : last;
+                    if (item < WITEMS) {
+                        int qr = q0 + r;
+                        qr = qr < len ? qr : len - 1;
+                        int kr = kb * 32 + r;
+                        kr = kr < len ? kr : len - 1;
+                        wreg[0][it] = *reinterpret_cast<const half8*>(c2p_h + (size_t)(t0 + qr) * a.rel_ld + col);
+                        wreg[1][it] = *reinterpret_cast<const half8*>(p2c_h + (size_t)(t0 + kr) * a.rel_ld + col);
+                    }
+                }
+                (void)dmax;
+            }
             half8 kf[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) kf[s4] = *reinterpret_cast<const half8*>(kt + k_off[s4]);
@@ -143,6 +181,16 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[s4], qf[s4], sc, 0, 0, 0);
 
+            if constexpr (WIN) {  // windows -> this wave's LDS (wave-private: its own waits order the stores and the reads below)
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int item = it * 64 + lane;
+                    if (item < WITEMS) {
+                        *reinterpret_cast<half8*>(win + item * 8) = wreg[0][it];
+                        *reinterpret_cast<half8*>(win + 32 * WCOLS + item * 8) = wreg[1][it];
+                    }
+                }
+            }
             // + c2p[i][t(i - j)] + p2c[j][t(i - j)], mask keys beyond the sequence, block max
             const int key0 = kb * 32 + 4 * h;
             float bmax = -__builtin_inff();
@@ -151,7 +199,13 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
                 const int key = key0 + (v & 3) + 8 * (v >> 2);
                 const int kk = key < len ? key : len - 1;
                 const int t = ridx[qrow - kk + len - 1];
-                const float bias = (float)c2p_row[t] + (float)p2c_h[(size_t)(t0 + kk) * a.rel_ld + t];
+                float bias;
+                if constexpr (WIN) {
+                    const int wc = t - tlo8;  // 0 .. 69: t lies in [t(delta_min), t(delta_min) + 62], tlo8 at most 7 below
+                    bias = (float)win[ql * WCOLS + wc] + (float)win[32 * WCOLS + (kk - kb * 32) * WCOLS + wc];
+                } else {
+                    bias = (float)c2p_row[t] + (float)p2c_h[(size_t)(t0 + kk) * a.rel_ld + t];
+                }
                 sc[v] = key < len ? sc[v] + bias : -__builtin_inff();
                 bmax = fmaxf(bmax, sc[v]);
             }
@@ -207,18 +261,27 @@ hipError_t bh_launch_attention_rel(const BhAttnArgs& a_in, int batch, int n_head
     if (!a_in.c2p || !a_in.p2c || !a_in.rel_idx || a_in.rel_ld <= 0 || max_len - 1 > a_in.rel_center) return hipErrorInvalidValue;
     const int nkb = (max_len + 31) / 32;
     const size_t table = ((size_t)(2 * max_len) * sizeof(int) + 15) / 16 * 16;
-    const size_t smem = (size_t)nkb * 8192 + table;
+    const size_t base = (size_t)nkb * 8192 + table;
+    const size_t windows = (size_t)8 * 2 * 32 * 72 * 2;  // eight waves x two 32 x 72 fp16 windows
+    // the LDS windows of the position terms where they fit beside the sequence's K / V^T (up to 320 tokens), rows of at least
+    // one window chunk and 16-byte aligned; else the round-3 gathers from L2
+    const bool win = base + windows <= 160 * 1024 && a_in.rel_ld >= 8 && a_in.rel_ld % 8 == 0 && a_in.rel_head_stride % 8 == 0;
+    const size_t smem = base + (win ? windows : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;  // sequences longer than ~600 tokens
     BhAttnArgs a = a_in;
     a.v_lds_off = nkb * 4096;
     a.rel_lds_off = nkb * 8192;
-    static size_t attr_smem = 0;
-    if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_rel_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    a.win_lds_off = (int)base;
+    static size_t attr_smem[2] = {0, 0};
+    const void* fn = win ? reinterpret_cast<const void*>(bh_attention_rel_kernel<true>) : reinterpret_cast<const void*>(bh_attention_rel_kernel<false>);
+    if (smem > attr_smem[win ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_smem = smem;
+        attr_smem[win ? 1 : 0] = smem;
     }
-    hipLaunchKernelGGL(bh_attention_rel_kernel, dim3(n_heads, batch), dim3(512), smem, stream, a);
+    if (win)
+        hipLaunchKernelGGL(bh_attention_rel_kernel<true>, dim3(n_heads, batch), dim3(512), smem, stream, a);
+    else
+        hipLaunchKernelGGL(bh_attention_rel_kernel<false>, dim3(n_heads, batch), dim3(512), smem, stream, a);
     return hipGetLastError();
 }

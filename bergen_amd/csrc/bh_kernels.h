@@ -194,6 +194,7 @@ struct BhAttnArgs {
     int rel_center = 0;             // max sequence length - 1
     float rel_scale = 0.f;          // 1 / sqrt(3 * head_dim)
     int rel_lds_off = 0;            // filled by the launcher: byte offset of the index table in LDS
+    int win_lds_off = 0;            // filled by the launcher: byte offset of the waves' position windows in LDS (attention_rel.hip, WIN)
 };
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
