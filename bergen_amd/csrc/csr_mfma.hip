@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
     unsigned n_entries = 0, n_appends = 0, n_app_early = 0, n_app_mid = 0;
     // pending hits of the current group (wave-uniform ring indices)
     unsigned q_head = 0, q_tail = 0;
+    unsigned rq[3] = {0u, 0u, 0u};  // row pointers rel[8], rel[16], rel[24] of the current group, wave-uniform (drain's search)
     unsigned gfrag[16];  // the current group's corpus-head tile: A fragments of 4 k-steps (HD != 0)
 #pragma unroll
     for (int i = 0; i < 16; ++i) gfrag[i] = 0u;
@@ -219,20 +220,24 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
         const uint2 it = Qt[(q_head + lane) & (BH_CSR_MFMA_QUEUE - 1)];
         q_head += n;
         const unsigned p = it.x, ent = it.y;
+        // the slot lookup's first two reads do not depend on the document: issued ahead of the search, they land under it
+        const unsigned term = ent & 0xffffu;
+        const unsigned word = bitmap[term >> 5];
+        const unsigned pre = prefix[term >> 5];
         // document of the hit = number of row pointers rel[1..31] (lane l holds rel[l]) that are <= p — rel[32], the group's
-        // entry count, is above every position —: a 5-step binary search with ds_bpermute, all 64 hits at once (each step is
-        // a dependent LDS-crossbar round trip: the search is most of a drain's latency)
-        int dd = 0;
+        // entry count, is above every position.  A binary search, all 64 hits at once: its first two levels against the three
+        // boundaries the group keeps in scalar registers (rq[] = rel[8], rel[16], rel[24]: five VALU instructions), the last three
+        // with ds_bpermute (each a dependent LDS-crossbar round trip: round 3 spent five of them here, most of a drain's latency)
+        int dd = p >= rq[1] ? 16 : 0;
+        dd += p >= (dd ? rq[2] : rq[0]) ? 8 : 0;
 #pragma unroll
-        for (int step = 16; step >= 1; step >>= 1) {
+        for (int step = 4; step >= 1; step >>= 1) {
             const int mid = dd + step;  // <= 31
             const unsigned bv = (unsigned)__shfl((int)rel, mid, 64);
             if (bv <= p) dd = mid;
         }
         if ((a.ablate & 16) == 0 && (unsigned)lane < n) {  // (16, bench-only: queue without resolving)
-            const unsigned term = ent & 0xffffu;
-            const unsigned word = bitmap[term >> 5];
-            const int slot = (int)prefix[term >> 5] + __builtin_popcount(word & ((1u << (term & 31)) - 1u));
+            const int slot = (int)pre + __builtin_popcount(word & ((1u << (term & 31)) - 1u));
             const unsigned info = sinfo[slot];
             if (info & 0x80000000u) {
                 const unsigned hx = info & 63u;
@@ -243,10 +248,21 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
                 const float val = (float)__builtin_bit_cast(_Float16, (unsigned short)(ent >> 16));
                 const unsigned off = info >> 8, np = info & 0xffu;
                 float* srow = St + dd * 64;
-                for (unsigned pp = 0; pp < np; ++pp) {
-                    const unsigned pr = pairs[off + pp];
-                    const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
-                    atomicAdd(&srow[pr & 63u], val * w);
+                // four pairs per step: the pair reads of a step are independent (one LDS round trip for the four — words past the
+                // term's list belong to the next term's list or to the tables behind `pairs`, read and ignored), the adds return
+                // nothing.  A drain lasts as long as the longest list among its 64 hits: with one dependent read per pair that
+                // was ~100 cycles per pair
+                for (unsigned pp = 0; pp < np; pp += 4) {
+                    unsigned pr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pr[j] = pairs[off + pp + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (pp + j < np) {
+                            const float w = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr[j] >> 16));
+                            atomicAdd(&srow[pr[j] & 63u], val * w);
+                        }
+                    }
                 }
             }
         }
@@ -465,6 +481,9 @@ __global__ void __launch_bounds__(512, 2) bh_csr_scan_mfma_kernel(BhCsrMfmaArgs 
             }
         }
         const long long g0 = grp * 32;
+        rq[0] = __builtin_amdgcn_readlane(rel, 8);
+        rq[1] = __builtin_amdgcn_readlane(rel, 16);
+        rq[2] = __builtin_amdgcn_readlane(rel, 24);
         const unsigned total = __builtin_amdgcn_readlane(rel, 32) + HD;  // dwords of the group's stream (head tile + tail entries)
         const unsigned nsc = total == 0 ? 1u : (total + SC * 64 - 1) / (SC * 64);
         load_group(grp + 1, nbase, nrel);  // (used by the last refill of this group)

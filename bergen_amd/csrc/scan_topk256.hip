@@ -893,6 +893,13 @@ hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int gr
         case 512: return launch256_kp<16, 4, 9, 4>(a, kp, grid, stream);
         case 1024:
             if (a.ring_variant == 6) return launch256_kp<32, 4, 10, 4, 1>(a, kp, grid, stream);  // 16 KiB stages x 10: four rendezvous per tile
+            // 32 KiB stages x 4 = 128 KiB: one stage less in flight, but room for the claim word — the DYNAMIC tile distribution
+            // (the five-stage ring takes all 160 KiB and stays static: 79 us between the first and the last workgroup's end on
+            // an eighth of the 21 M x 1024 corpus, profiles/r04e_scan_phases_d1024.txt)
+            // Same-box A/B (profiles/README.md round 4): +0.7 % per pass over all 21 M rows, -2.0 % over an eighth of them — so a
+            // SHARD (< 8 M rows: one of several GPUs' share) takes the dynamic ring, a whole corpus the five-stage one;
+            // ring_variant 5 / 7 force either (tests run both on small corpora)
+            if (a.ring_variant == 5 || (a.ring_variant == 0 && a.n_rows < 8000000ll)) return launch256_kp<32, 8, 4, 4, 1>(a, kp, grid, stream);
             return launch256_kp<32, 8, 5, 4, 1>(a, kp, grid, stream);  // 32 KiB stages x 5 = all 160 KiB of LDS, two rendezvous per tile
         case 768:
             if (kp == 64) {

@@ -621,10 +621,21 @@ class Retrieve:
             s, i = ix.search(q.detach().cpu().contiguous(), top_k_documents)
         finally:
             ix.close()
-        if return_embeddings and len(doc_embeds) and doc_embeds[0].is_sparse:
-            raise NotImplementedError("return_embeddings is not supported for sparse indexes")
         final_top_k_scores = torch.from_numpy(s)
         final_top_k_indices = torch.from_numpy(i)
+        if return_embeddings and len(doc_embeds) and doc_embeds[0].is_sparse:
+            # the reference densifies every chunk (`emb_chunk.to_dense()`, retrieve.py:160-163) and gathers; here only the
+            # retrieved rows of each sparse chunk are densified: [Q, k, vocab] like the reference's result
+            flat = final_top_k_indices.clamp(min=0).reshape(-1)
+            out = torch.zeros((flat.numel(), dim), dtype=doc_embeds[0].dtype)
+            off = 0
+            for c in doc_embeds:
+                n_c = int(c.shape[0])
+                sel = ((flat >= off) & (flat < off + n_c)).nonzero().reshape(-1)
+                if sel.numel():
+                    out[sel] = c.cpu().coalesce().index_select(0, flat[sel] - off).to_dense()
+                off += n_c
+            return final_top_k_scores, final_top_k_indices, out.reshape(tuple(final_top_k_indices.shape) + (dim,))
         if return_embeddings:
             all_rows = torch.cat([self._dense_chunk(c).cpu() for c in doc_embeds])
             return final_top_k_scores, final_top_k_indices, all_rows[final_top_k_indices.clamp(min=0)]

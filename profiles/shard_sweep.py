@@ -18,7 +18,9 @@ from bergen_amd import _lib  # noqa: E402
 def main():
     _lib.init(0)
     # python profiles/shard_sweep.py [dim k queries [g ...]]   (defaults: the headline geometry; configs[4]: 1024 200 1000)
-    av = [int(x) for x in sys.argv[1:]]
+    for kv in [x for x in sys.argv[1:] if "=" in x]:  # library options, e.g. ring_variant=5
+        _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    av = [int(x) for x in sys.argv[1:] if "=" not in x]
     dim, k, nq = (av + [768, 50, 2837][len(av):])[:3] if len(av) < 3 else av[:3]
     n_total = 21_000_000
     shards = tuple(av[3:]) or (1, 2, 4, 8)

@@ -95,6 +95,39 @@ def test_load_collection_and_retrieve_signature():
         r.load_collection_and_retrieve(q, [x], 7, dataset_size=705)
 
 
+def test_load_collection_and_retrieve_returns_embeddings_dense_and_sparse():
+    """return_embeddings=True (reference retrieve.py:160-163,179-183): the [Q, k, D] rows of the hits — for sparse (SPLADE) chunks
+    densified like the reference's `emb_chunk.to_dense()`, only for the rows retrieved."""
+    import bergen_amd
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(500, 64, generator=g).half()
+    q = torch.randn(6, 64, generator=g).half()
+    r = bergen_amd.Retrieve(init_args=_TableDense(q, x, bergen_amd.DotProduct()), num_workers=0)
+    s, i, e = r.load_collection_and_retrieve(q, [x[:200], x[200:]], 5, dataset_size=500, return_embeddings=True)
+    assert tuple(e.shape) == (6, 5, 64) and torch.equal(e, x[i])
+    # sparse chunks: non-negative weights over a vocabulary of 300 terms, ~12 per document
+    V = 300
+    dense_docs = torch.zeros(400, V)
+    for row in range(400):
+        cols = torch.randperm(V, generator=g)[:12]
+        dense_docs[row, cols] = torch.rand(12, generator=g) + 0.05
+    dense_docs = dense_docs.half()
+    qs = torch.zeros(4, V)
+    for row in range(4):
+        qs[row, torch.randperm(V, generator=g)[:8]] = torch.rand(8, generator=g) + 0.05
+    qs = qs.half()
+
+    class _Sparse(_TableDense):
+        sparse = True
+
+    rs = bergen_amd.Retrieve(init_args=_Sparse(qs, dense_docs, bergen_amd.DotProduct()), num_workers=0)
+    chunks = [dense_docs[:150].to_sparse(), dense_docs[150:].to_sparse()]
+    s2, i2, e2 = rs.load_collection_and_retrieve(qs, chunks, 5, dataset_size=400, return_embeddings=True)
+    assert tuple(e2.shape) == (4, 5, V) and torch.equal(e2, dense_docs[i2])
+    want = (qs.double() @ dense_docs.double().T).topk(5, dim=1).values.float()
+    assert torch.allclose(s2, want, rtol=0, atol=1e-6)
+
+
 class _DeviceTableDense(_TableDense):
     """The same plug-in with its embeddings coming out of the 'encoder' on the GPU, as a real Dense model's do."""
 

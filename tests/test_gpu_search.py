@@ -439,7 +439,8 @@ def test_tile256_kernel_dims_and_list_lengths(amd, no_tail_routing, n, d, nq, k)
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(300001, 768, 40, 50), (300001, 384, 40, 50), (300001, 512, 40, 120), (70001, 384, 300, 50),
-                                      (70001, 512, 100, 200), (100003, 768, 257, 56), (340000, 768, 30, 200), (299617, 768, 64, 50)])
+                                      (70001, 512, 100, 200), (100003, 768, 257, 56), (340000, 768, 30, 200), (299617, 768, 64, 50),
+                                      (300001, 1024, 40, 200), (320017, 1024, 130, 50)])
 def test_dynamic_tile_distribution_matches_oracle(amd, no_tail_routing, n, d, nq, k):
     """scan_topk256's dynamic tile distribution (option dyn_tiles, default on): the first 7/8 of the corpus round robin and
     the tail in runs claimed from the pass's counter (>= 300 k rows on 256 workgroups; smaller corpora stay round robin).
@@ -453,13 +454,19 @@ def test_dynamic_tile_distribution_matches_oracle(amd, no_tail_routing, n, d, nq
     ix = amd.FlatIndex(n, d, metric="ip")
     ix.upload(x)
     ix.finalize()
+    # d = 1024: the four-stage ring with the claim word (ring_variant 5; the default of a shard of < 8 M rows) and the five-stage
+    # ring that fills the LDS and stays static (ring_variant 7; the default of a whole corpus) — both on this corpus
+    rings = (0, 5, 7) if d == 1024 else (0,)
     try:
-        for dyn in (1, 0, 1):
-            _lib.set_option("dyn_tiles", dyn)
-            s, i = ix.search(q, k)
-            compare.assert_bit_exact(s, i, ws, wi, f"dyn_tiles={dyn} n={n} d={d} nq={nq} k={k}")
+        for ring in rings:
+            _lib.set_option("ring_variant", ring)
+            for dyn in (1, 0, 1):
+                _lib.set_option("dyn_tiles", dyn)
+                s, i = ix.search(q, k)
+                compare.assert_bit_exact(s, i, ws, wi, f"ring_variant={ring} dyn_tiles={dyn} n={n} d={d} nq={nq} k={k}")
     finally:
         _lib.set_option("dyn_tiles", 1)
+        _lib.set_option("ring_variant", 0)
         ix.close()
 
 
