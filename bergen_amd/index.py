@@ -193,6 +193,7 @@ def merge_topk(scores, ids, out=None):
             out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
             out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
         torch.cuda.current_stream(scores.device).synchronize()
+        _lib.init(scores.device.index if scores.device.index is not None else torch.cuda.current_device())  # (the lists' GPU: one process may hold several)
         _lib.check(_lib.lib().bh_merge_topk_device(ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
                                                    n_lists, nq, k, ctypes.c_void_p(out_s.data_ptr()),
                                                    ctypes.c_void_p(out_i.data_ptr())))

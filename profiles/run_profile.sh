@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-real-size --full-list-queries 8"   # (the real-size leg launches the headline kernel on 24.85 M rows: it would blur the per-kernel average of the 21 M launches)
 BENCH_PMC="$BENCH --no-encoder --no-stage --no-certificate-leg --no-larger-k"   # the counter passes of the scan kernels (dense and sparse) do not need the encoder legs
 BENCH_ENC="$BENCH --no-other-kernels --no-larger-k --no-config5 --no-certificate-leg --no-stage --no-splade --encode-stage-passages 0"
 echo "== kernel trace + stats" 
