@@ -165,6 +165,8 @@ struct bh_index {
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> events;
     bh_counters counters{};
+    int last_shape_nq = -1, last_shape_k = -1;  // the previous search's shape and GPU time: when to stop sleeping between polls (spin_sync)
+    double last_shape_ms = 0.0;
     int opt_override[sizeof(g_option_defs) / sizeof(g_option_defs[0])];  // kUnset = inherit (bh_index_set_option)
 
     bh_index() {
@@ -193,17 +195,22 @@ Options effective_options(const bh_index* ix) {
 // Wait for a stream by polling it.  hipStreamSynchronize parks the thread once the wait gets long (tens of milliseconds:
 // every search over a whole corpus) and the wake-up costs 1-2 ms, 2 % of the headline search.  A full-speed spin for the
 // whole search would hold a host core per rank (8 ranks per node next to tokenizer workers), so: spin for the first
-// 200 us (short searches), then poll every 50 us with the thread asleep in between (wake-up latency <= ~0.1 ms, a few
-// per cent of a core), and fall back to the blocking wait after 10 s.
-hipError_t spin_sync(hipStream_t st) {
+// 200 us (short searches), then poll every 50 us with the thread asleep in between (wake-up latency <= ~0.1 ms on an idle host, a
+// few per cent of a core) — until 80 % of `expect_ms` (the duration of the handle's previous search of this shape) have gone by:
+// from there the thread spins without sleeping.  On a host loaded by other tenants a 50 us sleep can come back milliseconds late
+// (round 4: a 97 ms step around 87 ms of kernels on a box at load average 100), and only the last sleep of a search costs
+// anything.  The blocking wait takes over after 10 s.
+hipError_t spin_sync(hipStream_t st, double expect_ms = 0.0) {
     const auto t0 = std::chrono::steady_clock::now();
+    const auto spin_from = std::chrono::microseconds((long long)(expect_ms * 800.0));
     for (unsigned n = 0;; ++n) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
         if ((n & 15u) != 15u) continue;
         const auto waited = std::chrono::steady_clock::now() - t0;
         if (waited > std::chrono::seconds(10)) return hipStreamSynchronize(st);
-        if (waited > std::chrono::microseconds(200)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (waited > std::chrono::microseconds(200) && (expect_ms <= 0.0 || waited < spin_from))
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 
@@ -729,7 +736,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         for (int p = std::max(0, n_pass - 2); p < n_pass; ++p) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * p + 3), 0));
     }
     HIP_TRY(hipEventRecord(ev_end, st));
-    HIP_TRY(spin_sync(st));
+    HIP_TRY(spin_sync(st, (ix->last_shape_nq == nq && ix->last_shape_k == k) ? ix->last_shape_ms : 0.0));
     // ---- exactness: queries the certificate could not prove go through the exact scan (certify.hip)
     int64_t n_uncert = 0, n_filter_passes = 0, n_filter_rows = 0;
     double exact_ms = 0;
@@ -896,6 +903,9 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     float tot = 0;
     HIP_TRY(hipEventElapsedTime(&tot, ev_begin, ev_end));
     c.total_ms = tot + exact_ms;
+    ix->last_shape_nq = nq;
+    ix->last_shape_k = k;
+    ix->last_shape_ms = tot;
     c.algorithmic_bytes = alg_bytes;
     c.uncertified_queries = n_uncert;
     c.exact_ms = exact_ms;

@@ -1,0 +1,26 @@
+"""Where the host-side time of a headline step goes: python profiles/step_gap.py"""
+import os, sys, time, statistics
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, bergen_amd
+from bergen_amd import _lib
+_lib.init(0)
+dev = torch.device("cuda", 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 21_000_000
+q = bench.make_queries(2837, 768, dev)
+ix = bergen_amd.FlatIndex(n, 768, metric="ip", device=0)
+bench.fill_shard(ix, 0, n, 768, q, n, dev)
+ix.finalize()
+for _ in range(3):
+    ix.search(q, 50, host=True)
+rows = []
+for _ in range(10):
+    t0 = time.perf_counter(); s, i = ix.search(q, 50, host=True); t1 = time.perf_counter()
+    s2, i2 = s.clone(), i.clone(); t2 = time.perf_counter()
+    c = ix.counters(); t3 = time.perf_counter()
+    rows.append(((t1 - t0) * 1e3, c["total_ms"], (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+for name, j in (("search() wall ms", 0), ("kernels total_ms", 1), ("clone ms", 2), ("counters ms", 3)):
+    v = [r[j] for r in rows]
+    print(f"{name:18s} median {statistics.median(v):8.3f}  min {min(v):8.3f}  max {max(v):8.3f}")
+print("pinned clone is_pinned:", s2.is_pinned())
