@@ -57,6 +57,13 @@ class ShardedSearcher:
         self._buf = {}
         self._search_takes_out = _takes(local_index.search, "out")
         self._merge_takes_out = _takes(merge, "out")
+        # gloo moves host memory only: under it the collective's buffers live on the host whatever the queries' device (the local
+        # lists are copied down, gathered and merged there — bh_merge_topk takes host lists), e.g. several processes sharing one
+        # GPU, or a host without RCCL.  RCCL ("nccl") gathers device memory.
+        try:
+            self._host_collective = self.world_size > 1 and dist.is_initialized() and str(dist.get_backend(group)) == "gloo"
+        except Exception:  # noqa: BLE001
+            self._host_collective = False
 
     def _buffers(self, nq, k, device):
         """Per (nq, k) buffers, allocated once: this rank's packed (scores | ids) lists — the local search writes straight
@@ -95,8 +102,10 @@ class ShardedSearcher:
         nq = int(queries.shape[0])
         on_device = isinstance(queries, torch.Tensor) and queries.is_cuda
         device = queries.device if on_device else (self.device or torch.device("cpu"))
+        if self._host_collective:
+            device = torch.device("cpu")
         buf = self._buffers(nq, k, device)
-        if self._search_takes_out and on_device:
+        if self._search_takes_out and on_device and not self._host_collective:
             # (out= is the device-queries path of FlatIndex.search: the local lists land in the packed send buffer)
             self.local_index.search(queries, k, id_offset=self.row_lo, out=(buf["scores"], buf["ids"]))
         else:
