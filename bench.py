@@ -76,6 +76,10 @@ def parse_args():
     p.add_argument("--splade-docs", type=int, default=21_000_000, help="documents of the synthetic SPLADE corpus (S4: 21 M, ~180 terms each)")
     p.add_argument("--splade-term-seeds", type=int, default=3,
                    help="independent draws of the S4 term-set recipe behind the SPLADE corpus blocks (every block gets fresh weights)")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="transport of the N > 1 run: nccl (= RCCL over xGMI, one GPU per rank: the driver's run) or gloo — a TEST mode for "
+                        "boxes with fewer GPUs than ranks: ranks share GPUs (LOCAL_RANK modulo the device count) and the partial lists are "
+                        "gathered through host buffers; every other line of the run is the same")
     p.add_argument("--sweep", action="store_true", help="also time kernel variants (written to gpurun_out/sweep.json)")
     p.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                    help="optional PMC-derived HBM bytes per scan launch (written by profiles/collect_pmc.py)")
@@ -981,15 +985,21 @@ class HipEnv:
     merge = None  # ShardedSearcher's default: the HIP merge kernel
     results_to_host = True
 
-    def __init__(self, local_rank):
+    def __init__(self, local_rank, backend="nccl"):
         assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+        self.backend = backend
+        if backend != "nccl":  # (test mode: more ranks than GPUs)
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         self.local_rank = local_rank
         self.device = torch.device("cuda", local_rank)
 
     def init_dist(self, rank, world):
         import torch.distributed as dist
-        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=self.device)
+        if self.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=self.device)
+        else:
+            dist.init_process_group(self.backend, rank=rank, world_size=world)
 
     def init_library(self, args):
         from bergen_amd import _lib
@@ -1046,7 +1056,7 @@ def launch_ranks_if_needed(args, script=None):
 def main():
     args = parse_args()
     launch_ranks_if_needed(args)
-    run(args, HipEnv(int(os.environ.get("LOCAL_RANK", "0"))))
+    run(args, HipEnv(int(os.environ.get("LOCAL_RANK", "0")), backend=args.dist_backend))
 
 
 def run(args, env):
@@ -1113,7 +1123,7 @@ def run(args, env):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if getattr(env, "backend", "nccl") == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     c = ix.counters()

@@ -73,3 +73,27 @@ def test_two_processes_one_gpu_sharded_stage(tmp_path, kind, world, results):
         ws, wi = c_oracle.canonical_search(xq, xd, k)
     got_i = np.array([[int(s[3:]) for s in row] for row in single["doc_id"]])
     compare.assert_bit_exact(single["score"].numpy(), got_i, ws, wi, f"stage {kind}")
+
+
+def test_bench_multi_rank_run_on_one_gpu():
+    """`python bench.py --gpus 2 --dist-backend gloo` typed by hand on a one-GPU box: bench.py starts its two ranks itself (the
+    driver's own torch.distributed.run command), both on cuda:0, and runs exactly its N > 1 path — shard fill on the device, the
+    stage's search_rows on each shard, the gather of the packed lists (through host buffers here, RCCL in the driver's run), the HIP
+    merge on rank 0, barrier + max-over-ranks timing, ONE JSON line with the parity gate on the merged lists."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for world in (2, 3):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dist-backend", "gloo", "--steps", "2",
+                              "--warmup", "1", "--n-rows", "300011", "--queries", "300", "--no-cpu-baseline"],
+                             capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == world and r["parity_check"] == "pass" and r["scaling"] == "strong"
+        assert r["config"]["rows_per_gpu"] == -(-300011 // world) and f"row-shard x{world}" in r["config"]["parallelism"]
+        assert r["value"] > 0 and abs(r["value"] - 300 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+        assert r["roofline"]["frac"] > 0 and r["uncertified_queries"] == 0
