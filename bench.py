@@ -685,15 +685,15 @@ def encode_stage_leg(args, device_index):
         for b0 in range(0, n_pass, 512):
             dense.collate_fn([{"content": x} for x in texts[b0:b0 + 512]], "doc")
         res["tokenizer_only_passages_per_s_one_process"] = n_pass / (time.perf_counter() - t0)
-        # "threads": the stage's default loader — on a many-core host every batch is tokenised in eight pieces by up to 32 threads,
-        # each piece serially; "threads_whole": whole batches on 4 / 16 threads that share the tokenizer's own thread pool (the
-        # round-3 loader, BERGEN_AMD_TOKENIZER_PIECES=0); "processes": the reference's DataLoader workers; "inline": none
-        for loader, workers in (("threads", 4), ("threads_whole", 4), ("threads_whole", 16), ("processes", 4), ("inline", 0)):
+        # "threads": the stage's default loader — whole batches on 4 / 16 threads of this process, each call spread over the cores by the
+        # tokenizer's own pool; "threads_pieces": every batch tokenised in eight pieces by up to 32 threads, each piece serially
+        # (BERGEN_AMD_TOKENIZER_PIECES=1); "processes": the reference's DataLoader workers; "inline": none
+        for loader, workers in (("threads", 4), ("threads_pieces", 4), ("threads", 16), ("processes", 4), ("inline", 0)):
             stage = bergen_amd.Retrieve(init_args=dense, batch_size=512, num_workers=workers, device=device_index,
                                         loader="processes" if loader == "processes" else "threads")
             path = os.path.join(root, f"idx_{loader}{workers}")
-            if loader == "threads_whole":
-                os.environ["BERGEN_AMD_TOKENIZER_PIECES"] = "0"
+            if loader == "threads_pieces":
+                os.environ["BERGEN_AMD_TOKENIZER_PIECES"] = "1"
             else:
                 os.environ.pop("BERGEN_AMD_TOKENIZER_PIECES", None)
             try:

@@ -91,6 +91,16 @@ struct bh_encoder {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int vt_side_stream = 1;
+    // Micro-batches on their own streams (option "micro_batches" 1..4, default 2 for batches of >= 8192 packed rows; 1 = off; three
+    // and four measured slower than two): the layer
+    // stack runs once per micro-batch, over consecutive ranges of the batch's sequences, on `stream` and on `mb_stream[]`; a persistent GEMM of either half
+    // leaves most CUs idle through its last, partly filled round of tiles (804 tiles of an N = 768 projection = 3.14 -> 4 rounds on 256
+    // CUs: a fifth of that GEMM's time) and the other half's launches fill them — the workgroups of the two queues interleave CU by CU
+    // as they leave.  The vendor's 10-17 % lead on these shapes (profiles/r04a_gemm_yardstick.json) is about that partial round.
+    static constexpr int kMaxMicroBatches = 4;
+    hipStream_t mb_stream[kMaxMicroBatches - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_mb_fork = nullptr, ev_mb_join[kMaxMicroBatches - 1] = {nullptr, nullptr, nullptr};
+    int micro_batches = 2;
     int attn_side_stream = 0;  // the attention launches over the short and the long sequences of a batch side by side: measured
                                // 0.3 % SLOWER than back to back (16.71 vs 16.65 ms per 512-passage step; each launch fills the chip) — off
     bh_encoder_counters counters{};
@@ -278,6 +288,11 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_mb_fork, hipEventDisableTiming);
+        for (int m = 0; m < bh_encoder::kMaxMicroBatches - 1 && he == hipSuccess; ++m) {
+            he = hipStreamCreateWithFlags(&e->mb_stream[m], hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_mb_join[m], hipEventDisableTiming);
+        }
         if (he != hipSuccess) rc = bh_fail(BH_EHIP, "stream/event create: %s", hipGetErrorString(he));
     }
     if (rc != BH_OK) {
@@ -315,6 +330,11 @@ void bh_encoder_destroy(bh_encoder* e) {
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_mb_fork) (void)hipEventDestroy(e->ev_mb_fork);
+    for (int m = 0; m < bh_encoder::kMaxMicroBatches - 1; ++m) {
+        if (e->ev_mb_join[m]) (void)hipEventDestroy(e->ev_mb_join[m]);
+        if (e->mb_stream[m]) (void)hipStreamDestroy(e->mb_stream[m]);
+    }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -417,6 +437,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
         e->attn_side_stream = (int)value;
         return BH_OK;
     }
+    if (std::string(name) == "micro_batches") {
+        if (value < 1 || value > bh_encoder::kMaxMicroBatches) return bh_fail(BH_EINVAL, "micro_batches must be 1..4");
+        e->micro_batches = (int)value;
+        return BH_OK;
+    }
     if (std::string(name) == "vt_side_stream") {
         if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "vt_side_stream must be 0 or 1");
         e->vt_side_stream = (int)value;
@@ -509,12 +534,36 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         if (n == 0) return bh_fail(BH_EINVAL, "sequence %d has an all-zero attention mask", b);
         if ((pool == 0 || pool == 4) && attention_mask && attention_mask[(size_t)b * seq_len] == 0)
             return bh_fail(BH_EINVAL, "CLS pooling needs attention_mask[%d][0] != 0", b);
-        off[b] = cursor;
         len[b] = n;
         cursor = (cursor + n + 7) / 8 * 8;
         max_len = std::max(max_len, n);
         real_tokens += n;
         len_sq += (double)n * n;
+    }
+    // Two micro-batches (see bh_encoder::micro_batches): sequences [0, b_split) and [b_split, batch); the second half starts at a
+    // row that is a multiple of 256 (the GEMM tile), behind the +32 guard rows of the first half.  Plain BERT stacks only.
+    int n_mb = (e->micro_batches >= 2 && e->rel_span == 0 && e->mb_stream[0] != nullptr) ? e->micro_batches : 1;
+    while (n_mb > 1 && (batch < n_mb || cursor < 4096ll * n_mb)) --n_mb;
+    int b_split[bh_encoder::kMaxMicroBatches + 1];      // sequences [b_split[m], b_split[m + 1]) form micro-batch m
+    long long row_split[bh_encoder::kMaxMicroBatches + 1];
+    {
+        const long long total = cursor;
+        long long cur = 0;
+        int m = 0;
+        b_split[0] = 0;
+        row_split[0] = 0;
+        for (int b = 0; b < batch; ++b) {
+            if (m + 1 < n_mb && b > b_split[m] && cur >= total * (m + 1) / n_mb) {
+                ++m;
+                cur = round_up(cur + 32, 256);
+                b_split[m] = b;
+                row_split[m] = cur;
+            }
+            off[b] = cur;
+            cur = (cur + len[b] + 7) / 8 * 8;
+        }
+        n_mb = m + 1;  // (fewer when the sequences ran out first)
+        cursor = cur;
     }
     const int m_pad = round_up(cursor + 32, 256);  // +32: the attention's last key block may read past a sequence
     // tok | pos | typ  [m_pad each] | seq_len [batch] | seq_idx [batch] | slot [batch*seq_len] (pool == 2 only)
@@ -527,17 +576,37 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     int* slen = typ + m_pad;
     int* sidx = slen + batch;
     int* slot = sidx + batch;
-    // attention length buckets: sequences of at most 128 tokens first, then the longer ones
-    int n_short = 0, max_len_long = 0;
-    for (int b = 0; b < batch; ++b)
-        if (len[b] <= e->attn_short) sidx[n_short++] = b;
+    // attention length buckets, per micro-batch: its sequences of at most 128 tokens first, then its longer ones
+    struct MicroBatch {
+        int b0, b1;            // sequences [b0, b1)
+        long long r0, r1;      // packed rows [r0, r1), both multiples of 256
+        int sidx0, n_short, n_long, max_len_long;
+    };
+    MicroBatch mbs[bh_encoder::kMaxMicroBatches];
     {
-        int w = n_short;
-        for (int b = 0; b < batch; ++b)
-            if (len[b] > e->attn_short) {
-                sidx[w++] = b;
-                max_len_long = std::max(max_len_long, len[b]);
-            }
+        int w = 0;
+        b_split[n_mb] = batch;
+        row_split[n_mb] = m_pad;
+        for (int m = 0; m < n_mb; ++m) {
+            MicroBatch& mb = mbs[m];
+            mb.b0 = b_split[m];
+            mb.b1 = b_split[m + 1];
+            mb.r0 = row_split[m];
+            mb.r1 = row_split[m + 1];
+            mb.sidx0 = w;
+            mb.n_short = mb.n_long = mb.max_len_long = 0;
+            for (int b = mb.b0; b < mb.b1; ++b)
+                if (len[b] <= e->attn_short) {
+                    sidx[w++] = b;
+                    ++mb.n_short;
+                }
+            for (int b = mb.b0; b < mb.b1; ++b)
+                if (len[b] > e->attn_short) {
+                    sidx[w++] = b;
+                    ++mb.n_long;
+                    mb.max_len_long = std::max(mb.max_len_long, len[b]);
+                }
+        }
     }
     if (pool == 3)
         for (int b = 0; b < batch; ++b)
@@ -634,25 +703,36 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         ra.beta = e->rel_b;
         BH_HIP_TRY(bh_launch_layernorm(ra, st));
     }
-    for (int l = 0; l < c.n_layers; ++l) {
+    // ---- the layer stack: once over all rows, or (n_mb == 2) over the two micro-batches on two streams, layer by layer
+    auto run_layer = [&](int l, const MicroBatch& mb, hipStream_t ls, bool alone) -> int {
         const Layer& L = e->layers[l];
+        const size_t r0 = (size_t)mb.r0;
+        const int rows = (int)(mb.r1 - mb.r0);
+        _Float16* Xp = e->X.p + r0 * d;
+        _Float16* Yp = e->Y.p + r0 * d;
+        _Float16* QKp = e->QK.p + r0 * 2 * da;
+        _Float16* CTXp = e->CTX.p + r0 * da;
+        _Float16* Hp = e->H.p + r0 * dff;
+        // V^T rows of this micro-batch: blocked layout VT[m / 64][da][64] (r0 is a multiple of 256), else columns r0.. of [da][m_pad]
+        _Float16* VTp = vt_blocked ? e->VT.p + (r0 / 64) * (size_t)da * 64 : e->VT.p + r0;
         // Q | K projections: QK[m][2d] = X Wqk^T + bqk
-        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][da][64] = Wv X^T + bv (bias per row).  On the side
-        // stream, launched first: its workgroups take the CUs, and the Q | K launch fills them as they leave (and the other
-        // way round at the end) instead of each launch idling most CUs through its last round of tiles
-        const bool fork = e->vt_side_stream && e->side != nullptr;
+        // V projection, written TRANSPOSED and blocked by 64 tokens: VT[m/64][da][64] = Wv X^T + bv (bias per row).  Alone on the
+        // chip (one micro-batch): on the side stream, launched first — its workgroups take the CUs, and the Q | K launch fills them
+        // as they leave (and the other way round at the end) instead of each launch idling most CUs through its last round of
+        // tiles.  With two micro-batches the other half's launches do that.
+        const bool fork = alone && e->vt_side_stream && e->side != nullptr;
         if (fork) {
-            BH_HIP_TRY(hipEventRecord(e->ev_fork, st));  // (the layer input X is final; the previous layer's attention has read VT)
+            BH_HIP_TRY(hipEventRecord(e->ev_fork, ls));  // (the layer input X is final; the previous layer's attention has read VT)
             BH_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         }
-        if ((rc = gemm(e, L.wv, d, e->X.p, d, e->VT.p, m_pad, da, m_pad, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0,
-                       fork ? e->side : nullptr)))
+        if ((rc = gemm(e, L.wv, d, Xp, d, VTp, m_pad, da, rows, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0,
+                       fork ? e->side : ls)))
             return rc;
         if (fork) BH_HIP_TRY(hipEventRecord(e->ev_join, e->side));
-        if ((rc = gemm(e, e->X.p, d, L.wqk, d, e->QK.p, 2 * da, m_pad, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
-        if (fork) BH_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+        if ((rc = gemm(e, Xp, d, L.wqk, d, QKp, 2 * da, rows, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
+        if (fork) BH_HIP_TRY(hipStreamWaitEvent(ls, e->ev_join, 0));
         BhAttnArgs aa{};
-        aa.qk = e->QK.p;
+        aa.qk = e->QK.p;  // (the attention kernels address tokens by their absolute packed row: seq_off)
         aa.ldqk = 2 * da;
         aa.vt = e->VT.p;
         aa.ldvt = m_pad;
@@ -662,10 +742,11 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         aa.seq_off = e->seq_off.p;
         aa.seq_len = d_len;
         aa.d_model = da;
+        (void)CTXp;
         if (rel) {
             // Qr | Kr = rel . Wqk^T + bqk (share_att_key: the layer's own query / key projections), then per head
             // c2p = Q_h Kr_h^T and p2c = K_h Qr_h^T: [tokens][2 span] each (K = 64: one GEMM stage)
-            if ((rc = gemm(e, e->REL_LN.p, d, L.wqk, d, e->REL_QK.p, 2 * da, rel_n, 2 * da, d, L.bqk, 1, nullptr, 0, 0))) return rc;
+            if ((rc = gemm(e, e->REL_LN.p, d, L.wqk, d, e->REL_QK.p, 2 * da, rel_n, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
             _Float16* c2p = e->RELB.p;
             _Float16* p2c = e->RELB.p + (size_t)c.n_heads * M * rel_n;
             // all heads of a term in ONE launch where the shapes are whole 256 x 256 tiles (deberta-v3: 2 span = 512 columns):
@@ -685,12 +766,12 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
                 g.A = e->QK.p;             // Q_h
                 g.B = e->REL_QK.p + da;    // Kr_h
                 g.C = c2p;
-                hipError_t ge = bh_launch_gemm_f16_batched(g, st);
+                hipError_t ge = bh_launch_gemm_f16_batched(g, ls);
                 if (ge == hipSuccess) {
                     g.A = e->QK.p + da;    // K_h
                     g.B = e->REL_QK.p;     // Qr_h
                     g.C = p2c;
-                    ge = bh_launch_gemm_f16_batched(g, st);
+                    ge = bh_launch_gemm_f16_batched(g, ls);
                 }
                 if (ge == hipErrorNotSupported)
                     batched = false;
@@ -699,9 +780,9 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             }
             for (int hh = 0; hh < c.n_heads && !batched; ++hh) {
                 if ((rc = gemm(e, e->QK.p + hh * 64, 2 * da, e->REL_QK.p + da + hh * 64, 2 * da, c2p + (size_t)hh * M * rel_n, rel_n,
-                               m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0))) return rc;
+                               m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0, 0, ls))) return rc;
                 if ((rc = gemm(e, e->QK.p + da + hh * 64, 2 * da, e->REL_QK.p + hh * 64, 2 * da, p2c + (size_t)hh * M * rel_n, rel_n,
-                               m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0))) return rc;
+                               m_pad, rel_n, 64, nullptr, 0, nullptr, 0, 0, 0, ls))) return rc;
             }
             aa.c2p = c2p;
             aa.p2c = p2c;
@@ -712,39 +793,51 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             aa.rel_scale = 1.0f / sqrtf(3.0f * 64.0f);
             int max_len_all = 0;
             for (int b = 0; b < batch; ++b) max_len_all = std::max(max_len_all, len[b]);
-            BH_HIP_TRY(bh_launch_attention_rel(aa, batch, c.n_heads, max_len_all, st));
+            BH_HIP_TRY(bh_launch_attention_rel(aa, batch, c.n_heads, max_len_all, ls));
         } else {
             // the launches over the short and the long sequences touch disjoint sequences: side by side (option "attn_side_stream")
-            const bool fork_attn = e->attn_side_stream && e->side != nullptr && n_short > 0 && batch - n_short > 0;
+            const bool fork_attn = alone && e->attn_side_stream && e->side != nullptr && mb.n_short > 0 && mb.n_long > 0;
             if (fork_attn) {
-                BH_HIP_TRY(hipEventRecord(e->ev_fork, st));  // (Q | K and V^T are complete: the V projection was joined above)
+                BH_HIP_TRY(hipEventRecord(e->ev_fork, ls));  // (Q | K and V^T are complete: the V projection was joined above)
                 BH_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
             }
-            BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx, n_short, batch - n_short, max_len_long, c.n_heads, st, e->attn_short,
+            BH_HIP_TRY(bh_launch_attention_bucketed(aa, d_sidx + mb.sidx0, mb.n_short, mb.n_long, mb.max_len_long, c.n_heads, ls, e->attn_short,
                                                     fork_attn ? e->side : nullptr));
             if (fork_attn) {
                 BH_HIP_TRY(hipEventRecord(e->ev_join, e->side));
-                BH_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+                BH_HIP_TRY(hipStreamWaitEvent(ls, e->ev_join, 0));
             }
         }
         // attention output projection, then LayerNorm(projection + layer input)
-        if ((rc = gemm(e, e->CTX.p, da, L.wo, da, e->Y.p, d, m_pad, d, da, L.bo, 1, nullptr, 0, 0))) return rc;
+        if ((rc = gemm(e, CTXp, da, L.wo, da, Yp, d, rows, d, da, L.bo, 1, nullptr, 0, 0, 0, ls))) return rc;
         BhLnArgs la{};
-        la.in = e->Y.p;
-        la.residual = e->X.p;  // X <- LayerNorm(Y + X)
-        la.out = e->X.p;
-        la.n_rows = m_pad;
+        la.in = Yp;
+        la.residual = Xp;  // X <- LayerNorm(Y + X)
+        la.out = Xp;
+        la.n_rows = rows;
         la.d = d;
         la.eps = c.ln_eps;
         la.gamma = L.ln1g;
         la.beta = L.ln1b;
-        BH_HIP_TRY(bh_launch_layernorm(la, st));
+        BH_HIP_TRY(bh_launch_layernorm(la, ls));
         // FFN: H = GELU(X W1^T + b1);  Y = H W2^T + b2;  X = LN(Y + X)
-        if ((rc = gemm(e, e->X.p, d, L.w1, d, e->H.p, dff, m_pad, dff, d, L.b1, 1, nullptr, 0, 1))) return rc;
-        if ((rc = gemm(e, e->H.p, dff, L.w2, dff, e->Y.p, d, m_pad, d, dff, L.b2, 1, nullptr, 0, 0))) return rc;
+        if ((rc = gemm(e, Xp, d, L.w1, d, Hp, dff, rows, dff, d, L.b1, 1, nullptr, 0, 1, 0, ls))) return rc;
+        if ((rc = gemm(e, Hp, dff, L.w2, dff, Yp, d, rows, d, dff, L.b2, 1, nullptr, 0, 0, 0, ls))) return rc;
         la.gamma = L.ln2g;
         la.beta = L.ln2b;
-        BH_HIP_TRY(bh_launch_layernorm(la, st));
+        BH_HIP_TRY(bh_launch_layernorm(la, ls));
+        return BH_OK;
+    };
+    if (n_mb > 1) {
+        BH_HIP_TRY(hipEventRecord(e->ev_mb_fork, st));  // (the embeddings of every row are in X)
+        for (int m = 1; m < n_mb; ++m) BH_HIP_TRY(hipStreamWaitEvent(e->mb_stream[m - 1], e->ev_mb_fork, 0));
+    }
+    for (int l = 0; l < c.n_layers; ++l)
+        for (int m = 0; m < n_mb; ++m)
+            if ((rc = run_layer(l, mbs[m], m == 0 ? st : e->mb_stream[m - 1], n_mb == 1))) return rc;
+    for (int m = 1; m < n_mb; ++m) {
+        BH_HIP_TRY(hipEventRecord(e->ev_mb_join[m - 1], e->mb_stream[m - 1]));
+        BH_HIP_TRY(hipStreamWaitEvent(st, e->ev_mb_join[m - 1], 0));
     }
     if (pool == 4) {
         BhClsHeadArgs ca{};

@@ -277,17 +277,17 @@ class Retrieve:
         # tokeniser threads meant more of them (round 3: 16 threads slower than 4).  0.2 ms while the loader runs.
         old_interval = sys.getswitchinterval()
         sys.setswitchinterval(min(old_interval, 2e-4))
-        # How many threads, and who parallelises.  A Rust tokenizer's encode_batch spreads ONE call over every core (rayon); a few
-        # callers at once then share that pool and trip over each other (round 3 / 4 on the 256-core GPU host: 4 callers 26 k
-        # passages/s, 16 callers 19 k, one caller 13.6 k).  With enough cores the stage parallelises itself instead: every batch
-        # is cut into PIECES, each tokenised serially by one of many threads (TOKENIZERS_PARALLELISM=false is read per call) and
-        # merged back in order — throughput = threads x one core's ~2.9 k passages/s, no shared pool, and a batch is ready after
-        # an eighth of its serial time.  Few cores (or a model without a right-padding tokenizer): whole batches, the tokenizer's
-        # own pool.
+        # How many threads, and who parallelises.  Default: whole batches on `num_workers` threads, each call spread over the cores
+        # by the Rust tokenizer's own pool (rayon) — with the ids-only fast path and the short switch interval above, 4 threads
+        # feed the GPU at about its own rate (round 4, 256-core host: 28-30 k passages/s end to end, 34 k between the first and
+        # the last batch; 16 threads 24 k: the callers share one pool).  BERGEN_AMD_TOKENIZER_PIECES=1 selects the other scheme —
+        # every batch cut into eight PIECES, each tokenised serially (TOKENIZERS_PARALLELISM=false is read per call) by one of up
+        # to 32 threads and merged back in order: no shared pool, but eight times the Python calls per batch under the GIL; it
+        # measured 25-27 k on the same hosts.
         n_threads = max(int(self.num_workers), min(32, (os.cpu_count() or 4) // 4))
         tok = getattr(self.model, "tokenizer", None)
         serial = (n_threads >= 8 and pad_id is not None and getattr(tok, "padding_side", "right") == "right"
-                  and os.environ.get("BERGEN_AMD_TOKENIZER_PIECES", "1") != "0")  # (0: whole batches on num_workers threads, for A/B)
+                  and os.environ.get("BERGEN_AMD_TOKENIZER_PIECES", "0") == "1")
         n_pieces = 8 if serial else 1
         old_par = os.environ.get("TOKENIZERS_PARALLELISM")
         if serial:

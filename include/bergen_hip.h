@@ -238,7 +238,9 @@ int bh_encoder_set_tensor(bh_encoder* enc, const char* name, const void* host, i
 int bh_encoder_commit(bh_encoder* enc);
 /* name in {"gemm_variant" (0 = auto, 1..5 explicit tile configurations, 6 = generic bounds-checked kernel;
  * bench sweeps), "attn_short_len" (32..512, multiple of 32; default 128: longest sequence whose attention runs in a
- * 4-wave workgroup)}. */
+ * 4-wave workgroup), "micro_batches" (1..4, default 2: batches of >= 8192 packed rows run their layer stack as that many
+ * micro-batches on as many streams — results are bit-identical for every value), "vt_side_stream", "attn_side_stream",
+ * "rel_batched_gemm"}. */
 int bh_encoder_set_option(bh_encoder* enc, const char* name, int64_t value);
 /* DeBERTa-v2 / v3 encoders (the reference's default reranker, config/reranker/debertav3.yaml:3, loaded through
  * AutoModelForSequenceClassification, models/rerankers/crossencoder.py:18): set option "rel_attention_span" (=

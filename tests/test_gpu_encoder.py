@@ -375,6 +375,35 @@ def test_encoder_large_batch():
     enc.close()
 
 
+def test_micro_batches_give_identical_outputs():
+    """The layer stack over one, two, three or four micro-batches on as many streams (option micro_batches; default 2 from 8 192
+    packed rows on): the same kernels on disjoint row ranges, so every output — CLS / mean pooled, hidden states, classification
+    logits — must be BIT-identical to the single-stream forward pass, for ragged lengths whose split points do not fall on tile
+    boundaries; and the default must match the oracle."""
+    cfg = dict(vocab_size=900, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+               max_position_embeddings=160, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=71)
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=301, max_len=150, seed=72, min_len=5)
+    assert int(mask.sum()) > 17000
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(types)}
+    outs = {}
+    for n_mb in (1, 2, 3, 4, 2):
+        enc.set_option("micro_batches", n_mb)
+        outs[n_mb] = (enc.encode_pooled(kw, "mean").cpu(), enc.encode_pooled(kw, "cls").cpu(), enc(**kw)[0].cpu())
+    for n_mb in (2, 3, 4):
+        for got, want, what in zip(outs[n_mb], outs[1], ("mean", "cls", "hidden states")):
+            assert torch.equal(got, want), f"micro_batches={n_mb}: {what} differs from the single-stream forward pass"
+    ref = bert_oracle.encode(sd, cfg, ids, mask, types, pooler="mean")
+    _check_embeddings(outs[2][0], ref, "two micro-batches vs the oracle")
+    # a batch too small to split (< 8 192 packed rows) runs on one stream whatever the option says
+    small = {k_: v[:20] for k_, v in kw.items()}
+    a = enc.encode_pooled(small, "mean").cpu()
+    enc.set_option("micro_batches", 1)
+    assert torch.equal(a, enc.encode_pooled(small, "mean").cpu())
+    enc.close()
+
+
 def test_encoder_with_outlier_features_against_oracle():
     """Trained BERT-family checkpoints carry a few 'massive' hidden features (LayerNorm gains / biases an order of
     magnitude above the rest, present at every layer) and attention heads with very peaked softmax; seeded random

@@ -182,7 +182,7 @@ def test_fast_tokenize_equals_the_hf_call():
 
 
 def test_piecewise_tokeniser_threads_give_the_whole_batch_result(monkeypatch):
-    """On a many-core host the stage cuts every batch into eight pieces, each tokenised serially by one of many threads
+    """With BERGEN_AMD_TOKENIZER_PIECES=1 on a many-core host the stage cuts every batch into eight pieces, each tokenised serially by one of many threads
     (Retrieve._threaded_batches), and pads the pieces back to the batch's longest row: the batches must equal collate_fn over the
     whole batch — values, shapes, order — and the process-wide settings it borrows (tokenizer parallelism, GIL switch interval)
     must be back afterwards.  A collate_fn whose output is not a set of [B, T] tensors falls back to whole batches."""
@@ -194,6 +194,7 @@ def test_piecewise_tokeniser_threads_give_the_whole_batch_result(monkeypatch):
     tok, _ = ut1_fixture.tokenizer_for([str(w) for w in z["words"]])
     texts = [str(t) for t in z["doc_texts"]] * 3 + ["", "the " * 300]
     monkeypatch.setattr(os, "cpu_count", lambda: 64)
+    monkeypatch.setenv("BERGEN_AMD_TOKENIZER_PIECES", "1")
     monkeypatch.delenv("TOKENIZERS_PARALLELISM", raising=False)
 
     class Model:
