@@ -99,7 +99,7 @@ struct bh_encoder {
     // as they leave.  The vendor's 10-17 % lead on these shapes (profiles/r04a_gemm_yardstick.json) is about that partial round.
     static constexpr int kMaxMicroBatches = 4;
     hipStream_t mb_stream[kMaxMicroBatches - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_mb_fork = nullptr, ev_mb_join[kMaxMicroBatches - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_mb_fork = nullptr, ev_fork2 = nullptr, ev_mb_join[kMaxMicroBatches - 1] = {nullptr, nullptr, nullptr};
     int micro_batches = 2;
     int attn_side_stream = 0;  // the attention launches over the short and the long sequences of a batch side by side: measured
                                // 0.3 % SLOWER than back to back (16.71 vs 16.65 ms per 512-passage step; each launch fills the chip) — off
@@ -289,6 +289,7 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_mb_fork, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming);
         for (int m = 0; m < bh_encoder::kMaxMicroBatches - 1 && he == hipSuccess; ++m) {
             he = hipStreamCreateWithFlags(&e->mb_stream[m], hipStreamNonBlocking);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_mb_join[m], hipEventDisableTiming);
@@ -331,6 +332,7 @@ void bh_encoder_destroy(bh_encoder* e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->ev_mb_fork) (void)hipEventDestroy(e->ev_mb_fork);
+    if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
     for (int m = 0; m < bh_encoder::kMaxMicroBatches - 1; ++m) {
         if (e->ev_mb_join[m]) (void)hipEventDestroy(e->ev_mb_join[m]);
         if (e->mb_stream[m]) (void)hipStreamDestroy(e->mb_stream[m]);
@@ -443,7 +445,7 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
         return BH_OK;
     }
     if (std::string(name) == "vt_side_stream") {
-        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "vt_side_stream must be 0 or 1");
+        if (value < 0 || value > 2) return bh_fail(BH_EINVAL, "vt_side_stream must be 0, 1 or 2");
         e->vt_side_stream = (int)value;
         return BH_OK;
     }
@@ -720,17 +722,21 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         // chip (one micro-batch): on the side stream, launched first — its workgroups take the CUs, and the Q | K launch fills them
         // as they leave (and the other way round at the end) instead of each launch idling most CUs through its last round of
         // tiles.  With two micro-batches the other half's launches do that.
-        const bool fork = alone && e->vt_side_stream && e->side != nullptr;
+        // (vt_side_stream 2, experiment: fork the V projection in two-micro-batch mode too — micro-batch 1 uses the spare stream)
+        const int mi = (int)(&mb - &mbs[0]);
+        const bool fork = e->side != nullptr && ((alone && e->vt_side_stream) || (e->vt_side_stream == 2 && n_mb == 2));
+        hipStream_t vs = mi == 0 ? e->side : e->mb_stream[1];
+        hipEvent_t evf = mi == 0 ? e->ev_fork : e->ev_fork2, evj = mi == 0 ? e->ev_join : e->ev_mb_join[1];
         if (fork) {
-            BH_HIP_TRY(hipEventRecord(e->ev_fork, ls));  // (the layer input X is final; the previous layer's attention has read VT)
-            BH_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+            BH_HIP_TRY(hipEventRecord(evf, ls));  // (the layer input X is final; the previous layer's attention has read VT)
+            BH_HIP_TRY(hipStreamWaitEvent(vs, evf, 0));
         }
         if ((rc = gemm(e, L.wv, d, Xp, d, VTp, m_pad, da, rows, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0,
-                       fork ? e->side : ls)))
+                       fork ? vs : ls)))
             return rc;
-        if (fork) BH_HIP_TRY(hipEventRecord(e->ev_join, e->side));
+        if (fork) BH_HIP_TRY(hipEventRecord(evj, vs));
         if ((rc = gemm(e, Xp, d, L.wqk, d, QKp, 2 * da, rows, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
-        if (fork) BH_HIP_TRY(hipStreamWaitEvent(ls, e->ev_join, 0));
+        if (fork) BH_HIP_TRY(hipStreamWaitEvent(ls, evj, 0));
         BhAttnArgs aa{};
         aa.qk = e->QK.p;  // (the attention kernels address tokens by their absolute packed row: seq_off)
         aa.ldqk = 2 * da;
