@@ -940,28 +940,46 @@ int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq,
     if (!q_dev || !out_scores_dev || !out_ids_dev) return fail(BH_EINVAL, "null buffer");
     HIP_TRY(hipSetDevice(ix->device));
     constexpr int KK = BH_MAX_LIST_K;
+    // A range holds lists for a SUBSET of the queries once it has been split: only the queries whose list overflowed in the
+    // parent are searched again in the four children (round 3 searched them for all nq queries: on clustered data with many
+    // queries that multiplied corpus passes and host time); the parent keeps serving the others.
     struct Range {
-        int64_t t0, t1;  // tiles [t0, t1)
-        std::vector<float> s;
+        int64_t t0, t1;           // tiles [t0, t1)
+        std::vector<int> qs;      // the queries this range holds lists for (ascending)
+        std::vector<int> qpos;    // [nq] position of query q in qs, -1 = none
+        std::vector<float> s;     // [qs.size()][KK]
         std::vector<long long> i;
     };
     _Float16* const rows0 = ix->rows;
     const int64_t n_rows0 = ix->n_rows, n_tiles0 = ix->n_tiles;
+    const size_t qrow_bytes = (size_t)ix->dim * (q_dtype == BH_F16 ? 2 : 4);
     float* d_s = nullptr;
     long long* d_i = nullptr;
+    unsigned char* d_qsub = nullptr;  // gathered query rows of a subset search
     HIP_TRY(hipMalloc((void**)&d_s, (size_t)nq * KK * sizeof(float)));
-    if (hipMalloc((void**)&d_i, (size_t)nq * KK * sizeof(long long)) != hipSuccess) {
+    if (hipMalloc((void**)&d_i, (size_t)nq * KK * sizeof(long long)) != hipSuccess ||
+        hipMalloc((void**)&d_qsub, (size_t)nq * qrow_bytes) != hipSuccess) {
         (void)hipFree(d_s);
+        if (d_i) (void)hipFree(d_i);
         return fail(BH_ENOMEM, "hipMalloc of the range lists");
     }
     bh_counters total{};
     int rc = BH_OK;
     auto search_range = [&](Range& r) -> int {
+        const int nqs = (int)r.qs.size();
+        const void* qptr = q_dev;
+        if (nqs != nq) {  // gather the subset's query rows (few: the queries one range overflowed for)
+            for (int j = 0; j < nqs; ++j)
+                HIP_TRY(hipMemcpyAsync(d_qsub + (size_t)j * qrow_bytes, (const unsigned char*)q_dev + (size_t)r.qs[(size_t)j] * qrow_bytes, qrow_bytes,
+                                       hipMemcpyDeviceToDevice, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+            qptr = d_qsub;
+        }
         const int64_t row_lo = r.t0 * 32, row_hi = std::min<int64_t>(n_rows0, r.t1 * 32);
         ix->rows = rows0 + (size_t)row_lo * ix->dim_padded;  // a view: rows of the range, tile-aligned
         ix->n_rows = row_hi - row_lo;
         ix->n_tiles = r.t1 - r.t0;
-        const int rc2 = search_device_lists(ix, q_dev, q_dtype, nq, KK, id_offset + row_lo, d_s, reinterpret_cast<int64_t*>(d_i));
+        const int rc2 = search_device_lists(ix, qptr, q_dtype, nqs, KK, id_offset + row_lo, d_s, reinterpret_cast<int64_t*>(d_i));
         ix->rows = rows0;
         ix->n_rows = n_rows0;
         ix->n_tiles = n_tiles0;
@@ -980,18 +998,25 @@ int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq,
         total.n_workgroups = c.n_workgroups;
         total.k_padded = c.k_padded;
         total.shader_mhz = c.shader_mhz;
-        r.s.resize((size_t)nq * KK);
-        r.i.resize((size_t)nq * KK);
+        r.s.resize((size_t)nqs * KK);
+        r.i.resize((size_t)nqs * KK);
         HIP_TRY(hipMemcpy(r.s.data(), d_s, r.s.size() * sizeof(float), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(r.i.data(), d_i, r.i.size() * sizeof(long long), hipMemcpyDeviceToHost));
         return BH_OK;
     };
+    auto make_range = [&](int64_t t0, int64_t t1, const std::vector<int>& qs) {
+        Range r{t0, t1, qs, std::vector<int>((size_t)nq, -1), {}, {}};
+        for (size_t j = 0; j < qs.size(); ++j) r.qpos[(size_t)qs[j]] = (int)j;
+        return r;
+    };
     // ranges: ~100 expected members of the top k each, tile-aligned
     std::vector<Range> ranges;
     {
+        std::vector<int> all_q((size_t)nq);
+        for (int q = 0; q < nq; ++q) all_q[(size_t)q] = q;
         const int64_t want = std::max<int64_t>(1, std::min<int64_t>(n_tiles0, (k + 99) / 100));
         const int64_t per = (n_tiles0 + want - 1) / want;
-        for (int64_t t = 0; t < n_tiles0; t += per) ranges.push_back(Range{t, std::min(n_tiles0, t + per), {}, {}});
+        for (int64_t t = 0; t < n_tiles0; t += per) ranges.push_back(make_range(t, std::min(n_tiles0, t + per), all_q));
     }
     for (auto& r : ranges)
         if ((rc = search_range(r)) != BH_OK) break;
@@ -1000,19 +1025,22 @@ int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq,
     struct Ent {
         float s;
         long long id;
-        int range;
     };
     std::vector<Ent> all;
-    for (int round = 0; rc == BH_OK && round < 64; ++round) {
-        std::vector<char> overflow(ranges.size(), 0);
+    constexpr int kMaxRounds = 64;
+    for (int round = 0; rc == BH_OK; ++round) {
+        std::vector<std::vector<int>> over(ranges.size());  // per range: the queries whose list may have dropped a member of the top k
         bool any = false;
         for (int q = 0; q < nq; ++q) {
             all.clear();
-            for (size_t j = 0; j < ranges.size(); ++j)
+            for (size_t j = 0; j < ranges.size(); ++j) {
+                const int at = ranges[j].qpos[(size_t)q];
+                if (at < 0) continue;
                 for (int t = 0; t < KK; ++t) {
-                    const long long id = ranges[j].i[(size_t)q * KK + t];
-                    if (id >= 0) all.push_back(Ent{ranges[j].s[(size_t)q * KK + t], id, (int)j});
+                    const long long id = ranges[j].i[(size_t)at * KK + t];
+                    if (id >= 0) all.push_back(Ent{ranges[j].s[(size_t)at * KK + t], id});
                 }
+            }
             std::sort(all.begin(), all.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s > b.s : a.id < b.id; });
             const size_t take = std::min<size_t>(all.size(), (size_t)k);
             for (size_t t = 0; t < (size_t)k; ++t) {
@@ -1021,34 +1049,44 @@ int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq,
             }
             // a FULL list whose last entry is still inside the merged top k may have dropped a member of the top k
             for (size_t j = 0; j < ranges.size(); ++j) {
-                const long long last_id = ranges[j].i[(size_t)q * KK + KK - 1];
+                const int at = ranges[j].qpos[(size_t)q];
+                if (at < 0) continue;
+                const long long last_id = ranges[j].i[(size_t)at * KK + KK - 1];
                 if (last_id < 0) continue;  // the range's list is not full: it holds every candidate of the range
-                const float last_s = ranges[j].s[(size_t)q * KK + KK - 1];
+                const float last_s = ranges[j].s[(size_t)at * KK + KK - 1];
                 // (fewer than k entries in all: every full list may hide members of the top k)
                 const bool last_in_topk = take < (size_t)k || last_s > all[take - 1].s ||
                                           (last_s == all[take - 1].s && last_id <= all[take - 1].id);
                 if (last_in_topk && ranges[j].t1 - ranges[j].t0 > 1) {
-                    overflow[j] = 1;
+                    over[j].push_back(q);
                     any = true;
                 }
             }
         }
         if (!any) break;
+        if (round + 1 >= kMaxRounds) {  // (cannot happen: a range shrinks fourfold per round down to one tile, which cannot overflow)
+            rc = fail(BH_EUNSUPPORTED, "k = %d: the range search did not converge in %d rounds", k, kMaxRounds);
+            break;
+        }
         std::vector<Range> next;
         for (size_t j = 0; j < ranges.size() && rc == BH_OK; ++j) {
-            if (!overflow[j]) {
+            if (over[j].empty()) {
                 next.push_back(std::move(ranges[j]));
                 continue;
             }
             const int64_t span = ranges[j].t1 - ranges[j].t0, per = (span + 3) / 4;
             for (int64_t t = ranges[j].t0; t < ranges[j].t1 && rc == BH_OK; t += per) {
-                Range r{t, std::min(ranges[j].t1, t + per), {}, {}};
+                Range r = make_range(t, std::min(ranges[j].t1, t + per), over[j]);
                 rc = search_range(r);
                 next.push_back(std::move(r));
             }
+            // the parent keeps its lists for the queries it did not overflow for
+            for (int q : over[j]) ranges[j].qpos[(size_t)q] = -1;
+            if (over[j].size() < ranges[j].qs.size()) next.push_back(std::move(ranges[j]));
         }
         ranges.swap(next);
     }
+    (void)hipFree(d_qsub);
     (void)hipFree(d_s);
     (void)hipFree(d_i);
     if (rc != BH_OK) return rc;

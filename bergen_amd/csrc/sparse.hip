@@ -701,26 +701,41 @@ static int sparse_search_view(bh_sparse_index* ix, int64_t view_lo, int64_t view
 static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_t q_dtype, int32_t nq, int32_t k, int64_t id_offset,
                                  float* out_scores, int64_t* out_ids) {
     constexpr int KK = kSparseListK;
+    // (as index.hip search_large_k: once split, a range holds lists only for the queries that overflowed in its parent)
     struct Range {
         int64_t g0, g1;  // 32-document groups [g0, g1)
+        std::vector<int> qs;    // the queries this range holds lists for (ascending)
+        std::vector<int> qpos;  // [nq] position of query q in qs, -1 = none
         std::vector<float> s;
         std::vector<long long> i;
     };
     const int64_t n_rows = ix->n_rows, n_groups = (n_rows + 31) / 32;
+    const size_t qrow_bytes = (size_t)ix->vocab * (q_dtype == BH_F16 ? 2 : 4);
+    std::vector<unsigned char> qsub;  // gathered query rows of a subset search
     bh_counters total{};
     // Non-negative data (the usual SPLADE case; per query tile, see the view search): a range's list holds every document with
     // a POSITIVE score first and continues with its lowest zero-score rows.  Zero-score rows need no search — they are the
     // rows that are not positive, in row order — so such a list has dropped something only if its LAST entry is still
     // positive, and a query with fewer than k matching documents is completed here from the lowest absent rows of the whole
     // corpus (without this, every range would be drilled down to single groups looking for more zeros).
-    std::vector<char> floor_q((size_t)nq, 0);
+    std::vector<char> floor_q((size_t)nq, 0), floor_sub;
     auto search_range = [&](Range& r) -> int {
+        const int nqs = (int)r.qs.size();
         const int64_t lo = r.g0 * 32, hi = std::min<int64_t>(n_rows, r.g1 * 32);
-        r.s.assign((size_t)nq * KK, -INFINITY);
-        r.i.assign((size_t)nq * KK, -1);
-        const int rc = sparse_search_view(ix, lo, hi - lo, q_host, q_dtype, nq, KK, id_offset + lo, r.s.data(), reinterpret_cast<int64_t*>(r.i.data()),
-                                          floor_q.data());
+        r.s.assign((size_t)nqs * KK, -INFINITY);
+        r.i.assign((size_t)nqs * KK, -1);
+        const void* qptr = q_host;
+        if (nqs != nq) {
+            qsub.resize((size_t)nqs * qrow_bytes);
+            for (int j = 0; j < nqs; ++j)
+                memcpy(qsub.data() + (size_t)j * qrow_bytes, (const unsigned char*)q_host + (size_t)r.qs[(size_t)j] * qrow_bytes, qrow_bytes);
+            qptr = qsub.data();
+        }
+        floor_sub.assign((size_t)nqs, 0);
+        const int rc = sparse_search_view(ix, lo, hi - lo, qptr, q_dtype, nqs, KK, id_offset + lo, r.s.data(), reinterpret_cast<int64_t*>(r.i.data()),
+                                          floor_sub.data());
         if (rc != BH_OK) return rc;
+        for (int j = 0; j < nqs; ++j) floor_q[(size_t)r.qs[(size_t)j]] = floor_sub[(size_t)j];  // (a property of the query and the corpus: the same in every range)
         const bh_counters& c = ix->counters;
         total.scan_ms += c.scan_ms;
         total.merge_ms += c.merge_ms;
@@ -734,11 +749,18 @@ static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_
         total.dim_padded = c.dim_padded;
         return BH_OK;
     };
+    auto make_range = [&](int64_t g0, int64_t g1, const std::vector<int>& qs) {
+        Range r{g0, g1, qs, std::vector<int>((size_t)nq, -1), {}, {}};
+        for (size_t j = 0; j < qs.size(); ++j) r.qpos[(size_t)qs[j]] = (int)j;
+        return r;
+    };
     std::vector<Range> ranges;
     {
+        std::vector<int> all_q((size_t)nq);
+        for (int q = 0; q < nq; ++q) all_q[(size_t)q] = q;
         const int64_t want = std::max<int64_t>(1, std::min<int64_t>(n_groups, (k + 49) / 50));
         const int64_t per = (n_groups + want - 1) / want;
-        for (int64_t g = 0; g < n_groups; g += per) ranges.push_back(Range{g, std::min(n_groups, g + per), {}, {}});
+        for (int64_t g = 0; g < n_groups; g += per) ranges.push_back(make_range(g, std::min(n_groups, g + per), all_q));
     }
     int rc = BH_OK;
     for (auto& r : ranges)
@@ -748,18 +770,22 @@ static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_
         long long id;
     };
     std::vector<Ent> all;
-    for (int round = 0; round < 64; ++round) {
-        std::vector<char> overflow(ranges.size(), 0);
+    constexpr int kMaxRounds = 64;
+    for (int round = 0;; ++round) {
+        std::vector<std::vector<int>> over(ranges.size());
         bool any = false;
         for (int q = 0; q < nq; ++q) {
             const bool floor = floor_q[(size_t)q] != 0;
             all.clear();
-            for (auto& r : ranges)
+            for (auto& r : ranges) {
+                const int at = r.qpos[(size_t)q];
+                if (at < 0) continue;
                 for (int t = 0; t < KK; ++t) {
-                    const long long id = r.i[(size_t)q * KK + t];
-                    const float sc = r.s[(size_t)q * KK + t];
+                    const long long id = r.i[(size_t)at * KK + t];
+                    const float sc = r.s[(size_t)at * KK + t];
                     if (id >= 0 && !(floor && !(sc > 0.f))) all.push_back(Ent{sc, id});  // (floor: the zero-score fill is rebuilt below)
                 }
+            }
             std::sort(all.begin(), all.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s > b.s : a.id < b.id; });
             const size_t take = std::min<size_t>(all.size(), (size_t)k);
             for (size_t t = 0; t < (size_t)k; ++t) {
@@ -783,30 +809,36 @@ static int sparse_search_large_k(bh_sparse_index* ix, const void* q_host, int32_
                 }
             }
             for (size_t j = 0; j < ranges.size(); ++j) {
-                const long long last_id = ranges[j].i[(size_t)q * KK + KK - 1];
+                const int at = ranges[j].qpos[(size_t)q];
+                if (at < 0) continue;
+                const long long last_id = ranges[j].i[(size_t)at * KK + KK - 1];
                 if (last_id < 0) continue;  // not full: the list holds every document of the range that can matter
-                const float last_s = ranges[j].s[(size_t)q * KK + KK - 1];
+                const float last_s = ranges[j].s[(size_t)at * KK + KK - 1];
                 if (floor && !(last_s > 0.f)) continue;  // its positive documents are all listed; zeros are rebuilt above
                 const bool last_in_topk = take < (size_t)k || last_s > all[take - 1].s || (last_s == all[take - 1].s && last_id <= all[take - 1].id);
                 if (last_in_topk && ranges[j].g1 - ranges[j].g0 > 1) {
-                    overflow[j] = 1;
+                    over[j].push_back(q);
                     any = true;
                 }
             }
         }
         if (!any) break;
+        if (round + 1 >= kMaxRounds)  // (cannot happen: a range shrinks fourfold per round down to one group, which cannot overflow)
+            return bh_fail(BH_EUNSUPPORTED, "k = %d: the sparse range search did not converge in %d rounds", k, kMaxRounds);
         std::vector<Range> next;
         for (size_t j = 0; j < ranges.size(); ++j) {
-            if (!overflow[j]) {
+            if (over[j].empty()) {
                 next.push_back(std::move(ranges[j]));
                 continue;
             }
             const int64_t span = ranges[j].g1 - ranges[j].g0, per = (span + 3) / 4;
             for (int64_t g = ranges[j].g0; g < ranges[j].g1; g += per) {
-                Range r{g, std::min(ranges[j].g1, g + per), {}, {}};
+                Range r = make_range(g, std::min(ranges[j].g1, g + per), over[j]);
                 if ((rc = search_range(r)) != BH_OK) return rc;
                 next.push_back(std::move(r));
             }
+            for (int q : over[j]) ranges[j].qpos[(size_t)q] = -1;  // the parent keeps its lists for the queries it did not overflow for
+            if (over[j].size() < ranges[j].qs.size()) next.push_back(std::move(ranges[j]));
         }
         ranges.swap(next);
     }
