@@ -332,6 +332,7 @@ struct BhClsHeadArgs {
     const _Float16* wc;        // [n_labels][d]  classifier.weight
     const _Float16* bc;        // [n_labels]
     float* out;                // [batch][n_labels] logits, fp32
+    float* pooled;             // [batch][d] scratch: the pooler's output, fp32
     int batch, d, n_labels;
     int activation = 0;        // 0 = tanh (BertPooler), 1 = erf-GELU (DeBERTa's ContextPooler)
 };

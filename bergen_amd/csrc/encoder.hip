@@ -60,6 +60,7 @@ struct bh_encoder {
     int attn_short = 128;  // sequences up to this length use the 4-wave attention workgroups
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
+    BhDevBuf<float> POOLED;  // classification head: the pooler's output [batch][d]
     BhDevBuf<unsigned> SEG;  // SPLADE head: per (sequence, term) running max of relu(logit)
     // optional masked-LM head (BertOnlyMLMHead: transform dense + GELU + LayerNorm, decoder); SPLADE pooling (pool 3)
     _Float16* mlm_arena = nullptr;
@@ -318,6 +319,7 @@ void bh_encoder_destroy(bh_encoder* e) {
     e->ibuf.release();
     e->seq_off.release();
     e->SEG.release();
+    e->POOLED.release();
     e->rel_idx.release();
     e->REL_LN.release();
     e->REL_QK.release();
@@ -654,6 +656,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size
                              : pool == 4 ? (size_t)batch * e->n_labels * 2 /* fp32 logits, counted in halves */ : (size_t)batch * d;
     if (pool == 3 && (rc = e->SEG.ensure((size_t)batch * e->vpad))) return rc;
+    if (pool == 4 && (rc = e->POOLED.ensure((size_t)batch * d))) return rc;
     _Float16* out_dev = static_cast<_Float16*>(out);
     if (!out_on_device) {
         if ((rc = e->OUT.ensure(out_elems))) return rc;
@@ -854,6 +857,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         ca.wc = e->cls_wc;
         ca.bc = e->cls_bc;
         ca.out = reinterpret_cast<float*>(out_dev);
+        ca.pooled = e->POOLED.p;
         ca.batch = batch;
         ca.d = d;
         ca.n_labels = e->n_labels;

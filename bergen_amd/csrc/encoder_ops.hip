@@ -197,41 +197,54 @@ __global__ void __launch_bounds__(256) bh_splade_finish_kernel(BhSpladeFinishArg
 
 // Sequence-classification head of HF BertForSequenceClassification (the reference's cross-encoder reranker,
 // models/rerankers/crossencoder.py:18,34-38 -> .logits): pooled = tanh(Wp h_cls + bp) (BertPooler), logits = Wc pooled + bc.
-// One workgroup per sequence; a wave per output row, lanes striding over d with 16-byte loads; fp32 throughout.
-__global__ void __launch_bounds__(256) bh_cls_head_kernel(BhClsHeadArgs a) {
-    __shared__ float hs[2048];
-    __shared__ float ps[2048];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Two launches, fp32 throughout.  (1) pooler: a wave per (output row j, sequence) pair group -- grid (d / 8, batch), four
+// waves of two rows each, lanes striding over d with 16-byte loads (the [CLS] row and the weight rows are L2 hits after
+// the first workgroup; one workgroup per SEQUENCE walking all d rows serially took 0.33 ms for 32 pairs at d = 1024,
+// 4 % of a BERT-large forward).  (2) classifier: one workgroup per sequence, a wave per label.  The per-lane summation
+// order is the one the single-kernel version had.
+__global__ void __launch_bounds__(256) bh_cls_pool_kernel(BhClsHeadArgs a) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = a.d, nchunk = d >> 3;
     const _Float16* h = a.x + (size_t)a.seq_off[b] * d;
-    for (int c = tid; c < nchunk; c += 256) {
-        const half8 v = *reinterpret_cast<const half8*>(h + (size_t)c * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) hs[c * 8 + e] = (float)v[e];
-    }
-    __syncthreads();
-    for (int j = wave; j < d; j += 4) {
+    for (int r = 0; r < 2; ++r) {
+        const int j = blockIdx.x * 8 + wave * 2 + r;
+        if (j >= d) break;
         const _Float16* w = a.wp + (size_t)j * d;
         float s = 0.f;
         for (int c = lane; c < nchunk; c += 64) {
             const half8 v = *reinterpret_cast<const half8*>(w + (size_t)c * 8);
+            const half8 x = *reinterpret_cast<const half8*>(h + (size_t)c * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)v[e] * hs[c * 8 + e];
+            for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)x[e];
         }
         s = wave_sum(s);
         if (lane == 0) {
             const float z = s + (float)a.bp[j];
-            ps[j] = a.activation == 1 ? 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)) : tanhf(z);
+            a.pooled[(size_t)b * d + j] = a.activation == 1 ? 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)) : tanhf(z);
         }
     }
-    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) bh_cls_head_kernel(BhClsHeadArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = a.d, nchunk = d >> 3;
+    const float* ps = a.pooled + (size_t)b * d;
     for (int l = wave; l < a.n_labels; l += 4) {
         const _Float16* w = a.wc + (size_t)l * d;
         float s = 0.f;
         for (int c = lane; c < nchunk; c += 64) {
             const half8 v = *reinterpret_cast<const half8*>(w + (size_t)c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += (float)v[e] * ps[c * 8 + e];
+            const float4 p0 = *reinterpret_cast<const float4*>(ps + (size_t)c * 8);
+            const float4 p1 = *reinterpret_cast<const float4*>(ps + (size_t)c * 8 + 4);
+            s += (float)v[0] * p0.x;
+            s += (float)v[1] * p0.y;
+            s += (float)v[2] * p0.z;
+            s += (float)v[3] * p0.w;
+            s += (float)v[4] * p1.x;
+            s += (float)v[5] * p1.y;
+            s += (float)v[6] * p1.z;
+            s += (float)v[7] * p1.w;
         }
         s = wave_sum(s);
         if (lane == 0) a.out[(size_t)b * a.n_labels + l] = s + (float)a.bc[l];
@@ -240,8 +253,16 @@ __global__ void __launch_bounds__(256) bh_cls_head_kernel(BhClsHeadArgs a) {
 
 hipError_t bh_launch_cls_head(const BhClsHeadArgs& a, hipStream_t st) {
     if (a.batch <= 0) return hipSuccess;
-    if (a.d > 2048 || (a.d & 7)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(bh_cls_head_kernel, dim3((unsigned)a.batch), dim3(256), 0, st, a);
+    if (a.d > 2048 || (a.d & 7) || !a.pooled) return hipErrorInvalidValue;
+    for (int b0 = 0; b0 < a.batch; b0 += 65535) {  // (grid.y limit)
+        BhClsHeadArgs t = a;
+        t.seq_off = a.seq_off + b0;
+        t.pooled = a.pooled + (size_t)b0 * a.d;
+        t.out = a.out + (size_t)b0 * a.n_labels;
+        t.batch = a.batch - b0 < 65535 ? a.batch - b0 : 65535;
+        hipLaunchKernelGGL(bh_cls_pool_kernel, dim3((unsigned)((a.d + 7) / 8), (unsigned)t.batch), dim3(256), 0, st, t);
+        hipLaunchKernelGGL(bh_cls_head_kernel, dim3((unsigned)t.batch), dim3(256), 0, st, t);
+    }
     return hipGetLastError();
 }
 

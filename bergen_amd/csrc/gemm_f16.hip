@@ -110,6 +110,15 @@ hipError_t bh_launch_gemm_f16_batched(const BhGemmArgs& a_in, hipStream_t stream
     return bh_gemm_persist(a, BH_EPI_BATCHED, 1, stream);
 }
 
+static int gemm_cu_count() {
+    static int cached = 0;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (cached == 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return cached > 0 ? cached : 256;
+}
+
 // variant: 0 = auto; 1..5 = explicit tile configuration (gemm_f16_kernel.h); 6 = generic bounds-checked kernel
 // for everything; 7 = persistent 256x256 kernel (gemm_f16_persist.h; burst stores); 8 = 7 with stores deferred into
 // the next tile's main loop, 9 = 7 with non-temporal stores (both valid results; ablations); 11..28 = bench-only
@@ -153,10 +162,18 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     const bool variant_balanced = variant == 10;  // 7 + balanced remainder, explicitly
     if (variant == 10) variant = 7;
     if (variant == 0) variant = (a.M >= 256 && a.N >= 256) ? ((epi & BH_EPI_RESIDUAL) ? 5 : 7) : (a.M >= 256 && a.N >= 128) ? 2 : 1;
+    // A small problem leaves most of the chip idle under 256x256 tiles (a rerank batch of 32 pairs: 5 632 packed rows x
+    // N = 1024 = 88 tiles on 256 CUs): with at most half a round of them, 128x128 tiles (two workgroups per CU) put four
+    // times as many workgroups on the chip.  Measured (profiles/r04i_gemm_small_m.jsonl): 0.0282 -> 0.0218 ms at
+    // K = 1024 and 0.0852 -> 0.0637 ms at K = 4096 for 88 tiles; at 176 tiles the 256x256 kernel is still ahead.
+    if (auto_variant && variant == 7 && (!a.c_block_rows || (a.M % 128 == 0 && a.N % 128 == 0)) &&
+        (long long)(a.M / 256) * (a.N / 256) * 2 <= gemm_cu_count())
+        variant = 1;
     if (variant == 6 || !epi_fast || g_swap_b != 0) return bh_gemm_generic(a, epi, stream);
     const bool persist = (variant >= 7 && variant <= 9) || variant == 31 || variant == 32 || variant == 33;
-    if (a.c_block_rows && !(persist && a.M % 256 == 0 && a.N % 256 == 0 && !(epi & BH_EPI_RESIDUAL)))
-        return hipErrorInvalidValue;  // blocked output: whole 256x256 tiles only (fast epilogues)
+    if (a.c_block_rows && !(((persist && a.M % 256 == 0 && a.N % 256 == 0) || (variant == 1 && a.M % 128 == 0 && a.N % 128 == 0)) &&
+                            !(epi & BH_EPI_RESIDUAL)))
+        return hipErrorInvalidValue;  // blocked output: whole tiles only (fast epilogues)
     // burst stores; non-temporal for the GELU (FFN-up) output, which is far larger than the caches and is read
     // back only by the next kernel (measured: +8 % on that GEMM, -7 % on the others)
     // 33: deferred stores with alternating loader teams (gemm_f16_persist.h PST 16) where the stage count allows it
@@ -180,15 +197,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         // N = 768 projection = 3.14 -> 4 rounds).  In auto mode the tiles beyond the last FULL round go to a second
         // launch with 128x128 tiles (two blocks per CU): a quarter of the work per tile, spread over the whole chip.
         // Variant 10 only: measured neutral (a small tile still pays the full K-loop latency), kept as an experiment.
-        int n_cu = 256;
-        {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            static int cached = 0;
-            if (cached == 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            if (cached > 0) n_cu = cached;
-        }
+        const int n_cu = gemm_cu_count();
         const int tm_ = mi / 256, tn_ = ni / 256;
         const long long T = (long long)tm_ * tn_;
         const long long full = T / n_cu * n_cu;
