@@ -69,6 +69,8 @@ __host__ __device__ inline unsigned bh_scan256_first_claimed_tile(int n_tiles, i
 // scan_topk256.hip (8 waves, two per SIMD, 256 queries per pass; d in {384, 512, 768})
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);
 bool bh_scan256_supports(int dim_padded, int kp);
+bool bh_scan256_pair_supports(int dim_padded, int kp);
+hipError_t bh_launch_scan256_paired(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream);  // qsplit = 2: two passes, see scan_topk256.hip
 int bh_scan256_tile(int dim_padded);  // queries per pass: 256, or 128 at d = 1024
 
 struct BhMergeArgs {

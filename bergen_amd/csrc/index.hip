@@ -63,7 +63,7 @@ struct Options {
     int tail128 = 1;  // scan_topk256: a last pass of at most 128 queries runs on the 128-query kernel (5.6 instead of 7.2 ms at 21 M x 768)
     int err_scale = 1;  // test-only: multiplies the certificate's error bound (forces queries through the fall-back)
     int filter256 = 1;  // exact fall-back: filter passes of 256 queries on scan_topk256.hip where it applies (0: 128 queries on scan_topk.hip)
-    int pair256 = 0;    // scan_topk256: workgroups b and b ^ 8 (same XCD) walk the same tiles for different 256-query halves of a 512-query launch
+    int pair256 = 1;    // scan_topk256: workgroups b and b ^ 8 (same XCD) walk the same tiles for two 256-query passes of one launch (1 = paced every 16 tiles, 2 = free-running, 3 = paced with the non-temporal stream policy of the unpaired launches)
 };
 
 // One row per dense-search option: name, member, accepted values (lo..hi, or a short list), the message of a rejected value.
@@ -92,7 +92,7 @@ const OptionDef g_option_defs[] = {
     {"ring_variant", &Options::ring_variant, 0, 7, {-1, -1, -1, -1}, "ring_variant must be 0..7"},
     {"workgroups_per_cu", &Options::workgroups_per_cu, 1, 1, {-1, -1, -1, -1}, "workgroups_per_cu must be 1 (LDS ring fills the CU)"},
     {"filter256", &Options::filter256, 0, 1, {-1, -1, -1, -1}, "filter256 must be 0 or 1"},
-    {"pair256", &Options::pair256, 0, 1, {-1, -1, -1, -1}, "pair256 must be 0 or 1"},
+    {"pair256", &Options::pair256, 0, 3, {-1, -1, -1, -1}, "pair256 must be 0..3"},
 };
 constexpr int kUnset = INT32_MIN;  // per-handle override table: "inherit the process-wide value"
 
@@ -578,7 +578,9 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     // one threshold block per pass (scan_topk256: [bq][256] slots + [bq] bounds + the claim counter; else [bq * qs][64] slots):
     // all of them are reset by ONE launch up front; the paired-workgroup progress words sit behind the blocks
     const size_t gthr_pass = use256 ? (size_t)bq * (BH_SLOTS256 + 1) + 4 : (size_t)bq * qs_max * 64;
-    if ((rc = ix->gthr.ensure(gthr_pass * (size_t)n_pass + grid))) return rc;
+    // (the progress words of paired workgroups sit behind the blocks, 64-byte aligned: partners are 32 bytes apart)
+    const size_t progress_off = (gthr_pass * (size_t)n_pass + 15) / 16 * 16;
+    if ((rc = ix->gthr.ensure(progress_off + grid))) return rc;
     if ((rc = ix->clk.ensure((size_t)grid * 8 + BH_TL_WORDS, true, ix->stream))) return rc;
     if ((rc = ix->uncert.ensure((size_t)nq_pad))) return rc;
     if ((rc = ix->kth.ensure((size_t)nq_pad))) return rc;
@@ -604,7 +606,21 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     // corpus pass costs 5.6 instead of 7.2 ms there —, as a group of its own (its lists are 128 queries wide)
     const bool tail128 = grouped && use256 && bq == 256 && opt.tail128 && opt.ablate == 0 && nq % bq != 0 && nq % bq <= 128;
     const int n_main = tail128 ? n_pass - 1 : n_pass;
-    const int n_group = grouped ? (n_main + group - 1) / group + (tail128 ? 1 : 0) : n_pass;
+    // option pair256 (scan_topk256.hip, ABL bit 128): the main passes two at a time in ONE launch — each pass on half the grid, the
+    // partner workgroups of the two passes on one XCD walking the same tiles, so that a corpus line leaves HBM once per 512
+    // queries.  A pass of a paired launch has grid / 2 lists per query, stored behind each other: such passes are merged in
+    // groups of their own; an odd main pass is left over and runs unpaired.
+    const bool pair256 = grouped && use256 && opt.pair256 != 0 && opt.ablate == 0 && grid == 256 && n_main >= 2 &&
+                         bh_scan256_pair_supports(dp, kp) && (dp != 1024 || opt.ring_variant == 0 || opt.ring_variant == 5);
+    const int n_paired = pair256 ? (n_main & ~1) : 0;
+    struct Group {
+        int p0, p1;
+        bool paired;
+    };
+    std::vector<Group> groups;
+    for (int g0 = 0; g0 < n_paired; g0 += 2 * group) groups.push_back({g0, std::min(n_paired, g0 + 2 * group), true});
+    for (int g0 = n_paired; g0 < n_main; g0 += group) groups.push_back({g0, std::min(n_main, g0 + group), false});
+    const int n_group = grouped ? (int)groups.size() + (tail128 ? 1 : 0) : n_pass;
     for (int p = 0; p < n_group; ++p)
         if (!ix->event(2 + 4 * p + 3)) return fail(BH_EHIP, "hipEventCreate failed");
 
@@ -613,6 +629,9 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     // starts at the first tile that is not handed out by workgroup index
     HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)(gthr_pass * (size_t)n_pass), 0x007fffffu, st, use256 ? (long long)gthr_pass : 0,
                                (long long)bq * (BH_SLOTS256 + 1), use256 ? bh_scan256_first_claimed_tile((int)ix->n_tiles, grid, dp) : 0u));
+    if (n_paired > 0)  // (a pass of a paired launch is distributed over half the grid)
+        HIP_TRY(bh_launch_fill_u32(ix->gthr.p, (long long)(gthr_pass * (size_t)n_paired), 0x007fffffu, st, (long long)gthr_pass,
+                                   (long long)bq * (BH_SLOTS256 + 1), bh_scan256_first_claimed_tile((int)ix->n_tiles, grid / 2, dp)));
     double alg_bytes = 0;
     auto scan_args = [&](int p, bh_u64* partial_p) {
         const int q0 = passes[p].first, qs = passes[p].second;
@@ -633,7 +652,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         sa.pair_window = opt.pair_window;
         sa.dyn_tiles = opt.dyn_tiles;
         sa.clk = use256 ? ix->clk.p : nullptr;
-        sa.progress = ix->gthr.p + gthr_pass * (size_t)n_pass;  // [grid] words behind the threshold blocks
+        sa.progress = ix->gthr.p + progress_off;  // [grid] words behind the threshold blocks
         return sa;
     };
     auto merge_args = [&](int q0, int tile, int n_lists, const bh_u64* partial_p, long long pass_stride) {
@@ -662,18 +681,31 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         return bh_launch_scan(sa, dp, kp, qw, grid, st);
     };
     if (grouped) {
-        for (int g0 = 0, gi = 0; g0 < n_main; g0 += group, ++gi) {
-            const int g1 = std::min(n_main, g0 + group);
+        for (int gi = 0; gi < (int)groups.size(); ++gi) {
+            const int g0 = groups[(size_t)gi].p0, g1 = groups[(size_t)gi].p1;
+            const bool paired = groups[(size_t)gi].paired;
+            const size_t pass_elems = paired ? partial_elems / 2 : partial_elems;  // keys between the list sets of consecutive passes
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi), st));
-            for (int p = g0; p < g1; ++p) {
-                HIP_TRY(launch_scan(scan_args(p, ix->partial.p + (size_t)(p - g0) * partial_elems)));
+            for (int p = g0; p < g1; p += paired ? 2 : 1) {
+                BhScanArgs sa = scan_args(p, ix->partial.p + (size_t)(p - g0) * pass_elems);
+                if (paired) {  // passes p and p + 1: queries, threshold blocks and list sets behind each other
+                    sa.qsplit = 2;
+                    sa.pair_window = opt.pair256 == 2 ? 0 : 1;
+                    // the partner finds a line in L2 only if the first reader's request left it there: the stream of a paired
+                    // launch is cached unless pair256 = 3 (same box: 84.9 ms per headline search non-temporal, 83.0 cached; unpaired 88.4 / 90.3)
+                    if (opt.pair256 != 3) sa.nontemporal = 0;
+                    HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
+                    HIP_TRY(bh_launch_scan256_paired(sa, dp, kp, grid, st));
+                } else {
+                    HIP_TRY(launch_scan(sa));
+                }
                 // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
-                alg_bytes += (double)ix->n_rows * ix->dim * 2.0 + (double)bq * ix->dim * 2.0 + (double)bq * k * 12.0;
+                alg_bytes += (paired ? 2.0 : 1.0) * ((double)ix->n_rows * ix->dim * 2.0 + (double)bq * ix->dim * 2.0 + (double)bq * k * 12.0);
             }
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 1), st));
             const int q0 = passes[g0].first;
             const int nq_group = std::min(nq, passes[g1 - 1].first + bq) - q0;
-            HIP_TRY(bh_launch_merge_rescore(merge_args(q0, bq, grid, ix->partial.p, (long long)partial_elems), kp, nq_group, st));
+            HIP_TRY(bh_launch_merge_rescore(merge_args(q0, bq, paired ? grid / 2 : grid, ix->partial.p, (long long)pass_elems), kp, nq_group, st));
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 3), st));
         }
         if (tail128) {

@@ -68,6 +68,11 @@
 #include "bh_device.h"
 #include "bh_kernels.h"
 
+// paired launches: tiles between two checkpoints of partner workgroups (a power of two >= 4)
+#ifndef BH_PAIR_CKPT
+#define BH_PAIR_CKPT 16
+#endif
+
 namespace {
 
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -135,7 +140,7 @@ template <int NK32, int KP, int LS, int R, int PD, bool NT, int ABL = 0, int LM 
 __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     // diagnostics block of this workgroup (a.clk, 8 words: 100 MHz ticks at entry / loop start / loop end / exit, shader
     // cycles at loop start / end, candidates wave 0 holds at the end); every stamp is stored where it is taken
-    if (a.clk != nullptr && threadIdx.x == 0) a.clk[8 * blockIdx.x + 0] = wall_clock64();
+    if (a.clk != nullptr && threadIdx.x == 0) a.clk[8 * blockIdx.x + 0] = wall_clock64();  // (paired launch: the block of the REAL index; the other stamps go by b below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int D = NK32 * 32;
     constexpr int LINES = D / 64;
@@ -182,7 +187,30 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     if (LM == 1 || LM == 2) {
         if (loader) __builtin_amdgcn_s_setprio(1);
     }
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    // ABL bit 128 is not an ablation either: the PAIRED launch (index.hip option pair256).  One launch serves TWO 256-query passes
+    // with the same grid: workgroup B works for pass (B >> 3) & 1 as workgroup (B & 7) | (B >> 4) << 3 of a launch of half the
+    // grid — its own queries, thresholds, candidate buffers and lists, exactly as if the two passes had been launched one after
+    // the other on half the chip each — and B ^ 8, which the dispatcher puts on the same XCD, walks the same round-robin tiles
+    // for the other pass: whichever of the two asks for a line first takes it from HBM, the partner finds it in the XCD's L2.
+    // That only holds while the two stay within the L2's reach of each other (a few tiles): every 16 tiles they wait for each
+    // other through a progress word (pure pacing: a stale or missing value only changes timing, a timeout switches it off).
+    constexpr bool PAIRED = (ABL & 128) != 0;
+    static_assert(!PAIRED || R == 3 || LM == 1, "the pacing load of wave 7 must not disturb a loader's vmcnt arithmetic");
+    // Inside the kernel a paired workgroup goes by b = pass * 128 + its index in the pass's half grid (the launcher insists on a
+    // grid of 256): the buffers of the two passes lie behind each other in exactly that order, the slots 128 .. 255 of the
+    // second pass's tables are as good as 0 .. 127, and the only things that need the pass are the tile distribution's start,
+    // the query pointer (both before the loop) and the pass's threshold block.
+    int G = (int)gridDim.x, b = (int)blockIdx.x;
+    int b_pass = b;  // index in the pass's grid: the tile distribution
+    if constexpr (PAIRED) {
+        const int bc = b, h = (bc >> 3) & 1;
+        G >>= 1;
+        b_pass = (bc & 7) | ((bc >> 4) << 3);
+        b = h * G + b_pass;
+        a.qtile += (size_t)h * (8 * 16 * NB) * (NK32 * 32);
+        a.gthr += (size_t)h * ((size_t)(8 * 16 * NB) * (BH_SLOTS256 + 1) + 4);
+    }
+    auto gthr_pass = [&]() -> unsigned* { return a.gthr; };  // (paired: moved to the pass's block above)
     const int q16 = lane & 15, lg = lane >> 4;
 
     const int n_tiles = (int)a.n_tiles;  // < 2^27 (n_rows < 2^32)
@@ -197,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     //             worse than round robin does.
     const int rr = DYN && a.dyn_tiles != 0 ? bh_scan256_round_robin_tiles(n_tiles, G, D) : 0;  // (the host starts the claim counter behind them)
     const bool dyn = rr > 0;
-    int run_base = b, run_stride = G, run_len = n_tiles > b ? (n_tiles - b + G - 1) / G : 0;
+    int run_base = b_pass, run_stride = G, run_len = n_tiles > b_pass ? (n_tiles - b_pass + G - 1) / G : 0;
     int nxt_base = 0, nxt_len = 0;
     int claim_len = CH;  // tiles the next claim asks for
     if (dyn) {
@@ -324,6 +352,14 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
     const int nboot = (!a.share || FILT) ? 0 : run_len < BH_BOOT_TILES ? run_len : BH_BOOT_TILES;
     const int boot_step = (run_len / BH_BOOT_TILES > 1 ? run_len / BH_BOOT_TILES : 1) * run_stride;  // in tiles
     unsigned* lds_claim = reinterpret_cast<unsigned*>(smem + R * STAGE_BYTES);
+    if constexpr (PAIRED) {
+        static_assert(DYN, "the partner's progress word lives behind the claim word");
+        if (tid == 448) {  // (wave 7 reads these: its own writes, in program order)
+            lds_claim[1] = 0u;
+            *reinterpret_cast<unsigned long long*>(lds_claim + 2) =
+                (a.pair_window != 0 && a.progress != nullptr) ? (unsigned long long)(a.progress + blockIdx.x) : 0ull;
+        }
+    }
     if (run_len > 0) {
         const unsigned char* corpus = reinterpret_cast<const unsigned char*>(a.corpus);
         // issue cursor: the tile it stands on, the tile step and the tiles left of ITS run (phase 0: the bootstrap tiles;
@@ -551,7 +587,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                                 }
                             pubv = top[RB - 1];
                         }
-                        __hip_atomic_fetch_max(a.gthr + (size_t)((wave * NB + nb) * 16 + q16) * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(pubv),
+                        __hip_atomic_fetch_max(gthr_pass() + (size_t)((wave * NB + nb) * 16 + q16) * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(pubv),
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
@@ -599,7 +635,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                                             // lists of 64: the slot holds the best score of its workgroups; published right
                                             // here (fire and forget) instead of tracked in a register
                                             if (a.share)
-                                                __hip_atomic_fetch_max(a.gthr + (size_t)((wave * NB + nb) * 16 + q16) * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(sv),
+                                                __hip_atomic_fetch_max(gthr_pass() + (size_t)((wave * NB + nb) * 16 + q16) * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(sv),
                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         } else {
                                             float x = sv;
@@ -643,7 +679,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                             const int q = (wave * NB + nb) * 16 + q16;
                             const float mine = best[nb][RB - 1];
                             if (mine > -__builtin_inff()) {  // (re-published at every exchange: ~20 atomics per lane and pass)
-                                __hip_atomic_fetch_max(a.gthr + (size_t)q * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(mine), __ATOMIC_RELAXED,
+                                __hip_atomic_fetch_max(gthr_pass() + (size_t)q * BH_SLOTS256 + (b & (BH_SLOTS256 - 1)), bh_ordf(mine), __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
@@ -655,12 +691,12 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     //     rows at or above T.  (b) the bounds the other workgroups refined: one word per query.
                     const int sel = (b + i + tj) & (16 * NB - 1);
                     const int qsel = wave * (16 * NB) + sel;
-                    unsigned* gbound = a.gthr + (size_t)(128 * NB) * BH_SLOTS256;
+                    unsigned* gbound = gthr_pass() + (size_t)(128 * NB) * BH_SLOTS256;
                     uintx4 sl;
                     unsigned gb[NB];
                     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1"
                                  : "=v"(sl)
-                                 : "v"((unsigned)lane_c * 16u), "s"(sgpr_ptr(a.gthr + (size_t)qsel * BH_SLOTS256))
+                                 : "v"((unsigned)lane_c * 16u), "s"(sgpr_ptr(gthr_pass() + (size_t)qsel * BH_SLOTS256))
                                  : "memory");
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
@@ -710,6 +746,47 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
             }
             ++i;
             if (i > n_tiles) break;  // (cannot happen: a workgroup never scans more tiles than there are; keeps a logic error from hanging the GPU)
+            if constexpr (PAIRED) {
+                // Checkpoint every BH_PAIR_CKPT (16) tiles of the round-robin run: wave 7 publishes the count and starts the load of the
+                // partner's word (LDS-DMA into the word behind the claim word: no register is in flight; the rendezvous of
+                // the next tile waits for it with the refill); one tile later it reads the word and, if the partner has not
+                // reached the checkpoint, polls until it has.  The other waves wait at the next rendezvous meanwhile.
+                // Nothing of this lives in registers across the tile loop: the workgroup's progress pointer is parked in LDS
+                // (null = not paced), the partner's word is 32 bytes away from it (bc ^ 8; the block is 64-byte aligned).
+                if (run_stride != 1 && wave == 7 && (i & (BH_PAIR_CKPT - 2)) == 0 && i > 1) {
+                    const unsigned long long ppv = *(volatile unsigned long long*)(lds_claim + 2);
+                    unsigned pv = *(volatile unsigned*)(lds_claim + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragment reads in flight land too: no register moves)
+                    const unsigned long long pp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ppv >> 32)) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ppv);
+                    if (pp != 0ull) {
+                        unsigned* mine = reinterpret_cast<unsigned*>(pp);
+                        const unsigned* theirs = reinterpret_cast<const unsigned*>(pp ^ 32ull);
+                        if ((i & 1) == 0) {
+                            if (opaque_lane() == 0) {
+                                __hip_atomic_fetch_max(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)theirs,
+                                                                 (__attribute__((address_space(3))) void*)(lds_claim + 1), 4, 0, 16);
+                            }
+                        } else {
+                            int spins = 0;
+                            while ((unsigned)__builtin_amdgcn_readfirstlane(pv) + 1u < (unsigned)i) {
+                                if (++spins > 8192) {  // the partner is not coming (not resident?): stop pacing
+                                    if (opaque_lane() == 0) *(volatile unsigned long long*)(lds_claim + 2) = 0ull;
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                                if (opaque_lane() == 0)
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)theirs,
+                                                                     (__attribute__((address_space(3))) void*)(lds_claim + 1), 4, 0, 16);
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                pv = *(volatile unsigned*)(lds_claim + 1);
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
+                        }
+                    }
+                }
+            }
             if constexpr (DYN) {
                 // The run after the current one: claimed LEAD + 2 tiles before the current run's end by wave 7 (it does not
                 // issue LDS-DMA, its vmcnt is its own; it waits for the answer on the spot — an answer on its way into a
@@ -719,7 +796,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 if (dyn && run_len >= CH) {  // (a shorter run is the corpus's last, clipped: nothing follows)
                     const int left = run_len - tj;
                     if (left == LEAD + 2 && wave == 7) {
-                        unsigned* ctr = a.gthr + (size_t)BQ * (BH_SLOTS256 + 1);
+                        unsigned* ctr = gthr_pass() + (size_t)BQ * (BH_SLOTS256 + 1);
                         unsigned got = (unsigned)claim_len;
                         const unsigned off = 0u;
                         if (opaque_lane() == 0) {
@@ -741,6 +818,16 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 }
             }
             if (tj == run_len) {
+                if constexpr (PAIRED) {  // the partner must not wait for a workgroup that has left the shared tiles
+                    if (run_stride != 1 && wave == 7) {
+                        const unsigned long long ppv = *(volatile unsigned long long*)(lds_claim + 2);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const unsigned long long pp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ppv >> 32)) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ppv);
+                        if (pp != 0ull && opaque_lane() == 0)
+                            __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(pp), 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (nxt_len == 0) break;
                 run_base = nxt_base;
                 run_stride = 1;
@@ -838,7 +925,7 @@ template <int NK32, int KP, int LS, int R, int PD, int ABL = 0, int LM = 1, int 
 static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t stream) {
     constexpr size_t ring = (size_t)R * 32 * LS * 128;
     constexpr size_t smem = ring + 16 <= 160 * 1024 ? ring + 16 : ring;  // + the chunk claim word (dynamic tile distribution)
-    constexpr bool kProduction = ABL == 0 && (LM == 1 || LM == 0) && SCHED == 1 && NBUF == PD;
+    constexpr bool kProduction = (ABL == 0 || ABL == 128) && (LM == 1 || LM == 0) && SCHED == 1 && NBUF == PD;
     // the bench-only instantiations exist with the non-temporal stream policy only (compile time)
     const bool nt = a.nontemporal != 0 || !kProduction;
     static bool attr_done[2] = {false, false};
@@ -884,6 +971,24 @@ hipError_t bh_launch_filter_scan256(const BhScanArgs& a, int dim_padded, int gri
         case 768: return launch256_one<24, 64, 12, 3, 4, 64, 0>(a, grid, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// the paired launch (two passes of one launch on partner workgroups, see the kernel): d = 768 on the one-rendezvous ring, d = 1024
+// on the four-stage ring (the five-stage one has no room for the claim and progress words)
+bool bh_scan256_pair_supports(int dim_padded, int kp) { return (dim_padded == 768 || dim_padded == 1024) && (kp == 64 || kp == 128 || kp == 256); }
+template <int NK32, int LS, int R, int PD, int NB, int LM>
+static hipError_t launch256_paired_kp(const BhScanArgs& a, int kp, int grid, hipStream_t stream) {
+    switch (kp) {
+        case 64: return launch256_one<NK32, 64, LS, R, PD, 128, LM, 1, PD, NB>(a, grid, stream);
+        case 128: return launch256_one<NK32, 128, LS, R, PD, 128, LM, 1, PD, NB>(a, grid, stream);
+        case 256: return launch256_one<NK32, 256, LS, R, PD, 128, LM, 1, PD, NB>(a, grid, stream);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t bh_launch_scan256_paired(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream) {
+    if (!bh_scan256_pair_supports(dim_padded, kp) || a.qsplit != 2 || grid != 256 || !a.progress || a.ablate != 0) return hipErrorInvalidValue;
+    if (dim_padded == 1024) return launch256_paired_kp<32, 8, 4, 4, 1, 1>(a, kp, grid, stream);
+    return launch256_paired_kp<24, 12, 3, 4, 2, 0>(a, kp, grid, stream);
 }
 
 hipError_t bh_launch_scan256(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream) {

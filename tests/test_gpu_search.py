@@ -470,6 +470,34 @@ def test_dynamic_tile_distribution_matches_oracle(amd, no_tail_routing, n, d, nq
         ix.close()
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(300001, 768, 600, 50), (70001, 768, 1300, 50), (340000, 768, 520, 10), (4999, 768, 512, 50),
+                                      (100003, 768, 530, 100), (100003, 768, 515, 200), (320017, 1024, 300, 200), (70001, 1024, 650, 50),
+                                      (90001, 1024, 257, 100)])
+def test_paired_launches_match_oracle(amd, n, d, nq, k):
+    """Option pair256 (scan_topk256.hip, ABL bit 128): two 256-query passes per launch, each on half the grid, partner
+    workgroups on one XCD walking the same tiles (1 = paced through the progress words, 2 = free-running).  Whatever the
+    pacing does, a pass of a paired launch is an ordinary pass on 128 workgroups: bit-exact against the oracle for two pairs +
+    the 128-query tail (600), two pairs + an unpaired pass + the tail (1 300), one pair + 8 tail queries with the dynamic
+    tile claims of half a grid (340 k rows), and a corpus with fewer tiles than workgroups; lists of 128 and 256; d = 1024 (128-query
+    passes on the four-stage ring: three launches of 2 x 128 queries at 300 queries ...)."""
+    rng = np.random.default_rng(n + nq + k + d)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    try:
+        tile = 256 if d == 768 else 128
+        for mode in (1, 2, 0, 3, 1):
+            ix.set_option("pair256", mode)
+            s, i = ix.search(q, k)
+            compare.assert_bit_exact(s, i, ws, wi, f"pair256={mode} n={n} d={d} nq={nq} k={k}")
+            assert ix.counters()["n_passes"] == (nq + tile - 1) // tile
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("k", [50, 56, 120])
 @pytest.mark.parametrize("d", [768, 1024])
 def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
