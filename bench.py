@@ -199,10 +199,15 @@ def streamed_full_lists(check, queries, dim, k, plant_rows, n_total, device, met
 def gate_queries(nq, counters, n_check):
     """Query indices for the full-list gate, spread over the passes of the search that `counters` describes: the first pass, a
     middle one, the last full pass of the main kernel and the LAST pass (the 128-query tail kernel when the search had one) —
-    both ends of each tile."""
+    both ends of each tile.  With paired launches (counter paired_launches) passes 2j and 2j + 1 share a launch, on different
+    halves of the grid: the second half of the first and of the last paired launch is covered as well."""
     tile = int(counters["query_tile"])
     n_pass = int(counters["n_passes"])
-    starts = sorted({0, (n_pass // 2) * tile, max(0, n_pass - 2) * tile, (n_pass - 1) * tile})
+    n_pair = int(counters.get("paired_launches", 0))
+    starts = {0, (n_pass // 2) * tile, max(0, n_pass - 2) * tile, (n_pass - 1) * tile}
+    if n_pair > 0:
+        starts |= {tile, (2 * n_pair - 1) * tile}
+    starts = sorted(starts)
     starts = [s0 for s0 in starts if s0 < nq]
     per = max(1, n_check // len(starts))
     idx = []
@@ -492,11 +497,14 @@ def config5_leg(args, local_rank, device):
     torch.cuda.synchronize()
     steps = max(1, min(args.steps, 3))
     t0 = time.perf_counter()
-    scan_ms = 0.0
+    scan_ms = pair_ms = tail_ms = 0.0
     for _ in range(steps):
         res = ix.search(queries, k)
         host = (torch.as_tensor(res[0]).cpu(), torch.as_tensor(res[1]).cpu())
-        scan_ms += ix.counters()["scan_ms"]
+        cc = ix.counters()
+        scan_ms += cc["scan_ms"]
+        pair_ms += cc.get("paired_scan_ms", 0.0)
+        tail_ms += cc.get("tail_scan_ms", 0.0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     c = ix.counters()
@@ -515,17 +523,12 @@ def config5_leg(args, local_rank, device):
         check = gate_queries(nq, c, min(16, args.full_list_queries))
         gate_ok, gate = full_list_gate_fn(check, s_np, i_np, queries, dim, k, plant_rows, n, device, metric="cos", scaled=True)
         ok &= gate_ok
-    per_launch = c["algorithmic_bytes"] / c["n_passes"]
-    avg = scan_ms / (steps * c["n_passes"])
+    roof = scan_roofline({"scan_ms": scan_ms, "tail_scan_ms": tail_ms, "paired_scan_ms": pair_ms}, c, steps, n, dim, k, args.traffic_json)
     ix.close()
     return {"workload": f"configs[4] geometry: {nq} queries x {n} x {dim} fp16, cosine (rows normalised once at finalize), top-{k}, one GPU",
             "queries_per_s": nq / dt, "finalize_seconds": finalize_s,
             "ms_per_step": dt * 1e3, "query_tile": c["query_tile"], "passes_per_step": c["n_passes"], "k_padded": c["k_padded"],
-            "roofline": {"bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]) if c["query_tile"] != 128 or c.get("shader_mhz", 0) == 0
-                         else "bh_scan_topk256_kernel", "achieved": per_launch / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": per_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic(args.traffic_json, "bh_scan_topk256_kernel", n, dim),
-                         "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg},
+            "roofline": roof,
             "uncertified_queries": c.get("uncertified_queries", 0), "full_list_gate": gate, "parity_check": "pass" if ok else "FAIL"}
 
 
@@ -544,12 +547,13 @@ def real_size_leg(args, local_rank, device):
     steps = max(1, min(args.steps, 3))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    scan_ms = tail_ms = 0.0
+    scan_ms = tail_ms = pair_ms = 0.0
     for _ in range(steps):
         res = ix.search(queries, k, host=True)
         cc = ix.counters()
         scan_ms += cc["scan_ms"]
         tail_ms += cc.get("tail_scan_ms", 0.0)
+        pair_ms += cc.get("paired_scan_ms", 0.0)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     c = ix.counters()
@@ -567,16 +571,11 @@ def real_size_leg(args, local_rank, device):
         check = gate_queries(nq, c, min(16, args.full_list_queries))
         gate_ok, gate = full_list_gate_fn(check, s_np, i_np, queries, dim, k, plant_rows, n, device)
         ok &= gate_ok
-    has_tail = c.get("tail_query_tile", 0) != 0 and c["n_passes"] > 1
-    n_launch = (c["n_passes"] - (1 if has_tail else 0)) * steps
-    per_launch = n * dim * 2.0 + c["query_tile"] * dim * 2.0 + c["query_tile"] * k * 12.0
-    avg = (scan_ms - (tail_ms if has_tail else 0.0)) / n_launch
+    roof = scan_roofline({"scan_ms": scan_ms, "tail_scan_ms": tail_ms, "paired_scan_ms": pair_ms}, c, steps, n, dim, k, args.traffic_json)
     ix.close()
     return {"workload": f"configs[1] at KILT-100w's real row count: {nq} queries x {n} x {dim} fp16, top-{k}, one GPU",
             "queries_per_s": nq / dt, "ms_per_step": dt * 1e3, "query_tile": c["query_tile"], "passes_per_step": c["n_passes"],
-            "roofline": {"bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]), "achieved": per_launch / (avg * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": per_launch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg},
+            "roofline": roof,
             "uncertified_queries": c.get("uncertified_queries", 0), "full_list_gate": gate, "parity_check": "pass" if ok else "FAIL"}
 
 
@@ -956,17 +955,71 @@ def scan_kernel_name(query_tile):
     return {256: "bh_scan_topk256_kernel", 192: "bh_scan_topk192_kernel"}.get(query_tile, "bh_scan_topk_kernel")
 
 
+def scan_roofline(acc, c, steps, n_rows, dim, k, traffic_json, dim_padded=None):
+    """The `roofline` object of a dense search: the DOMINANT kernel launch of the step against the HBM roofline, with the
+    algorithmic bytes of SURVEY §8d — per pass of one query tile  N*d*2 + Bq*d*2 + Bq*k*12  — times the passes ONE launch serves.
+    `acc` = scan_ms / tail_scan_ms / paired_scan_ms summed over `steps` searches, `c` = the last search's counters.
+    Three kinds of launch can make up a step (bergen_amd/csrc/index.hip):
+      * PAIRED launches (option pair256, the default): two query-tile passes in one launch, each on half the grid; partner
+        workgroups of one XCD walk the same tiles, so a corpus line leaves HBM once per launch and the second reader takes it
+        from L2.  Units per launch = 2 passes: `algorithmic_bytes_per_launch` is twice the per-pass figure, while the HBM bytes
+        such a launch has to move are only  N*d*2 + 2*(Bq*d*2 + Bq*k*12)  (`hbm_bytes_needed_per_launch`; `traffic` = PMC).
+      * one unpaired launch when the number of full passes is odd, and
+      * the tail pass (<= 128 queries left) on the 128-query kernel.
+    Each kind is timed by its own pair of HIP events on the launch stream (counters paired_scan_ms / tail_scan_ms / scan_ms)."""
+    tile = c["query_tile"]
+    has_tail = c.get("tail_query_tile", 0) != 0 and c["n_passes"] > 1
+    n_pair = c.get("paired_launches", 0)
+    n_single = c["n_passes"] - (1 if has_tail else 0) - 2 * n_pair
+    per_pass = n_rows * dim * 2.0 + tile * dim * 2.0 + tile * k * 12.0  # SURVEY §8d
+    tail_ms = acc.get("tail_scan_ms", 0.0) if has_tail else 0.0
+    pair_ms = acc.get("paired_scan_ms", 0.0) if n_pair else 0.0
+    single_ms = acc["scan_ms"] - tail_ms - pair_ms
+    name = scan_kernel_name(tile) if not (tile == 128 and c.get("shader_mhz", 0) != 0) else "bh_scan_topk256_kernel"  # (d = 1024: 128-query tile of the 256 kernel)
+    dp = dim_padded or dim
+    if n_pair:
+        units, launches, avg = 2, n_pair * steps, pair_ms / (n_pair * steps)
+        traffic = pmc_traffic(traffic_json, name, n_rows, dp, variant="paired")
+        kind = f"paired: two {tile}-query passes per launch (template ABL = 128), partner workgroups of one XCD share the corpus stream through L2"
+    else:
+        units, launches, avg = 1, n_single * steps, single_ms / max(1, n_single * steps)
+        traffic = pmc_traffic(traffic_json, name, n_rows, dp)
+        kind = f"one {tile}-query pass per launch"
+    per_launch = units * per_pass
+    achieved = per_launch / (avg * 1e-3) / 1e9
+    flops = 2.0 * units * tile * n_rows * dim
+    hbm_needed = n_rows * dim * 2.0 + units * (tile * dim * 2.0 + tile * k * 12.0)
+    out = {"bound": "hbm", "kernel": name, "launch": kind, "passes_per_launch": units,
+           "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+           "algorithmic_bytes_per_launch": per_launch, "algorithmic_bytes_per_pass": per_pass, "avg_launch_ms": avg, "launches": launches,
+           # what the launch must take from / bring to HBM when the corpus is read once per LAUNCH, and the rate that corresponds to
+           "hbm_bytes_needed_per_launch": hbm_needed, "hbm_frac_of_needed_bytes": hbm_needed / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           # the same launch against the other roofline: a tile of 256 queries is 256 flop per corpus byte (ridge ~310)
+           "mfma_tflops": flops / (avg * 1e-3) / 1e12, "mfma_frac": flops / (avg * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+           "shader_mhz": c.get("shader_mhz", 0.0)}
+    if n_pair and n_single > 0:
+        a1 = single_ms / (n_single * steps)
+        out["unpaired_launch"] = {"kernel": name, "passes_per_launch": 1, "launches": n_single * steps, "avg_launch_ms": a1,
+                                  "frac": per_pass / (a1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "traffic": pmc_traffic(traffic_json, name, n_rows, dp),
+                                  "what": "an odd number of full passes leaves one that runs alone"}
+    out["tail_pass"] = ({"kernel": "bh_scan_topk_kernel", "query_tile": 128, "avg_launch_ms": tail_ms / steps,
+                         "what": "the last pass of a step (<= 128 queries left) runs on the 128-query kernel"} if has_tail else None)
+    return out
+
+
 KERNEL_SOURCES = {"bh_scan_topk256_kernel": "scan_topk256.hip", "bh_scan_topk192_kernel": "scan_topk192.hip",
                   "bh_scan_topk_kernel": "scan_topk.hip", "bh_csr_scan_mfma_kernel": "csr_mfma.hip"}
 
 
-def pmc_traffic(path, kernel, n_rows, dim_padded):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/hbm_traffic.json, keyed "<kernel>@<dim>"), or
+def pmc_traffic(path, kernel, n_rows, dim_padded, variant=None):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/hbm_traffic.json, keyed "<kernel>@<dim>";
+    `variant` "paired" = the paired launch of the 256-query kernel, keyed "<kernel>/paired@<dim>"), or
     None when that file holds no entry for this kernel at this geometry — or when the kernel's source file has changed since
     the counters were collected (the entry carries the file's sha256): a stale measurement is not reported."""
     import hashlib
     try:
-        ent = json.load(open(path)).get("kernels", {}).get(f"{kernel}@{dim_padded}")
+        ent = json.load(open(path)).get("kernels", {}).get(f"{kernel}/{variant}@{dim_padded}" if variant else f"{kernel}@{dim_padded}")
         if not ent or ent.get("n_rows") != n_rows:
             return None
         src = os.path.join(ROOT, "bergen_amd", "csrc", KERNEL_SOURCES[kernel])
@@ -1108,7 +1161,7 @@ def run(args, env):
 
     for _ in range(args.warmup):
         res, res_host = step()
-    scan_ms = merge_ms = kernel_total_ms = tail_ms = 0.0
+    scan_ms = merge_ms = kernel_total_ms = tail_ms = pair_ms = 0.0
     uncertified = 0
     barrier()
     t0 = time.perf_counter()
@@ -1117,6 +1170,7 @@ def run(args, env):
         c = ix.counters()
         scan_ms += c["scan_ms"]
         tail_ms += c.get("tail_scan_ms", 0.0)
+        pair_ms += c.get("paired_scan_ms", 0.0)
         merge_ms += c["merge_ms"]
         kernel_total_ms += c["total_ms"]
         uncertified += c.get("uncertified_queries", 0)
@@ -1176,15 +1230,11 @@ def run(args, env):
         parity = "pass" if ok else "FAIL"
 
     if rank == 0:
-        # The roofline object is the DOMINANT kernel's: when the last pass (<= 128 queries left) ran on the 128-query kernel
-        # (counters tail_query_tile / tail_scan_ms), that launch is taken out of the average and reported beside it.
-        has_tail = c.get("tail_query_tile", 0) != 0 and c["n_passes"] > 1
-        n_launch = (c["n_passes"] - (1 if has_tail else 0)) * args.steps
-        per_launch_bytes = (hi - lo) * dim * 2.0 + c["query_tile"] * dim * 2.0 + c["query_tile"] * k * 12.0
-        avg_scan_ms = (scan_ms - (tail_ms if has_tail else 0.0)) / n_launch
-        achieved = per_launch_bytes / (avg_scan_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(args.traffic_json, scan_kernel_name(c["query_tile"]), hi - lo, dim)
-        flops_per_launch = 2.0 * c["query_tile"] * (hi - lo) * dim  # MFMA work of one launch (query tile padded to its full width)
+        # The roofline object is the DOMINANT launch's (scan_roofline): paired launches of the 256-query kernel when there are
+        # any, with the unpaired launch and the 128-query tail pass reported beside it.
+        roof = scan_roofline({"scan_ms": scan_ms, "tail_scan_ms": tail_ms, "paired_scan_ms": pair_ms}, c, args.steps, hi - lo, dim, k,
+                             args.traffic_json)
+        roof["power"] = power  # the launch is power-bound before it is HBM- or MFMA-bound: see PowerSampler
         out = {
             "metric": "queries/sec (value) + passages-encoded/sec (passages_per_s), KILT-100w-sized corpus (21M x 768 fp16) "
                       "top-50, kilt_nq-dev-sized query set; % of HBM / MFMA roofline",
@@ -1205,20 +1255,7 @@ def run(args, env):
                 "query_tile": c["query_tile"], "passes_per_step": c["n_passes"], "workgroups": c["n_workgroups"],
                 "rows_per_gpu": hi - lo, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of partial top-k" if world > 1 else ""),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": scan_kernel_name(c["query_tile"]),
-                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_scan_ms, "launches": n_launch,
-                # the same launch against the other roofline: a tile of 256 queries is 256 flop per corpus byte (ridge ~310)
-                "mfma_tflops": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12,
-                "mfma_frac": flops_per_launch / (avg_scan_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                "shader_mhz": c.get("shader_mhz", 0.0),
-                # the launch is power-bound before it is HBM- or MFMA-bound: see PowerSampler
-                "power": power,
-                "tail_pass": ({"kernel": "bh_scan_topk_kernel", "query_tile": 128, "avg_launch_ms": tail_ms / args.steps,
-                               "what": "the last pass of a step (<= 128 queries left) runs on the 128-query kernel"} if has_tail else None),
-            },
+            "roofline": roof,
             "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,
                                    "stream_total": kernel_total_ms / args.steps},
             "index_build_seconds": build_s,

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BERGEN_HIP_LIB", os.path.join(_HERE, "lib", "libbergen_hip.so"))
 
-BH_VERSION = 140  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
+BH_VERSION = 141  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
 
 BH_OK = 0
 BH_EINVAL = -1
@@ -29,7 +29,7 @@ BH_METRIC_COS = 1
 
 
 class _Sized(ctypes.Structure):
-    """Structs whose first field is `struct_size` (include/bergen_hip.h, BH_VERSION 140): set on construction."""
+    """Structs whose first field is `struct_size` (include/bergen_hip.h, BH_VERSION 141): set on construction."""
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
@@ -59,6 +59,9 @@ class bh_counters(_Sized):
         ("reserved0", ctypes.c_int32),
         ("exact_passes", ctypes.c_int64),
         ("exact_rows_rescored", ctypes.c_int64),
+        ("paired_scan_ms", ctypes.c_double),
+        ("paired_launches", ctypes.c_int32),
+        ("reserved1", ctypes.c_int32),
     ]
 
 

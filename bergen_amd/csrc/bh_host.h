@@ -18,7 +18,7 @@ int bh_fail(int code, const char* fmt, ...);
     } while (0)
 
 // Copy a library-side struct into a caller's struct whose first field is `int32_t struct_size` = the caller's sizeof
-// (include/bergen_hip.h, BH_VERSION 140): at most that many bytes are written, the caller's struct_size stays as it was.
+// (include/bergen_hip.h, BH_VERSION 141): at most that many bytes are written, the caller's struct_size stays as it was.
 // Returns false when the caller's size is implausible (smaller than `min_size`).
 template <typename T>
 inline bool bh_copy_sized(T* out, const T& src, size_t min_size) {

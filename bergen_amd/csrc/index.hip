@@ -923,12 +923,15 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     c.k_padded = kp;
     c.scan_ms = 0;
     c.merge_ms = 0;
+    c.paired_scan_ms = 0;
+    c.paired_launches = n_paired / 2;
     for (int p = 0; p < n_group; ++p) {
         float ms = 0;
         // grouped: the group's scans back to back (launch gaps included), then its one merge; paired: per pass, the merge
         // on the side stream (beside the next pass's scan: not additive with scan_ms)
         HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p), ix->event(2 + 4 * p + 1)));
         c.scan_ms += ms;
+        if (grouped && p < (int)groups.size() && groups[(size_t)p].paired) c.paired_scan_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p + (grouped ? 1 : 2)), ix->event(2 + 4 * p + 3)));
         c.merge_ms += ms;
     }
@@ -1026,6 +1029,8 @@ int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq,
         total.exact_ms += c.exact_ms;
         total.exact_passes += c.exact_passes;
         total.exact_rows_rescored += c.exact_rows_rescored;
+        total.paired_scan_ms += c.paired_scan_ms;
+        total.paired_launches += c.paired_launches;
         total.query_tile = c.query_tile;
         total.n_workgroups = c.n_workgroups;
         total.k_padded = c.k_padded;

@@ -32,8 +32,9 @@ extern "C" {
  * library never touches bytes beyond it, so a caller built against an older, shorter struct stays memory-safe and a newer,
  * longer one gets zeros in the fields this build does not know); bh_counters grew the fall-back / tail-pass fields (they were
  * added under 130 without a bump: VERDICT r3); + bh_index_set_option / bh_sparse_set_option (per-handle options),
- * bh_encoder_set_rel_index (DeBERTa). */
-#define BH_VERSION 140
+ * bh_encoder_set_rel_index (DeBERTa); 141 = 0.1.4.1 (round 4): bh_counters grew paired_scan_ms / paired_launches at its END (option
+ * pair256); a caller built against 140 keeps working memory-wise (struct_size) but must be rebuilt to pass the version check. */
+#define BH_VERSION 141
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -79,6 +80,10 @@ typedef struct bh_counters {
     int32_t reserved0;
     int64_t exact_passes;     /* filter passes (corpus passes) the fall-back of the last search took */
     int64_t exact_rows_rescored; /* rows the filter passes let through, summed over the uncertified queries */
+    double paired_scan_ms;    /* part of scan_ms spent in PAIRED launches (option pair256: two query-tile passes per launch, the
+                                 corpus stream of the second served from the L2 of the first's XCD), else 0 */
+    int32_t paired_launches;  /* number of such launches in the last search (each counts as 2 in n_passes) */
+    int32_t reserved1;
 } bh_counters;
 
 /* Library / device lifecycle ------------------------------------------------------- */

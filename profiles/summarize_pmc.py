@@ -74,7 +74,10 @@ for k, cs in scan.items():
     name = base_name(k)
     sparse = name == "bh_csr_scan_mfma_kernel"
     dim = dim_of(name, k, sparse_vocab if sparse else dim_arg)
-    key = f"{name}@{dim}"
+    # the paired launch of the 256-query kernel (option pair256: two passes per launch, template argument ABL = 128) has its own entry
+    tpl = k.split("<", 1)[1].split(",") if "<" in k else []
+    paired = name == "bh_scan_topk256_kernel" and len(tpl) > 6 and tpl[6].strip() == "128"
+    key = f"{name}/paired@{dim}" if paired else f"{name}@{dim}"
     # a run may hold several instantiations of one kernel at one dim (ablations, the sparse pre-pass): keep the one that moves
     # the most bytes per launch
     if key in traffic and traffic[key]["hbm_bytes_per_launch"] >= rd + wr:

@@ -21,10 +21,24 @@ with open(os.path.join(out_dir, "scan_launches.csv"), "w") as f:
     f.write("kernel,start_ms,duration_ms\n")
     for t, name, d in rows:
         f.write(f'"{name}",{(t - t0) / 1e6:.3f},{d / 1e6:.4f}\n')
-head = [d for _, name, d in rows if name.startswith("bh_scan_topk256_kernel<24, 64,")]  # (candidate lists of 64: k <= 56)
+def abl(name):
+    """7th template argument of bh_scan_topk256_kernel<NK32, KP, LS, R, PD, NT, ABL, ...>: 128 = the paired launch (option pair256)."""
+    parts = name.split("<", 1)[1].split(",")
+    return int(parts[6]) if len(parts) > 6 and parts[6].strip().lstrip("-").isdigit() else 0
+
+
+h64 = [(name, d) for _, name, d in rows if name.startswith("bh_scan_topk256_kernel<24, 64,")]  # (candidate lists of 64: k <= 56)
+pair = [d for name, d in h64 if abl(name) == 128]
+head = [d for name, d in h64 if abl(name) == 0]
 tail = [d for _, name, d in rows if name.startswith("bh_scan_topk_kernel<48,") and ", 5, " not in name]
-n_head = n_search * (n_pass - 1)
-res = {"headline_kernel": "bh_scan_topk256_kernel<24, ...> (d = 768)", "headline_launches": n_head,
+# a headline step of n_pass passes (the last one on the 128-query kernel): (n_pass - 1) // 2 paired launches + (n_pass - 1) % 2
+# unpaired ones when option pair256 is on (any paired launch in the trace), n_pass - 1 unpaired ones otherwise
+n_pair = n_search * ((n_pass - 1) // 2) if pair else 0
+n_head = n_search * ((n_pass - 1) % 2 if pair else n_pass - 1)
+res = {"headline_kernel": "bh_scan_topk256_kernel<24, 64, ...> (d = 768)",
+       "paired_launches": n_pair, "paired_avg_ms": sum(pair[:n_pair]) / max(1, len(pair[:n_pair])) / 1e6,
+       "all_paired_launches_of_that_instantiation": len(pair), "all_paired_avg_ms": sum(pair) / max(1, len(pair)) / 1e6,
+       "headline_launches": n_head,
        "headline_avg_ms": sum(head[:n_head]) / max(1, len(head[:n_head])) / 1e6,
        "all_launches_of_that_instantiation": len(head), "all_avg_ms": sum(head) / max(1, len(head)) / 1e6,
        "tail_pass_kernel": "bh_scan_topk_kernel<48, ...> (128-query kernel, last pass of a step)",

@@ -91,10 +91,11 @@ def test_committed_pmc_traffic_is_reported_only_for_the_kernel_source_it_was_mea
     for key, ent in table.items():
         src = os.path.join(ROOT, "bergen_amd", "csrc", bench.KERNEL_SOURCES[ent["kernel"]])
         fresh = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16] == ent["source_sha16"]
-        got = bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"], ent["dim"])
+        variant = "paired" if "/paired@" in key else None  # (the paired launch of the 256-query kernel has an entry of its own)
+        got = bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"], ent["dim"], variant=variant)
         assert (got == ent["hbm_bytes_per_launch"]) if fresh else (got is None), key
-        assert bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"] + 1, ent["dim"]) is None      # another corpus size
-        assert bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"], ent["dim"] + 64) is None     # another geometry
+        assert bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"] + 1, ent["dim"], variant=variant) is None      # another corpus size
+        assert bench.pmc_traffic(committed, ent["kernel"], ent["n_rows"], ent["dim"] + 64, variant=variant) is None     # another geometry
     # a stale hash
     k0 = "bh_scan_topk256_kernel@768"
     stale = {"kernels": {k0: dict(table[k0], source_sha16="0" * 16)}}
@@ -102,3 +103,37 @@ def test_committed_pmc_traffic_is_reported_only_for_the_kernel_source_it_was_mea
     p.write_text(json.dumps(stale))
     assert bench.pmc_traffic(str(p), "bh_scan_topk256_kernel", table[k0]["n_rows"], 768) is None
     assert bench.pmc_traffic(str(tmp_path / "missing.json"), "bh_scan_topk256_kernel", 1, 768) is None
+
+
+def test_scan_roofline_accounts_for_paired_unpaired_and_tail_launches():
+    """bench.scan_roofline: the roofline object names the DOMINANT launch of a step.  With paired launches (index.hip option
+    pair256: two query-tile passes per launch) the units per launch are 2 passes, so SURVEY §8d's per-pass bytes count twice per
+    launch while the corpus leaves HBM once; the unpaired launch of an odd pass count and the 128-query tail pass are reported
+    beside it, each from its own HIP-event time; and the gate's query choice covers both halves of a paired launch."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n, d, k, steps = 21_000_000, 768, 50, 4
+    per_pass = n * d * 2.0 + 256 * d * 2.0 + 256 * k * 12.0
+    c = {"query_tile": 256, "n_passes": 12, "paired_launches": 5, "tail_query_tile": 128, "shader_mhz": 1500.0}
+    acc = {"scan_ms": steps * (5 * 13.4 + 7.3 + 5.0), "paired_scan_ms": steps * 5 * 13.4, "tail_scan_ms": steps * 5.0}
+    r = bench.scan_roofline(acc, c, steps, n, d, k, os.path.join(ROOT, "profiles", "missing.json"))
+    assert r["passes_per_launch"] == 2 and r["launches"] == 5 * steps and abs(r["avg_launch_ms"] - 13.4) < 1e-9
+    assert r["algorithmic_bytes_per_launch"] == 2 * per_pass and r["algorithmic_bytes_per_pass"] == per_pass
+    assert abs(r["achieved"] - 2 * per_pass / 13.4e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["hbm_bytes_needed_per_launch"] == n * d * 2.0 + 2 * (256 * d * 2.0 + 256 * k * 12.0) and r["traffic"] is None
+    assert r["unpaired_launch"]["launches"] == steps and abs(r["unpaired_launch"]["avg_launch_ms"] - 7.3) < 1e-9
+    assert abs(r["tail_pass"]["avg_launch_ms"] - 5.0) < 1e-9
+    # pairing off (or a library that does not report it): one pass per launch, the tail pass taken out of the average
+    c1 = {"query_tile": 256, "n_passes": 12, "tail_query_tile": 128, "shader_mhz": 1500.0}
+    r1 = bench.scan_roofline({"scan_ms": steps * (11 * 7.3 + 5.0), "tail_scan_ms": steps * 5.0}, c1, steps, n, d, k, "missing.json")
+    assert r1["passes_per_launch"] == 1 and r1["launches"] == 11 * steps and abs(r1["avg_launch_ms"] - 7.3) < 1e-9 and "unpaired_launch" not in r1
+    assert r1["algorithmic_bytes_per_launch"] == per_pass
+    # d = 1024: the 256-query kernel's tile is 128 queries (no tail routing), four paired launches for 1 000 queries
+    c5 = {"query_tile": 128, "n_passes": 8, "paired_launches": 4, "tail_query_tile": 0, "shader_mhz": 1400.0}
+    r5 = bench.scan_roofline({"scan_ms": 4 * 13.0, "paired_scan_ms": 4 * 13.0, "tail_scan_ms": 0.0}, c5, 1, n, 1024, 200, "missing.json")
+    assert r5["kernel"] == "bh_scan_topk256_kernel" and r5["launches"] == 4 and r5["tail_pass"] is None and "unpaired_launch" not in r5
+    # the gate looks into both halves of the first and the last paired launch, the unpaired pass and the tail pass
+    idx = bench.gate_queries(2837, c, 32)
+    passes = {i // 256 for i in idx}
+    assert {0, 1, 9, 10, 11} <= passes and len(idx) <= 32
+    assert {i // 256 for i in bench.gate_queries(2837, c1, 32)} == {0, 6, 10, 11}

@@ -1,4 +1,4 @@
-"""GPU: the boundary's own promises (include/bergen_hip.h, BH_VERSION 140) — sized structs and per-handle options."""
+"""GPU: the boundary's own promises (include/bergen_hip.h, BH_VERSION 141) — sized structs and per-handle options."""
 import ctypes
 import threading
 
