@@ -20,6 +20,8 @@ rm -rf "$OUT/trace"
 echo "== same-box A/B: pair256 off / on (headline geometry, all 21 M rows)"
 cd "$REPO"
 AB_CONFIGS="0,1;1,1" timeout 150 python profiles/ab_pair256.py 1 768 50 2>&1 | grep '^{' | tee "$REPO/gpurun_out/r04m_ab_pair256.jsonl"
+echo "== host-side gap of a headline step"
+timeout 120 python profiles/step_gap.py 2>&1 | grep -v amdgpu.ids | tee "$REPO/gpurun_out/r04m_step_gap.txt"
 cd /tmp
 echo "== PMC pass 1: FETCH_SIZE"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "bh_scan_topk256" --output-format csv -d "$OUT/pmc_fetch" -o bench -- $BENCH_PMC > "$OUT/pmc_fetch.log" 2>&1

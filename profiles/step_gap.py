@@ -24,3 +24,17 @@ for name, j in (("search() wall ms", 0), ("kernels total_ms", 1), ("clone ms", 2
     v = [r[j] for r in rows]
     print(f"{name:18s} median {statistics.median(v):8.3f}  min {min(v):8.3f}  max {max(v):8.3f}")
 print("pinned clone is_pinned:", s2.is_pinned())
+# the same through the stage (Retrieve.search_rows: what bench.py times), and with paired launches off
+stage = bench.HipEnv(0).make_stage(0, 1)
+key = "bench://synthetic-corpus"
+stage.adopt_resident_index(key, ix, n, "ip", rows=None)
+for pair in (1, 0, 1):
+    ix.set_option("pair256", pair)
+    for _ in range(2):
+        stage.search_rows(q, key, 50, "ip", n)
+    wall, kern = [], []
+    for _ in range(8):
+        t0 = time.perf_counter(); r = stage.search_rows(q, key, 50, "ip", n); t1 = time.perf_counter()
+        wall.append((t1 - t0) * 1e3); kern.append(ix.counters()["total_ms"])
+    print(f"stage.search_rows pair256={pair}: wall median {statistics.median(wall):8.3f} min {min(wall):8.3f} max {max(wall):8.3f}   kernels median {statistics.median(kern):8.3f}")
+print("loadavg", open("/proc/loadavg").read().strip(), "cpus", os.cpu_count())
