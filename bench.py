@@ -233,7 +233,8 @@ def cpu_baseline(args, dim, k):
     """The reference's op sequence (torch.mm + torch.topk per chunk + host merge, fp32) on the host cores,
     on a bounded sample, scaled linearly in N to the full corpus."""
     from oracle import ref_port
-    cores = os.cpu_count() or 1
+    from bergen_amd.utils import cpu_budget
+    cores = cpu_budget()  # the CPUs this container may keep busy (affinity mask cut to the cgroup quota), not the host's count
     torch.set_num_threads(cores)
     nq, n = args.cpu_sample_queries, args.cpu_sample_rows
     g = torch.Generator().manual_seed(5)
@@ -253,8 +254,10 @@ def cpu_baseline(args, dim, k):
     except Exception:
         model = "unknown"
     return {
-        # `cores` = the threads torch was given: every LOGICAL CPU of the box (os.cpu_count(); SMT siblings included)
-        "value": qps_full, "unit": "queries/s", "cores": cores, "cores_are": "logical CPUs = torch intra-op threads", "kind": "port",
+        # `cores` = the threads torch was given: the container's CPU budget (bergen_amd.utils.cpu_budget: logical CPUs in the
+        # affinity mask, cut to the cgroup quota — 16 of the 256 the MI355X boxes show); "host_logical_cpus" = os.cpu_count()
+        "value": qps_full, "unit": "queries/s", "cores": cores, "cores_are": "logical CPUs the container may use (cgroup quota) = torch intra-op threads",
+        "host_logical_cpus": os.cpu_count(), "kind": "port",
         "sample": (f"oracle/ref_port.py (the reference's torch.mm+torch.topk chunk loop, fp32, batch_size_sim=2048, "
                    f"chunks 150016/149504 rows) on Q={nq} x N={n} x d={dim}, best of 3 = {best:.3f} s, "
                    f"scaled x{scale:.1f} linearly in N to N={args.n_rows}; CPU: {model}; torch {torch.__version__}"),
@@ -1126,6 +1129,13 @@ def run(args, env):
                          f"(start it as `python bench.py --gpus N`, or under torch.distributed.run with --nproc-per-node N)")
 
     import bergen_amd
+    # Host-side thread pools (torch intra-op, OpenMP, the tokenizer's rayon pool) sized for the CPUs this container may use — 16 of
+    # the 256 logical CPUs a 1-GPU MI355X pod shows — instead of the host's count: pools of 256 threads spin through the cgroup's
+    # CPU quota and the kernel then freezes the whole process for the rest of the 100 ms period (round 4: 18 ms of host-side stall
+    # per 100 ms search step on one box, `nr_throttled` counting up; profiles/r04n_step_gap.txt).  Per rank: its share of the budget.
+    cpu_budget = bergen_amd.utils.fit_host_pools_to_cpu_budget()
+    if world > 1:
+        torch.set_num_threads(max(1, cpu_budget // world))
     env.init_library(args)
     if world == 1:
         from bergen_amd import _lib  # (the single-GPU secondary legs switch library options)
@@ -1259,6 +1269,7 @@ def run(args, env):
             "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,
                                    "stream_total": kernel_total_ms / args.steps},
             "index_build_seconds": build_s,
+            "host": {"cpu_budget": cpu_budget, "host_logical_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()},
             # queries (summed over the timed steps) whose exactness the certificate could not prove from the scan's
             # candidate lists and that took the exact fall-back scan (bergen_amd/csrc/certify.hip); inside the timed region
             "uncertified_queries": uncertified,
@@ -1380,7 +1391,7 @@ def run(args, env):
             try:
                 out["cpu_baseline"] = cpu_baseline(args, dim, k)
             except Exception as exc:
-                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + repr(exc)}
+                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": bergen_amd.utils.cpu_budget(), "kind": "port", "sample": "failed: " + repr(exc)}
         print(json.dumps(out), flush=True)
     stage.close()
     if world > 1:

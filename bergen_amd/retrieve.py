@@ -284,7 +284,10 @@ class Retrieve:
         # every batch cut into eight PIECES, each tokenised serially (TOKENIZERS_PARALLELISM=false is read per call) by one of up
         # to 32 threads and merged back in order: no shared pool, but eight times the Python calls per batch under the GIL; it
         # measured 25-27 k on the same hosts.
-        n_threads = max(int(self.num_workers), min(32, (os.cpu_count() or 4) // 4))
+        # (pools sized for the CPUs the container may use, not for the host's: utils.cpu_budget)
+        from .utils import fit_host_pools_to_cpu_budget
+        budget = fit_host_pools_to_cpu_budget()
+        n_threads = max(int(self.num_workers), min(32, budget // 4))
         tok = getattr(self.model, "tokenizer", None)
         serial = (n_threads >= 8 and pad_id is not None and getattr(tok, "padding_side", "right") == "right"
                   and os.environ.get("BERGEN_AMD_TOKENIZER_PIECES", "0") == "1")

@@ -15,6 +15,50 @@ from collections import defaultdict
 import torch
 
 
+def cpu_budget(cgroup_root="/sys/fs/cgroup"):
+    """CPUs this PROCESS may actually keep busy: the scheduler affinity mask, cut down to the container's CPU quota (cgroup v2
+    `cpu.max` = "<quota> <period>", v1 `cpu/cpu.cfs_quota_us` / `cpu.cfs_period_us`) — not `os.cpu_count()`, which is the host's.
+    A GPU pod typically sees every logical CPU of its host (256 on the MI355X boxes) under a quota of a few of them (16 there):
+    thread pools sized for the host (torch intra-op, OpenMP, the Rust tokenizer's rayon pool) then burn the quota of a 100 ms
+    period in a few milliseconds of spinning and the kernel freezes the WHOLE container until the period ends — tens of
+    milliseconds of host-side stall between two launches (round 4: 18 ms on a 100 ms search step, `nr_throttled` counting up in
+    `cpu.stat`).  Host-side pools of this package and of bench.py are sized with this number."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            period = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
+            if q > 0 and period > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def fit_host_pools_to_cpu_budget():
+    """Size the host-side thread pools this process has not sized yet to cpu_budget(): torch's intra-op pool (set directly), and —
+    through the environment, for libraries that read it when they start their pool — OpenMP (`OMP_NUM_THREADS`) and the Rust
+    tokenizer's rayon pool (`RAYON_NUM_THREADS`).  Values the user already exported are left alone.  Returns the budget.
+    Called by bench.py at start-up and by Retrieve before its tokenizer threads start; see cpu_budget for why."""
+    n = cpu_budget()
+    if n < (os.cpu_count() or n):
+        if "OMP_NUM_THREADS" not in os.environ and torch.get_num_threads() > n:
+            torch.set_num_threads(n)
+        os.environ.setdefault("OMP_NUM_THREADS", str(n))
+        os.environ.setdefault("RAYON_NUM_THREADS", str(n))
+    return n
+
+
 def chunk_sort_key(path):
     """The reference orders chunk files by the integer formed from every digit of the path."""
     return int(''.join(filter(str.isdigit, path)))

@@ -37,4 +37,27 @@ for pair in (1, 0, 1):
         t0 = time.perf_counter(); r = stage.search_rows(q, key, 50, "ip", n); t1 = time.perf_counter()
         wall.append((t1 - t0) * 1e3); kern.append(ix.counters()["total_ms"])
     print(f"stage.search_rows pair256={pair}: wall median {statistics.median(wall):8.3f} min {min(wall):8.3f} max {max(wall):8.3f}   kernels median {statistics.median(kern):8.3f}")
-print("loadavg", open("/proc/loadavg").read().strip(), "cpus", os.cpu_count())
+# what the 1.7 MB of result copies cost by themselves: fresh tensors (malloc / free every time) vs one preallocated pair
+s, i = ix.search(q, 50, host=True)
+pre = (torch.empty_like(s, pin_memory=False), torch.empty_like(i, pin_memory=False))
+for label in ("clone + free", "copy_ into preallocated"):
+    ts = []
+    keep = None
+    for _ in range(200):
+        t0 = time.perf_counter()
+        if label.startswith("clone"):
+            keep = (s.clone(), i.clone())
+        else:
+            pre[0].copy_(s); pre[1].copy_(i)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    print(f"{label:26s} median {ts[100]:7.3f}  p90 {ts[180]:7.3f}  p99 {ts[198]:7.3f}  max {ts[-1]:7.3f} ms")
+def _read(p):
+    try:
+        return open(p).read().strip().replace("\n", " | ")
+    except OSError as e:
+        return f"({e.__class__.__name__})"
+print("loadavg", open("/proc/loadavg").read().strip(), "cpus", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
+print("cgroup cpu.max", _read("/sys/fs/cgroup/cpu.max"), "| cpu.stat", _read("/sys/fs/cgroup/cpu.stat"))
+print("THP", _read("/sys/kernel/mm/transparent_hugepage/enabled"), "| defrag", _read("/sys/kernel/mm/transparent_hugepage/defrag"))
+print("MALLOC env", {k: v for k, v in os.environ.items() if k.startswith("MALLOC_")})

@@ -600,3 +600,29 @@ def test_map_doc_ids_reads_the_arrow_table():
     assert got[2] == want[2][:5] and got[4] == [] and got[0] == want[0]
     # anything with an 'id' column
     assert Retrieve._map_doc_ids({"id": ["a", "b", "c"]}, torch.tensor([[2, 0, -1]])) == [["c", "a"]]
+
+
+def test_cpu_budget_follows_the_cgroup_quota(tmp_path, monkeypatch):
+    """utils.cpu_budget: thread pools are sized for the CPUs the container may use (cgroup v2 cpu.max / v1 cfs quota), not for
+    os.cpu_count() — a 1-GPU MI355X pod shows 256 logical CPUs under a quota of 16 and throttles a process that spins on all."""
+    import os
+    from bergen_amd import utils
+    have = len(os.sched_getaffinity(0))
+    (tmp_path / "v2").mkdir()
+    (tmp_path / "v2" / "cpu.max").write_text("1600000 100000\n")
+    assert utils.cpu_budget(str(tmp_path / "v2")) == min(have, 16)
+    (tmp_path / "v2" / "cpu.max").write_text("max 100000\n")
+    assert utils.cpu_budget(str(tmp_path / "v2")) == have
+    (tmp_path / "v2" / "cpu.max").write_text("50000 100000\n")       # half a CPU: still one thread
+    assert utils.cpu_budget(str(tmp_path / "v2")) == 1
+    (tmp_path / "v1" / "cpu").mkdir(parents=True)
+    (tmp_path / "v1" / "cpu" / "cpu.cfs_quota_us").write_text("300000\n")
+    (tmp_path / "v1" / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert utils.cpu_budget(str(tmp_path / "v1")) == min(have, 3)
+    (tmp_path / "v1" / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")  # v1: no limit
+    assert utils.cpu_budget(str(tmp_path / "v1")) == have
+    assert utils.cpu_budget(str(tmp_path / "nothing-here")) == have
+    # fit_host_pools_to_cpu_budget leaves a user's explicit settings alone
+    monkeypatch.setenv("RAYON_NUM_THREADS", "5")
+    n = utils.fit_host_pools_to_cpu_budget()
+    assert n == utils.cpu_budget() and os.environ["RAYON_NUM_THREADS"] == "5"
