@@ -66,7 +66,8 @@ def parse_args():
                    help="also run Retrieve.retrieve on a reference-layout folder of --stage-rows documents (first call loads the folder); off by "
                         "default: its small launches of the headline kernel would blur the kernel's average in a rocprofv3 --stats run")
     p.add_argument("--stage-rows", type=int, default=2_100_000, help="documents of the Retrieve.retrieve-level leg")
-    p.add_argument("--cpu-sample-rows", type=int, default=1_050_000)
+    p.add_argument("--cpu-sample-rows", type=int, default=3_150_000,
+                   help="rows of the cpu_baseline sample (scaled linearly to --n-rows): ~5 s per pass on the 16 CPUs of a GPU pod, best of 3")
     p.add_argument("--cpu-sample-queries", type=int, default=1000)
     p.add_argument("--no-encoder", action="store_true", help="skip the passages-encoded/s leg")
     p.add_argument("--no-power-leg", action="store_true", help="skip the board power / shader clock sampling behind the timed region")

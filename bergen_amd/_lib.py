@@ -79,6 +79,8 @@ class bh_encoder_config(_Sized):
         ("ln_eps", ctypes.c_float),
         ("head_dim", ctypes.c_int32),
         ("position_offset", ctypes.c_int32),
+        ("rotary_theta", ctypes.c_float),
+        ("ffn_gated", ctypes.c_int32),
     ]
 
 
@@ -130,6 +132,8 @@ SYMBOLS = {
                                       _i32, _i32, ctypes.POINTER(ctypes.c_float)]),
     "bh_op_attention": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32]),
     "bh_op_layernorm": (ctypes.c_int, [_vp, _vp, _i64, _i32, ctypes.c_float, _vp, _vp]),
+    "bh_op_rotary": (ctypes.c_int, [_vp, _i64, _i32, _vp, ctypes.c_float, _i32]),
+    "bh_op_swiglu": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
     "bh_gemm_permlane_mode": (ctypes.c_int, []),
     "bh_sparse_create": (ctypes.c_int, [ctypes.POINTER(_vp), _i64, _i32]),
     "bh_sparse_upload_csr": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32]),

@@ -228,6 +228,26 @@ struct BhLnArgs {
 };
 hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t stream);
 
+// rotary positions (NomicBert; bh_encoder_config.rotary_theta): rows of [Q | K] rotated in place by their token index
+struct BhRotaryArgs {
+    _Float16* qk;          // [n_rows][2 * n_heads * 64]: n_heads query slices, then n_heads key slices, 64 dims each
+    const int* pos;        // [n_rows] token index of the row inside its sequence (alignment rows: 0 = identity)
+    const float* cos_sin;  // [max_pos][64]: 32 cosines, then 32 sines, of pos * theta^(-2j / 64)
+    long long n_rows;
+    int n_heads;
+    int max_pos;           // rows of the table (positions beyond it are clamped: the caller checks seq_len against it)
+};
+hipError_t bh_launch_rotary(const BhRotaryArgs& a, hipStream_t stream);
+
+// gated feed-forward (NomicBertMLP; bh_encoder_config.ffn_gated): out = silu(gate) * up
+struct BhSwigluArgs {
+    const _Float16* gu;  // [n_rows][2 f]: gate columns, then up columns
+    _Float16* out;       // [n_rows][f]
+    long long n_rows;
+    int f;               // multiple of 8
+};
+hipError_t bh_launch_swiglu(const BhSwigluArgs& a, hipStream_t stream);
+
 struct BhPoolArgs {
     const _Float16* x;  // [tokens][d]
     _Float16* out;      // [batch][d]

@@ -60,6 +60,8 @@ struct bh_encoder {
     int attn_short = 128;  // sequences up to this length use the 4-wave attention workgroups
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
+    BhDevBuf<_Float16> GU;       // gated feed-forward (cfg.ffn_gated): [rows][2 dff] = gate | up columns of ONE GEMM, folded into H by bh_swiglu_kernel
+    BhDevBuf<float> rot;         // rotary positions (cfg.rotary_theta > 0): [max_position][64] = 32 cosines | 32 sines per position
     BhDevBuf<float> POOLED;  // classification head: the pooler's output [batch][d]
     BhDevBuf<unsigned> SEG;  // SPLADE head: per (sequence, term) running max of relu(logit)
     // optional masked-LM head (BertOnlyMLMHead: transform dense + GELU + LayerNorm, decoder); SPLADE pooling (pool 3)
@@ -114,7 +116,8 @@ int build_slots(bh_encoder* e) {
     const size_t d = c.hidden, dff = c.intermediate;
     const size_t da = (size_t)c.n_heads * 64;  // attention width: heads padded to 64 dims (= d for 64-dim heads)
     size_t total = (size_t)c.vocab_size * d + (size_t)c.max_position * d + (size_t)c.type_vocab_size * d + 2 * d;
-    const size_t per_layer = 2 * da * d + 2 * da + da * d + da + d * da + d + 2 * d + dff * d + dff + d * dff + d + 2 * d;
+    const size_t f1 = c.ffn_gated ? 2 * dff : dff;  // rows of the first feed-forward weight (gated: gate rows, then up rows)
+    const size_t per_layer = 2 * da * d + 2 * da + da * d + da + d * da + d + 2 * d + f1 * d + f1 + d * dff + d + 2 * d;
     total += per_layer * c.n_layers;
     total += 64;
     BH_HIP_TRY(hipMalloc((void**)&e->arena, total * sizeof(_Float16)));
@@ -148,8 +151,8 @@ int build_slots(bh_encoder* e) {
         L.bo = take(d);
         L.ln1g = take(d);
         L.ln1b = take(d);
-        L.w1 = take(dff * d);
-        L.b1 = take(dff);
+        L.w1 = take(f1 * d);
+        L.b1 = take(f1);
         L.w2 = take(d * dff);
         L.b2 = take(d);
         L.ln2g = take(d);
@@ -165,8 +168,8 @@ int build_slots(bh_encoder* e) {
         S[pre + "attention.output.dense.bias"] = {L.bo, (int64_t)d};
         S[pre + "attention.output.LayerNorm.weight"] = {L.ln1g, (int64_t)d};
         S[pre + "attention.output.LayerNorm.bias"] = {L.ln1b, (int64_t)d};
-        S[pre + "intermediate.dense.weight"] = {L.w1, (int64_t)(dff * d)};
-        S[pre + "intermediate.dense.bias"] = {L.b1, (int64_t)dff};
+        S[pre + "intermediate.dense.weight"] = {L.w1, (int64_t)(f1 * d)};
+        S[pre + "intermediate.dense.bias"] = {L.b1, (int64_t)f1};
         S[pre + "output.dense.weight"] = {L.w2, (int64_t)(d * dff)};
         S[pre + "output.dense.bias"] = {L.b2, (int64_t)d};
         S[pre + "output.LayerNorm.weight"] = {L.ln2g, (int64_t)d};
@@ -271,7 +274,12 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
                        "head_dim 8..64, heads * 64 <= 2048", c.hidden, c.n_heads, hd);
     if (c.position_offset < 0 || c.position_offset >= c.max_position) return bh_fail(BH_EINVAL, "position_offset %d", c.position_offset);
     if (c.intermediate % 64 != 0) return bh_fail(BH_EUNSUPPORTED, "intermediate=%d must be a multiple of 64", c.intermediate);
-    if (c.activation != 0) return bh_fail(BH_EUNSUPPORTED, "activation %d unsupported (0 = erf-GELU)", c.activation);
+    if (c.ffn_gated != 0 && c.ffn_gated != 1) return bh_fail(BH_EINVAL, "ffn_gated %d (0 or 1)", c.ffn_gated);
+    if (c.activation != (c.ffn_gated ? 1 : 0))
+        return bh_fail(BH_EUNSUPPORTED, "activation %d with ffn_gated %d unsupported (0 = erf-GELU with a plain feed-forward, 1 = SiLU with a gated one)",
+                       c.activation, c.ffn_gated);
+    if (!(c.rotary_theta >= 0.f) || (c.rotary_theta > 0.f && c.rotary_theta < 1.f)) return bh_fail(BH_EINVAL, "rotary_theta %g (0 = off, else >= 1)", (double)c.rotary_theta);
+    if (c.rotary_theta > 0.f && hd != 64) return bh_fail(BH_EUNSUPPORTED, "rotary positions need 64-dim heads (head_dim %d)", hd);
     int dev = 0;
     BH_HIP_TRY(hipGetDevice(&dev));
     hipDeviceProp_t prop;
@@ -282,6 +290,20 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
     e->cfg = c;
     e->device = dev;
     int rc = build_slots(e);
+    if (rc == BH_OK && c.rotary_theta > 0.f) {
+        // cos / sin of position x theta^(-2j / 64), j < 32 (NomicBertRotaryEmbedding: inv_freq in fp32, the angle in fp32; here the
+        // angle in double, rounded once to fp32 — closer to the exact value than the fp32 product, which is what the oracle holds)
+        std::vector<float> tab((size_t)c.max_position * 64);
+        for (int p = 0; p < c.max_position; ++p)
+            for (int j = 0; j < 32; ++j) {
+                const double ang = (double)p * pow((double)c.rotary_theta, -2.0 * j / 64.0);
+                tab[(size_t)p * 64 + j] = (float)cos(ang);
+                tab[(size_t)p * 64 + 32 + j] = (float)sin(ang);
+            }
+        rc = e->rot.ensure(tab.size());
+        if (rc == BH_OK && hipMemcpy(e->rot.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = bh_fail(BH_EHIP, "rotary table upload failed");
+    }
     if (rc == BH_OK) {
         hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreate(&e->ev0);
@@ -315,6 +337,8 @@ void bh_encoder_destroy(bh_encoder* e) {
     e->VT.release();
     e->CTX.release();
     e->H.release();
+    e->GU.release();
+    e->rot.release();
     e->OUT.release();
     e->ibuf.release();
     e->seq_off.release();
@@ -651,6 +675,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if ((rc = e->VT.ensure(M * da))) return rc;
     if ((rc = e->CTX.ensure(M * da, /*zero_new=*/true, st))) return rc;  // rows between sequences are never written
     if ((rc = e->H.ensure(M * dff))) return rc;
+    if (c.ffn_gated && (rc = e->GU.ensure(M * 2 * dff))) return rc;
     if ((rc = e->ibuf.ensure(ib.size()))) return rc;
     if ((rc = e->seq_off.ensure(batch))) return rc;
     const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size
@@ -739,6 +764,16 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             return rc;
         if (fork) BH_HIP_TRY(hipEventRecord(evj, vs));
         if ((rc = gemm(e, Xp, d, L.wqk, d, QKp, 2 * da, rows, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
+        if (c.rotary_theta > 0.f) {  // rotary positions: queries and keys of this micro-batch's rows, in place, by their token index
+            BhRotaryArgs ra{};
+            ra.qk = QKp;
+            ra.pos = d_pos + r0;
+            ra.cos_sin = e->rot.p;
+            ra.n_rows = rows;
+            ra.n_heads = c.n_heads;
+            ra.max_pos = c.max_position;
+            BH_HIP_TRY(bh_launch_rotary(ra, ls));
+        }
         if (fork) BH_HIP_TRY(hipStreamWaitEvent(ls, evj, 0));
         BhAttnArgs aa{};
         aa.qk = e->QK.p;  // (the attention kernels address tokens by their absolute packed row: seq_off)
@@ -830,7 +865,16 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         la.beta = L.ln1b;
         BH_HIP_TRY(bh_launch_layernorm(la, ls));
         // FFN: H = GELU(X W1^T + b1);  Y = H W2^T + b2;  X = LN(Y + X)
-        if ((rc = gemm(e, Xp, d, L.w1, d, Hp, dff, rows, dff, d, L.b1, 1, nullptr, 0, 1, 0, ls))) return rc;
+        if (c.ffn_gated) {  // H = silu(X Wg^T + bg) * (X Wu^T + bu): ONE GEMM over the [gate; up] rows, then the fold
+            _Float16* GUp = e->GU.p + r0 * 2 * dff;
+            if ((rc = gemm(e, Xp, d, L.w1, d, GUp, 2 * dff, rows, 2 * dff, d, L.b1, 1, nullptr, 0, 0, 0, ls))) return rc;
+            BhSwigluArgs sa{};
+            sa.gu = GUp;
+            sa.out = Hp;
+            sa.n_rows = rows;
+            sa.f = dff;
+            BH_HIP_TRY(bh_launch_swiglu(sa, ls));
+        } else if ((rc = gemm(e, Xp, d, L.w1, d, Hp, dff, rows, dff, d, L.b1, 1, nullptr, 0, 1, 0, ls))) return rc;
         if ((rc = gemm(e, Hp, dff, L.w2, dff, Yp, d, rows, d, dff, L.b2, 1, nullptr, 0, 0, 0, ls))) return rc;
         la.gamma = L.ln2g;
         la.beta = L.ln2b;
@@ -936,9 +980,10 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     k.real_tokens = real_tokens;
     k.packed_rows = m_pad;
     k.forward_ms = ms;
-    // algorithmic flops over REAL tokens: per layer 8 T d^2 + 4 T d dff (projections) + 4 sum(len^2) d (attention)
+    // algorithmic flops over REAL tokens: per layer 8 T d^2 + 4 T d dff (projections; 6 T d dff with a gated feed-forward: gate,
+    // up and down) + 4 sum(len^2) d (attention)
     k.flops = (double)c.n_layers *
-              ((double)real_tokens * (8.0 * d * d + 4.0 * d * dff) + 4.0 * len_sq * d);
+              ((double)real_tokens * (8.0 * d * d + (c.ffn_gated ? 6.0 : 4.0) * d * dff) + 4.0 * len_sq * d);
     if (pool == 3) k.flops += (double)real_tokens * (2.0 * d * d + 2.0 * d * (double)c.vocab_size);
     return BH_OK;
 }
@@ -1026,6 +1071,46 @@ int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float 
     la.gamma = static_cast<const _Float16*>(gamma);
     la.beta = static_cast<const _Float16*>(beta);
     BH_HIP_TRY(bh_launch_layernorm(la, nullptr));
+    BH_HIP_TRY(hipStreamSynchronize(nullptr));
+    return BH_OK;
+}
+
+int bh_op_rotary(void* qk, int64_t n_rows, int32_t n_heads, const int32_t* pos_dev, float theta, int32_t max_pos) {
+    if (!qk || !pos_dev) return bh_fail(BH_EINVAL, "null buffer");
+    if (n_rows < 0 || n_heads <= 0 || n_heads > 32 || max_pos <= 0 || !(theta >= 1.f)) return bh_fail(BH_EINVAL, "bad sizes");
+    std::vector<float> tab((size_t)max_pos * 64);
+    for (int p = 0; p < max_pos; ++p)
+        for (int j = 0; j < 32; ++j) {
+            const double ang = (double)p * pow((double)theta, -2.0 * j / 64.0);
+            tab[(size_t)p * 64 + j] = (float)cos(ang);
+            tab[(size_t)p * 64 + 32 + j] = (float)sin(ang);
+        }
+    float* dev = nullptr;
+    BH_HIP_TRY(hipMalloc((void**)&dev, tab.size() * sizeof(float)));
+    hipError_t he = hipMemcpy(dev, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+    BhRotaryArgs ra{};
+    ra.qk = static_cast<_Float16*>(qk);
+    ra.pos = pos_dev;
+    ra.cos_sin = dev;
+    ra.n_rows = n_rows;
+    ra.n_heads = n_heads;
+    ra.max_pos = max_pos;
+    if (he == hipSuccess) he = bh_launch_rotary(ra, nullptr);
+    if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+    (void)hipFree(dev);
+    if (he != hipSuccess) return bh_fail(BH_EHIP, "rotary: %s", hipGetErrorString(he));
+    return BH_OK;
+}
+
+int bh_op_swiglu(const void* gu, void* out, int64_t n_rows, int32_t f) {
+    if (!gu || !out) return bh_fail(BH_EINVAL, "null buffer");
+    if (n_rows < 0 || f <= 0 || (f & 7)) return bh_fail(BH_EUNSUPPORTED, "f=%d (a positive multiple of 8)", f);
+    BhSwigluArgs sa{};
+    sa.gu = static_cast<const _Float16*>(gu);
+    sa.out = static_cast<_Float16*>(out);
+    sa.n_rows = n_rows;
+    sa.f = f;
+    BH_HIP_TRY(bh_launch_swiglu(sa, nullptr));
     BH_HIP_TRY(hipStreamSynchronize(nullptr));
     return BH_OK;
 }

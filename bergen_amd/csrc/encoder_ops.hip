@@ -10,6 +10,10 @@
 //                        the packed rows of each sequence, optional L2 normalisation, fp16 [B][d] out
 //   bh_unpack_kernel     packed rows -> padded [B][T][d] last_hidden_state (API compatibility: a stock
 //                        pooler / stock BERGEN Retrieve can consume it); padding positions are zero
+//   bh_rotary_kernel     rotary positions of NomicBert (transformers modeling_nomic_bert.py:150-181, apply_rotary_pos_emb with
+//                        rotate_half): every 64-dim head slice of a token's query and key, in place in the Q | K buffer
+//   bh_swiglu_kernel     gated feed-forward of NomicBert (NomicBertMLP.forward, :266-279): silu(gate) * up over the [gate | up]
+//                        output of ONE GEMM, fp32 math
 #include "bh_device.h"
 #include "bh_kernels.h"
 
@@ -281,6 +285,72 @@ hipError_t bh_launch_embed_ln(const BhEmbedArgs& a, hipStream_t st) {
 hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t st) {
     if (a.n_rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(bh_layernorm_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+// One thread = 8 consecutive dims j .. j + 7 (j < 32) of one head slice and their partners j + 32 ..: two 16-byte loads, the 8
+// angles' cosines and sines from the fp32 table (positions are token indices inside a sequence: the table has max_position
+// rows, built on the host in double precision), fp32 rotation, two 16-byte stores.  x1' = x1 cos - x2 sin, x2' = x2 cos + x1 sin.
+__global__ void __launch_bounds__(256) bh_rotary_kernel(BhRotaryArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = a.n_heads * 8;  // 2 * n_heads slices x 4 chunks of 8 pairs
+    const long long row = t / per_row;
+    if (row >= a.n_rows) return;
+    const int rem = (int)(t - row * per_row);
+    const int slice = rem >> 2, c = rem & 3;
+    int p = a.pos[row];
+    p = p < 0 ? 0 : (p >= a.max_pos ? a.max_pos - 1 : p);
+    _Float16* x = a.qk + (size_t)row * (size_t)(a.n_heads * 128) + (size_t)slice * 64 + c * 8;
+    const float* cs = a.cos_sin + (size_t)p * 64 + c * 8;
+    half8 x1 = *reinterpret_cast<const half8*>(x);
+    half8 x2 = *reinterpret_cast<const half8*>(x + 32);
+    const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(cs + 32), s1 = *reinterpret_cast<const float4*>(cs + 36);
+    const float co[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float si[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    half8 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a1 = (float)x1[e], a2 = (float)x2[e];
+        o1[e] = (_Float16)(a1 * co[e] - a2 * si[e]);
+        o2[e] = (_Float16)(a2 * co[e] + a1 * si[e]);
+    }
+    *reinterpret_cast<half8*>(x) = o1;
+    *reinterpret_cast<half8*>(x + 32) = o2;
+}
+
+// One thread = 8 consecutive columns: out = g / (1 + exp(-g)) * u  (v_exp_f32 of -g log2 e; |g| large: exp -> inf or 0, the
+// quotient -> 0 or g, both finite).
+__global__ void __launch_bounds__(256) bh_swiglu_kernel(BhSwigluArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = a.f >> 3;
+    const long long row = t / per_row;
+    if (row >= a.n_rows) return;
+    const int c = (int)(t - row * per_row);
+    const _Float16* g = a.gu + (size_t)row * (size_t)(2 * a.f) + (size_t)c * 8;
+    const half8 gv = *reinterpret_cast<const half8*>(g);
+    const half8 uv = *reinterpret_cast<const half8*>(g + a.f);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gf = (float)gv[e];
+        const float sig = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-gf * 1.4426950408889634f));
+        o[e] = (_Float16)(gf * sig * (float)uv[e]);
+    }
+    *reinterpret_cast<half8*>(a.out + (size_t)row * (size_t)a.f + (size_t)c * 8) = o;
+}
+
+hipError_t bh_launch_rotary(const BhRotaryArgs& a, hipStream_t st) {
+    if (a.n_rows <= 0) return hipSuccess;
+    if (a.n_heads <= 0 || a.max_pos <= 0 || !a.qk || !a.pos || !a.cos_sin) return hipErrorInvalidValue;
+    const long long n = a.n_rows * (long long)a.n_heads * 8;
+    hipLaunchKernelGGL(bh_rotary_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t bh_launch_swiglu(const BhSwigluArgs& a, hipStream_t st) {
+    if (a.n_rows <= 0) return hipSuccess;
+    if (a.f <= 0 || (a.f & 7) || !a.gu || !a.out) return hipErrorInvalidValue;
+    const long long n = a.n_rows * (long long)(a.f >> 3);
+    hipLaunchKernelGGL(bh_swiglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 hipError_t bh_launch_pool(const BhPoolArgs& a, hipStream_t st) {

@@ -44,7 +44,14 @@ def pool_mode_or_none(pooler):
         return None
 
 
-SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert", "deberta-v2")
+SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert", "deberta-v2", "nomic_bert")
+
+# NomicBert names (transformers modeling_nomic_bert.py: layers.<l>.self_attn / mlp / post_*_layernorm) -> BERT names; the gate and
+# up projections of the gated feed-forward become ONE tensor (canonical_state_dict)
+_NOMIC = ((".self_attn.q_proj.", ".attention.self.query."), (".self_attn.k_proj.", ".attention.self.key."),
+          (".self_attn.v_proj.", ".attention.self.value."), (".self_attn.o_proj.", ".attention.output.dense."),
+          (".post_attention_layernorm.", ".attention.output.LayerNorm."), (".mlp.down_proj.", ".output.dense."),
+          (".post_mlp_layernorm.", ".output.LayerNorm."))
 
 # DistilBERT names -> BERT names (same post-LN block, no token types, no pooler)
 _DISTIL = (("embeddings.word_embeddings.", "embeddings.word_embeddings."),
@@ -106,6 +113,24 @@ def canonical_config(config):
                  hidden_act=get("hidden_act", "gelu"), type_vocab_size=1, layer_norm_eps=get("layer_norm_eps", 1e-7),
                  position_offset=0, rel_span=int(get("position_buckets")),
                  max_relative_positions=max_rel if max_rel >= 1 else int(get("max_position_embeddings")))
+    elif mt == "nomic_bert":
+        # NomicBert (config/retriever/nomic-embed-text-v1.5.yaml; transformers modeling_nomic_bert.py): BERT's post-LN block with
+        # rotary positions instead of a position table, bias-free projections and a gated SiLU feed-forward
+        rope = get("rope_parameters") or {}
+        rope_get = rope.get if isinstance(rope, dict) else (lambda k, dflt=None: getattr(rope, k, dflt))
+        rtype = rope_get("rope_type", "default") or "default"
+        if rtype != "default":
+            raise ValueError(f"nomic_bert rope_type {rtype!r} (default only)")
+        theta = float(rope_get("rope_theta", None) or get("rope_theta", None) or get("rotary_emb_base", None) or 1000.0)
+        if str(get("hidden_act", "silu")) != "silu":
+            raise ValueError(f"nomic_bert hidden_act {get('hidden_act')!r} (silu only)")
+        hd_cfg = get("head_dim", None)
+        if hd_cfg not in (None, int(get("hidden_size")) // int(get("num_attention_heads"))):
+            raise ValueError(f"nomic_bert head_dim {hd_cfg} != hidden_size / num_attention_heads")
+        c = dict(hidden_size=get("hidden_size"), num_attention_heads=get("num_attention_heads"),
+                 num_hidden_layers=get("num_hidden_layers"), intermediate_size=get("intermediate_size"),
+                 hidden_act="silu", type_vocab_size=get("type_vocab_size", 2), layer_norm_eps=get("layer_norm_eps", 1e-12),
+                 position_offset=0, rotary_theta=theta, ffn_gated=1)
     elif mt == "distilbert":
         c = dict(hidden_size=get("dim"), num_attention_heads=get("n_heads"), num_hidden_layers=get("n_layers"),
                  intermediate_size=get("hidden_dim"), hidden_act=get("activation", "gelu"), type_vocab_size=1,
@@ -123,14 +148,14 @@ def canonical_config(config):
         if pet not in (None, "absolute"):
             raise ValueError(f"position_embedding_type {pet!r}")
     c.update(vocab_size=get("vocab_size"), max_position_embeddings=get("max_position_embeddings"), model_type=mt)
-    if c["hidden_act"] != "gelu":
+    if c["hidden_act"] != ("silu" if c.get("ffn_gated") else "gelu"):
         raise ValueError(f"hidden_act {c['hidden_act']!r} (erf-GELU only)")
     d, nh = int(c["hidden_size"]), int(c["num_attention_heads"])
     hd = d // max(1, nh)
     if d != nh * hd or hd % 8 != 0 or not 8 <= hd <= 64:
         raise ValueError(f"head dim {d / max(1, nh):g} (multiples of 8 up to 64)")
-    if mt == "deberta-v2" and hd != 64:
-        raise ValueError(f"deberta-v2 with head dim {hd} (64 only)")
+    if mt in ("deberta-v2", "nomic_bert") and hd != 64:
+        raise ValueError(f"{mt} with head dim {hd} (64 only)")
     if d % 64 != 0 or d > 2048 or nh * 64 > 2048:
         raise ValueError(f"hidden_size {d} with {nh} heads (multiple of 64, heads * 64 <= 2048)")
     c["head_dim"] = hd
@@ -144,7 +169,7 @@ def canonical_state_dict(cfg, state_dict):
     out = {}
     for name, t in state_dict.items():
         key = name
-        for pre in ("bert.", "distilbert.", "roberta.", "deberta.", "model."):
+        for pre in ("bert.", "distilbert.", "roberta.", "deberta.", "nomic_bert.", "model."):
             if key.startswith(pre):
                 key = key[len(pre):]
         if key.endswith("position_ids") or key.endswith("token_type_ids"):
@@ -157,6 +182,17 @@ def canonical_state_dict(cfg, state_dict):
                     break
             if key.startswith(("lm_predictions.", "mask_predictions.", "cls.")):
                 continue
+        elif mt == "nomic_bert":
+            if key.endswith("inv_freq"):
+                continue  # (the rotary frequencies are a function of theta: rebuilt in the library)
+            if key.startswith("layers."):
+                key = "encoder.layer." + key[len("layers."):]
+            for a, b in _NOMIC:
+                if a in key:
+                    key = key.replace(a, b)
+                    break
+            if key.startswith(("cls.", "classifier.", "pooler.")):
+                continue  # task heads of NomicBertFor*: the retriever reads the last hidden state (dense.py:40-44)
         elif mt == "distilbert":
             if key.startswith("transformer.layer."):
                 key = "encoder.layer." + key[len("transformer.layer."):]
@@ -177,6 +213,19 @@ def canonical_state_dict(cfg, state_dict):
         out[key] = t
     if mt == "distilbert" or "embeddings.token_type_embeddings.weight" not in out:
         out["embeddings.token_type_embeddings.weight"] = torch.zeros(int(cfg["type_vocab_size"]), d, dtype=torch.float16)
+    if mt == "nomic_bert":
+        # no position table (rotary), no biases: zeros where the BERT-shaped stack expects them; gate and up rows as one tensor
+        nl, f = int(cfg["num_hidden_layers"]), int(cfg["intermediate_size"])
+        out["embeddings.position_embeddings.weight"] = torch.zeros(int(cfg["max_position_embeddings"]), d, dtype=torch.float16)
+        for l in range(nl):
+            pre = f"encoder.layer.{l}."
+            gate, up = out.pop(pre + "mlp.gate_proj.weight", None), out.pop(pre + "mlp.up_proj.weight", None)
+            if gate is None or up is None:
+                raise ValueError(f"nomic_bert state dict lacks layers.{l}.mlp.gate_proj / up_proj")
+            out[pre + "intermediate.dense.weight"] = torch.cat([gate.detach().float(), up.detach().float()], dim=0)
+            for name, n in (("attention.self.query", d), ("attention.self.key", d), ("attention.self.value", d),
+                            ("attention.output.dense", d), ("intermediate.dense", 2 * f), ("output.dense", d)):
+                out.setdefault(pre + name + ".bias", torch.zeros(n, dtype=torch.float16))
     if mt == "deberta-v2":  # word embeddings only (position_biased_input = False): a zero position table
         out["embeddings.position_embeddings.weight"] = torch.zeros(int(cfg["max_position_embeddings"]), d, dtype=torch.float16)
         if "encoder.rel_embeddings.weight" in out:  # the attention uses the first 2 * position_buckets rows
@@ -225,8 +274,9 @@ class BertEncoder:
             n_layers=int(get("num_hidden_layers")), hidden=self.hidden_size, n_heads=int(get("num_attention_heads")),
             intermediate=int(get("intermediate_size")), vocab_size=int(get("vocab_size")),
             max_position=int(get("max_position_embeddings")), type_vocab_size=int(get("type_vocab_size")),
-            activation=0, ln_eps=float(get("layer_norm_eps", 1e-12)), head_dim=int(get("head_dim")),
-            position_offset=int(get("position_offset", 0)))
+            activation=1 if get("ffn_gated") else 0, ln_eps=float(get("layer_norm_eps", 1e-12)), head_dim=int(get("head_dim")),
+            position_offset=int(get("position_offset", 0)), rotary_theta=float(get("rotary_theta", 0.0) or 0.0),
+            ffn_gated=int(get("ffn_gated", 0) or 0))
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))
         self._h = h
@@ -249,7 +299,7 @@ class BertEncoder:
         classifier = {}
         for name, t in state_dict.items():
             key = name
-            for pre in ("bert.", "model."):
+            for pre in ("bert.", "nomic_bert.", "model."):
                 if key.startswith(pre):
                     key = key[len(pre):]
             if key.endswith("position_ids") or key.endswith("token_type_ids"):
@@ -432,6 +482,25 @@ def layernorm(x, gamma, beta, eps):
     out = torch.empty_like(x)
     torch.cuda.synchronize(x.device)
     _lib.check(_lib.lib().bh_op_layernorm(_p(x), _p(out), x.shape[0], x.shape[1], float(eps), _p(gamma), _p(beta)))
+    return out
+
+
+def rotary(qk, pos, n_heads, theta, max_pos=None):
+    """Rotary positions IN PLACE on packed [Q | K] rows: qk [rows, 2 * n_heads * 64] fp16, pos [rows] int32 (device tensors)."""
+    assert qk.is_cuda and pos.is_cuda and qk.dtype == torch.float16 and pos.dtype == torch.int32 and qk.is_contiguous()
+    assert qk.shape[1] == 2 * n_heads * 64 and pos.shape[0] == qk.shape[0]
+    torch.cuda.synchronize(qk.device)
+    _lib.check(_lib.lib().bh_op_rotary(_p(qk), qk.shape[0], n_heads, _p(pos), float(theta),
+                                       int(max_pos if max_pos is not None else int(pos.max().item()) + 1)))
+    return qk
+
+
+def swiglu(gu):
+    """silu(gate) * up over gu [rows, 2 f] fp16 (gate columns, then up columns) -> [rows, f] fp16."""
+    assert gu.is_cuda and gu.dtype == torch.float16 and gu.is_contiguous() and gu.shape[1] % 16 == 0
+    out = torch.empty((gu.shape[0], gu.shape[1] // 2), dtype=torch.float16, device=gu.device)
+    torch.cuda.synchronize(gu.device)
+    _lib.check(_lib.lib().bh_op_swiglu(_p(gu), _p(out), gu.shape[0], gu.shape[1] // 2))
     return out
 
 

@@ -33,7 +33,9 @@ extern "C" {
  * longer one gets zeros in the fields this build does not know); bh_counters grew the fall-back / tail-pass fields (they were
  * added under 130 without a bump: VERDICT r3); + bh_index_set_option / bh_sparse_set_option (per-handle options),
  * bh_encoder_set_rel_index (DeBERTa); 141 = 0.1.4.1 (round 4): bh_counters grew paired_scan_ms / paired_launches at its END (option
- * pair256); a caller built against 140 keeps working memory-wise (struct_size) but must be rebuilt to pass the version check. */
+ * pair256) and bh_encoder_config grew rotary_theta / ffn_gated at its END (NomicBert: rotary positions, gated SiLU feed-forward;
+ * a shorter struct reads as plain BERT) + bh_op_rotary / bh_op_swiglu; a caller built against 140 keeps working memory-wise
+ * (struct_size) but must be rebuilt to pass the version check. */
 #define BH_VERSION 141
 
 typedef enum bh_status {
@@ -196,7 +198,7 @@ typedef struct bh_encoder_config {
     int32_t vocab_size;
     int32_t max_position;    /* max_position_embeddings */
     int32_t type_vocab_size;
-    int32_t activation;      /* 0 = erf-GELU ("gelu") */
+    int32_t activation;      /* 0 = erf-GELU ("gelu"); 1 = SiLU, with ffn_gated = 1 only */
     float ln_eps;            /* layer_norm_eps */
     int32_t head_dim;        /* 0 or 64: hidden / n_heads = 64.  8..56 (e5-small, bge-small, MiniLM: 32): the attention kernel
                                 works on 64-wide heads, the CALLER stores query / key / value weights and biases zero-padded to
@@ -205,6 +207,16 @@ typedef struct bh_encoder_config {
                                 to 64 columns per head ([hidden, n_heads*64]) */
     int32_t position_offset; /* added to the token index to form the position id: 0 = BERT, padding_idx + 1 (= 2) = RoBERTa /
                                 XLM-R with right-padded inputs */
+    /* ---- since BH_VERSION 141 (a shorter struct reads as zeros here: plain BERT) ---- */
+    float rotary_theta;      /* 0: learned absolute positions (the position table is added to the embeddings).  > 0: rotary
+                                positions (NomicBert: transformers modeling_nomic_bert.py:95-181, theta 1000): after the Q | K
+                                projection every 64-dim head slice of a token's query and key is rotated by its token index t,
+                                x' = x cos + rotate_half(x) sin with angles t * theta^(-2j / 64), j < 32; the caller uploads a
+                                zero position table.  head_dim must be 64 */
+    int32_t ffn_gated;       /* 0: H = act(X W1^T + b1), W1 = [intermediate][hidden].  1 (activation 1 = SiLU): gated feed-forward
+                                H = silu(X Wg^T) * (X Wu^T) (NomicBertMLP, modeling_nomic_bert.py:266-279): the tensor
+                                "intermediate.dense.weight" holds the gate rows, then the up rows — [2 * intermediate][hidden] —,
+                                "intermediate.dense.bias" 2 * intermediate entries */
 } bh_encoder_config;
 
 typedef struct bh_encoder bh_encoder;
@@ -290,6 +302,11 @@ int bh_op_gemm_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void*
 int bh_op_attention(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, void* ctx, int64_t ldc,
                     const int64_t* seq_off_dev, const int32_t* seq_len_dev, int32_t batch,
                     int32_t n_heads, int32_t max_len);
+/* bh_op_rotary: rows of [Q | K] ([n_rows][2 * n_heads * 64] fp16, device) rotated IN PLACE by pos[row] (int32, device) — the
+ * rotate-half RoPE of bh_encoder_config.rotary_theta.  bh_op_swiglu: out[n_rows][f] = silu(gu[row][j]) * gu[row][f + j] over
+ * gu [n_rows][2 f] fp16 (device).  Kernel-level entry points for the parity tests, like the three around them. */
+int bh_op_rotary(void* qk, int64_t n_rows, int32_t n_heads, const int32_t* pos, float theta, int32_t max_pos);
+int bh_op_swiglu(const void* gu, void* out, int64_t n_rows, int32_t f);
 int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float eps, const void* gamma,
                     const void* beta);
 /* 0 / 1 = direction of v_permlane32_swap found on the device (diagnostic), -1 on failure. */

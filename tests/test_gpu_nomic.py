@@ -1,0 +1,117 @@
+"""GPU parity tests of the NomicBert path (config/retriever/nomic-embed-text-v1.5.yaml): rotary positions and the gated SiLU
+feed-forward on the HIP kernels, through the C ABI, against the fp64 oracle (oracle/nomic_oracle.py) and the golden fixture that
+HF NomicBertModel and the reference's own Dense produced (tests/golden/nomic_tiny.npz, oracle/make_golden_nomic.py).
+
+Floating point (fp16 storage, fp32 math); tolerances, written here:
+  rotary     |got - ref| <= 1e-3 * max|ref|    (one fp16 rounding of an fp32 rotation; angles from a table built in double)
+  swiglu     |got - ref| <= 2e-3 * |ref| + 1e-3
+  encoder    cosine(embedding, oracle) >= 0.999 and max-abs <= 3e-2 * max|ref|   (the encoder bound of DESIGN.md)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nomic_oracle
+
+import nomic_fixture
+from test_gpu_encoder import DEV, _check_embeddings, _native, h16
+from test_nomic_oracle import load_tiny
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rotary_kernel_matches_oracle():
+    from bergen_amd import encoder
+    rng = np.random.default_rng(5)
+    for n_heads, rows in ((2, 77), (12, 1000), (16, 333)):
+        qk = (rng.standard_normal((rows, 2 * n_heads * 64)) * 2).astype(np.float16)
+        pos = rng.integers(0, 2048, size=rows).astype(np.int32)
+        pos[:3] = (0, 1, 2047)
+        got = encoder.rotary(h16(qk), torch.from_numpy(pos).to(DEV), n_heads, 1000.0, max_pos=2048).float().cpu().numpy()
+        ref = nomic_oracle.rotary_ref(qk, pos, n_heads, 1000.0)
+        assert np.array_equal(got[0], qk[0].astype(np.float32))  # position 0 is the identity, bit for bit
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (n_heads, rows, np.abs(got - ref).max())
+
+
+def test_swiglu_kernel_matches_oracle():
+    from bergen_amd import encoder
+    rng = np.random.default_rng(6)
+    gu = (rng.standard_normal((515, 2 * 3072)) * 3).astype(np.float16)
+    gu[0, :8] = (-60000, -30, -11, 0, 11, 30, 60000, 1)  # the ends of the range: silu -> 0 or the identity, never NaN
+    got = encoder.swiglu(h16(gu)).float().cpu().numpy()
+    ref = nomic_oracle.swiglu_ref(gu)
+    assert np.isfinite(got[:, 8:]).all() and not np.isnan(got).any()
+    ok = np.isfinite(ref) & (np.abs(ref) < 60000)
+    assert (np.abs(got - ref)[ok] <= 2e-3 * np.abs(ref)[ok] + 1e-3).all(), np.abs(got - ref)[ok].max()
+
+
+def test_encoder_matches_hf_nomic_fixture():
+    """Hidden states of HF NomicBertModel and the reference's MeanPooler on them (CPU, fp32), 6 right-padded sequences."""
+    cfg, sd, z = load_tiny()
+    enc = _native(dict(cfg, model_type="nomic_bert"), sd)
+    ids, mask, types = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "token_type_ids"))
+    hidden = enc(input_ids=ids, attention_mask=mask, token_type_ids=types)[0]
+    m = z["attention_mask"] != 0
+    got = hidden.float().cpu().numpy()
+    assert got.shape == z["hf_hidden"].shape and np.all(got[~m] == 0)
+    _check_embeddings(hidden[torch.from_numpy(m).to(DEV)], z["hf_hidden"][m].astype(np.float64), "hidden states")
+    kw = {"input_ids": ids, "attention_mask": mask, "token_type_ids": types}
+    _check_embeddings(enc.encode_pooled(kw, "mean"), z["ref_mean"].astype(np.float64), "mean pooling")
+    # a sequence alone == inside the batch, bit for bit (rotary angles are by token index, not by packed row)
+    full = enc.encode_pooled(kw, "mean").cpu().numpy()
+    for b in (1, 3):
+        alone = enc.encode_pooled({k: v[b:b + 1] for k, v in kw.items()}, "mean").cpu().numpy()
+        assert np.array_equal(alone[0].view(np.uint16), full[b].view(np.uint16)), b
+    enc.close()
+
+
+def test_encoder_nomic_embed_shape_against_oracle():
+    """nomic-embed-text-v1.5's geometry (768 x 12 heads x 3072 gated, theta 1000) with 3 layers; 96 sequences of up to 300 tokens:
+    more than 8 192 packed rows, so the layer stack runs as two micro-batches on two streams (rotary rows offset per half) —
+    and once more as one, bit-identical."""
+    cfg = dict(vocab_size=3000, hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="silu", rope_theta=1000.0,
+               model_type="nomic_bert", rope_parameters={"rope_type": "default", "rope_theta": 1000.0})
+    sd = nomic_oracle.random_nomic(cfg, seed=41, scale=0.03)
+    sd = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    rng = np.random.default_rng(42)
+    B, T = 96, 300
+    lens = rng.integers(20, T + 1, size=B)
+    lens[:2] = (T, 1)
+    ids = rng.integers(5, cfg["vocab_size"], size=(B, T)).astype(np.int64)
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    got = enc.encode_pooled(kw, "mean")
+    assert enc.counters()["packed_rows"] >= 8192
+    check = [0, 1, 2, 47, 48, 95]  # (the oracle runs these sequences alone: padding does not change real tokens)
+    ref = np.stack([nomic_oracle.encode(sd, cfg, ids[b:b + 1, :lens[b]], mask[b:b + 1, :lens[b]])[0] for b in check])
+    cos, err = _check_embeddings(got[torch.tensor(check, device=DEV)], ref, "nomic-embed shape, mean pooling")
+    enc.set_option("micro_batches", 1)
+    one = enc.encode_pooled(kw, "mean")
+    assert torch.equal(one, got), "one micro-batch and two must agree bit for bit"
+    print(f"nomic-embed shape: cos {cos:.6f} err {err:.4g}")
+    enc.close()
+
+
+def test_dense_from_a_nomic_checkpoint_directory_matches_the_reference_dense(tmp_path):
+    """bergen_amd.Dense on the checkpoint directory the reference's Dense produced the fixture from (rebuilt from the stored
+    weights): AutoModel resolves to NomicBertModel, the plug-in puts it on the HIP path, and query / document embeddings of the
+    fixture's texts — prompts, tokenizer, mean pooling — agree with the reference's own fp32 pass; so do the cosine scores."""
+    import bergen_amd
+    cfg, sd, z = load_tiny()
+    ckpt = nomic_fixture.build_checkpoint(str(tmp_path / "ckpt"), sd, cfg, words=[str(w) for w in z["words"]])
+    dense = bergen_amd.Dense(model_name=ckpt, max_len=nomic_fixture.MAX_LEN, pooler=bergen_amd.MeanPooler(), similarity=bergen_amd.CosineSim(),
+                             prompt_q="search_query: ", prompt_d="search_document: ")
+    assert dense.backend == "hip", "the NomicBert checkpoint did not resolve to the hand-written forward pass"
+    embs = {}
+    for side, texts, field in (("doc", z["doc_texts"], "content"), ("query", z["query_texts"], "generated_query")):
+        batch = dense.collate_fn([{field: str(t)} for t in texts], side)
+        assert np.array_equal(batch["input_ids"].numpy(), z[f"ref_{side}_input_ids"]), side  # same prompts, same tokenizer
+        got = dense(side, batch)["embedding"]
+        embs[side] = got.float().cpu().numpy().astype(np.float64)
+        _check_embeddings(got, z[f"ref_{side}_emb_fp32"].astype(np.float64), f"{side} embeddings vs the reference's Dense")
+    q = embs["query"] / np.linalg.norm(embs["query"], axis=1, keepdims=True)
+    d = embs["doc"] / np.linalg.norm(embs["doc"], axis=1, keepdims=True)
+    assert np.abs(q @ d.T - z["ref_cosine_fp32"]).max() < 5e-3
+    assert np.array_equal(np.argmax(q @ d.T, axis=1), np.argmax(z["ref_cosine_fp32"], axis=1))
