@@ -266,17 +266,25 @@ def cpu_baseline(args, dim, k):
     }
 
 
-def encoder_leg(args, device_index):
+def encoder_leg(args, device_index, arch="bert"):
     """passages-encoded/s: the bi-encoder forward pass (BASELINE configs[1] encoder = RetroMAE = BERT-base
     architecture, CLS pooling) on a batch of synthetic passages (lengths ~ clipped-Normal(130, 30)
     in [16, 256], random token ids, seeded random-init weights — no checkpoint exists offline).  A step = one
     forward pass of --enc-batch passages, token ids on the host (as a tokenizer leaves them), embeddings left
     in HBM (where the index consumes them).  Roofline = MFMA: algorithmic flops over REAL tokens
-    (12 x (T x 14.16 MFLOP + 4 d sum len^2)) / forward time / 2.5 PFLOP/s."""
+    (12 x (T x 14.16 MFLOP + 4 d sum len^2)) / forward time / 2.5 PFLOP/s.
+    arch="nomic": the same batch through nomic-embed-text-v1.5's architecture (config/retriever/nomic-embed-text-v1.5.yaml:
+    NomicBert 12 x 768 x 12 heads, rotary positions, gated SiLU feed-forward of 3072 — 18.9 MFLOP of projections per token and
+    layer instead of 14.2 —, mean pooling); returned under "nomic_encode"."""
     from bergen_amd import BertEncoder, synth
     cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
-    sd = synth.random_bert(cfg, seed=31)
+    if arch == "nomic":
+        cfg.update(model_type="nomic_bert", hidden_act="silu", vocab_size=30528, max_position_embeddings=2048, rope_theta=1000.0)
+        sd = synth.random_nomic(cfg, seed=33, scale=0.02)
+    else:
+        sd = synth.random_bert(cfg, seed=31)
+    pooler = "mean" if arch == "nomic" else "cls"
     enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=device_index)
     rng = np.random.default_rng(6)
     lens = np.clip(np.rint(rng.normal(130, 30, size=args.enc_batch)), 16, 256).astype(np.int64)
@@ -284,12 +292,12 @@ def encoder_leg(args, device_index):
     mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
     ids = rng.integers(1, cfg["vocab_size"], size=(args.enc_batch, T)).astype(np.int64) * mask
     kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
-    enc.encode_pooled(kw, "cls")  # warm-up (workspace allocation, kernel attribute setup)
+    enc.encode_pooled(kw, pooler)  # warm-up (workspace allocation, kernel attribute setup)
     torch.cuda.synchronize()
     fwd_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.enc_steps):
-        emb = enc.encode_pooled(kw, "cls")
+        emb = enc.encode_pooled(kw, pooler)
         fwd_ms += enc.counters()["forward_ms"]
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -297,6 +305,14 @@ def encoder_leg(args, device_index):
     ok = bool(torch.isfinite(emb.float()).all()) and tuple(emb.shape) == (args.enc_batch, 768)
     enc.close()
     achieved = c["flops"] / (fwd_ms / args.enc_steps * 1e-3) / 1e12
+    if arch == "nomic":
+        return {"nomic_encode": {
+            "workload": f"NomicBert (12x768x12 heads, rotary positions, gated SiLU d_ff 3072) forward + mean pool, {args.enc_batch} synthetic "
+                        f"passages/step, {int(c['real_tokens'])} real tokens, fp16 storage / fp32 accumulate, random-init weights",
+            "passages_per_s": args.enc_batch * args.enc_steps / wall, "ms_per_step_kernels": fwd_ms / args.enc_steps,
+            "finite_and_shaped": ok,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "algorithmic_flops_per_step": c["flops"]}}}
     return {
         "passages_per_s": args.enc_batch * args.enc_steps / wall,
         "encoder": {"workload": f"BERT-base (12x768x12 heads, d_ff 3072) forward + CLS pool, {args.enc_batch} synthetic "
@@ -1370,6 +1386,7 @@ def run(args, env):
             ix.close()  # the search index is no longer needed: give the HBM back before the encoder leg
             try:
                 out.update(encoder_leg(args, local_rank))
+                out.update(encoder_leg(args, local_rank, arch="nomic"))
             except Exception as exc:
                 out["encoder_error"] = repr(exc)
         if not args.no_encoder and world == 1 and args.encode_stage_passages > 0:

@@ -114,20 +114,5 @@ def swiglu_ref(gu):
     return _silu(gu[:, :f]) * gu[:, f:]
 
 
-def random_nomic(cfg, seed=0, scale=0.05):
-    """Seeded random NomicBertModel state dict (HF names, float32): weights ~ N(0, scale), LayerNorm gains near 1."""
-    rng = np.random.default_rng(seed)
-    d, f = cfg["hidden_size"], cfg["intermediate_size"]
-    n = lambda *shape: (rng.standard_normal(shape) * scale).astype(np.float32)
-    g = lambda: (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32)
-    sd = {"embeddings.word_embeddings.weight": n(cfg["vocab_size"], d) * 4,
-          "embeddings.token_type_embeddings.weight": n(cfg["type_vocab_size"], d) * 4,
-          "embeddings.LayerNorm.weight": g(), "embeddings.LayerNorm.bias": n(d)}
-    for l in range(cfg["num_hidden_layers"]):
-        p = f"layers.{l}."
-        for name in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            sd[p + f"self_attn.{name}.weight"] = n(d, d) * 2
-        sd[p + "post_attention_layernorm.weight"], sd[p + "post_attention_layernorm.bias"] = g(), n(d)
-        sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = n(f, d) * 2, n(f, d) * 2, n(d, f)
-        sd[p + "post_mlp_layernorm.weight"], sd[p + "post_mlp_layernorm.bias"] = g(), n(d)
-    return sd
+# seeded synthetic weights live in the product package's bench helpers (no arithmetic of the path)
+from bergen_amd.synth import random_nomic  # noqa: E402,F401
