@@ -149,6 +149,7 @@ struct BhGemmArgs {
     int M, N, K;  // K % 64 == 0; lda, ldb, ldc, ldr % 8 == 0
     int bias_mode;
     int gelu;    // erf-GELU on the result
+    int swiglu;  // persistent kernel, whole 256 x 256 tiles, bias per column: columns are (gate, up) pairs, C is [M][N / 2] = silu(gate) * up
     int swap_b;  // filled by the launcher: direction of v_permlane32_swap on this device
     // segmented-max epilogue (persistent kernel, SPLADE head): C is not stored; relu(C + bias) is max-reduced over the
     // COLUMNS (packed tokens) of each sequence into seg_out[sequence][m] (uint32 view of non-negative floats, zeroed
@@ -241,7 +242,7 @@ hipError_t bh_launch_rotary(const BhRotaryArgs& a, hipStream_t stream);
 
 // gated feed-forward (NomicBertMLP; bh_encoder_config.ffn_gated): out = silu(gate) * up
 struct BhSwigluArgs {
-    const _Float16* gu;  // [n_rows][2 f]: gate columns, then up columns
+    const _Float16* gu;  // [n_rows][2 f]: (gate, up) pairs — column 2 j = gate j, column 2 j + 1 = up j
     _Float16* out;       // [n_rows][f]
     long long n_rows;
     int f;               // multiple of 8

@@ -60,7 +60,9 @@ struct bh_encoder {
     int attn_short = 128;  // sequences up to this length use the 4-wave attention workgroups
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
-    BhDevBuf<_Float16> GU;       // gated feed-forward (cfg.ffn_gated): [rows][2 dff] = gate | up columns of ONE GEMM, folded into H by bh_swiglu_kernel
+    BhDevBuf<_Float16> GU;       // gated feed-forward (cfg.ffn_gated), unfused form: [rows][2 dff] = (gate, up) column pairs of ONE GEMM, folded into H by bh_swiglu_kernel
+    int ffn_fused = 1;           // option "ffn_fused": the persistent GEMM folds the pairs in its epilogue where it applies (0: always GU + fold kernel)
+    int n_cu = 256;
     BhDevBuf<float> rot;         // rotary positions (cfg.rotary_theta > 0): [max_position][64] = 32 cosines | 32 sines per position
     BhDevBuf<float> POOLED;  // classification head: the pooler's output [batch][d]
     BhDevBuf<unsigned> SEG;  // SPLADE head: per (sequence, term) running max of relu(logit)
@@ -289,6 +291,7 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
     bh_encoder* e = new bh_encoder();
     e->cfg = c;
     e->device = dev;
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int rc = build_slots(e);
     if (rc == BH_OK && c.rotary_theta > 0.f) {
         // cos / sin of position x theta^(-2j / 64), j < 32 (NomicBertRotaryEmbedding: inv_freq in fp32, the angle in fp32; here the
@@ -463,6 +466,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
     if (std::string(name) == "attn_side_stream") {
         if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "attn_side_stream must be 0 or 1");
         e->attn_side_stream = (int)value;
+        return BH_OK;
+    }
+    if (std::string(name) == "ffn_fused") {
+        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "ffn_fused must be 0 or 1");
+        e->ffn_fused = (int)value;
         return BH_OK;
     }
     if (std::string(name) == "micro_batches") {
@@ -675,7 +683,18 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     if ((rc = e->VT.ensure(M * da))) return rc;
     if ((rc = e->CTX.ensure(M * da, /*zero_new=*/true, st))) return rc;  // rows between sequences are never written
     if ((rc = e->H.ensure(M * dff))) return rc;
-    if (c.ffn_gated && (rc = e->GU.ensure(M * 2 * dff))) return rc;
+    // Gated feed-forward: H = silu(X Wg^T + bg) * (X Wu^T + bu) from ONE GEMM over the interleaved (gate, up) weight rows.  Whole
+    // 256 x 256 tiles that fill more than half the chip: the persistent kernel folds the pairs in its epilogue (BH_EPI_SWIGLU) and
+    // the [rows][2 dff] intermediate never exists; else the plain GEMM into GU + the fold kernel (option "ffn_fused" 0 forces it).
+    auto ffn_fused = [&](long long rows) {
+        return e->ffn_fused && rows % 256 == 0 && (2 * dff) % 256 == 0 && e->gemm_variant == 0 &&
+               (rows / 256) * (2 * dff / 256) * 2 > (long long)e->n_cu;
+    };
+    if (c.ffn_gated) {
+        bool need_gu = false;
+        for (int m = 0; m < n_mb; ++m) need_gu = need_gu || !ffn_fused(row_split[m + 1] - row_split[m]);
+        if (need_gu && (rc = e->GU.ensure(M * 2 * dff))) return rc;
+    }
     if ((rc = e->ibuf.ensure(ib.size()))) return rc;
     if ((rc = e->seq_off.ensure(batch))) return rc;
     const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size
@@ -865,15 +884,32 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         la.beta = L.ln1b;
         BH_HIP_TRY(bh_launch_layernorm(la, ls));
         // FFN: H = GELU(X W1^T + b1);  Y = H W2^T + b2;  X = LN(Y + X)
-        if (c.ffn_gated) {  // H = silu(X Wg^T + bg) * (X Wu^T + bu): ONE GEMM over the [gate; up] rows, then the fold
-            _Float16* GUp = e->GU.p + r0 * 2 * dff;
-            if ((rc = gemm(e, Xp, d, L.w1, d, GUp, 2 * dff, rows, 2 * dff, d, L.b1, 1, nullptr, 0, 0, 0, ls))) return rc;
-            BhSwigluArgs sa{};
-            sa.gu = GUp;
-            sa.out = Hp;
-            sa.n_rows = rows;
-            sa.f = dff;
-            BH_HIP_TRY(bh_launch_swiglu(sa, ls));
+        if (c.ffn_gated) {
+            if (ffn_fused(rows)) {  // (see above the layer loop)
+                BhGemmArgs g{};
+                g.A = Xp;
+                g.lda = d;
+                g.B = L.w1;
+                g.ldb = d;
+                g.C = Hp;
+                g.ldc = dff;
+                g.bias = L.b1;
+                g.bias_mode = 1;
+                g.M = rows;
+                g.N = 2 * dff;
+                g.K = d;
+                g.swiglu = 1;
+                BH_HIP_TRY(bh_launch_gemm_f16(g, 0, ls));
+            } else {
+                _Float16* GUp = e->GU.p + r0 * 2 * dff;
+                if ((rc = gemm(e, Xp, d, L.w1, d, GUp, 2 * dff, rows, 2 * dff, d, L.b1, 1, nullptr, 0, 0, 0, ls))) return rc;
+                BhSwigluArgs sa{};
+                sa.gu = GUp;
+                sa.out = Hp;
+                sa.n_rows = rows;
+                sa.f = dff;
+                BH_HIP_TRY(bh_launch_swiglu(sa, ls));
+            }
         } else if ((rc = gemm(e, Xp, d, L.w1, d, Hp, dff, rows, dff, d, L.b1, 1, nullptr, 0, 1, 0, ls))) return rc;
         if ((rc = gemm(e, Hp, dff, L.w2, dff, Yp, d, rows, d, dff, L.b2, 1, nullptr, 0, 0, 0, ls))) return rc;
         la.gamma = L.ln2g;
@@ -1019,7 +1055,8 @@ int bh_op_gemm_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void*
     g.M = M;
     g.N = N;
     g.K = K;
-    g.gelu = gelu;
+    g.gelu = gelu == 1 ? 1 : 0;
+    g.swiglu = gelu == 2 ? 1 : 0;  // (the gated fold of the persistent kernel: see the header)
     if (repeats < 1) repeats = 1;
     hipEvent_t e0, e1;
     BH_HIP_TRY(hipEventCreate(&e0));

@@ -12,8 +12,8 @@
 //                        pooler / stock BERGEN Retrieve can consume it); padding positions are zero
 //   bh_rotary_kernel     rotary positions of NomicBert (transformers modeling_nomic_bert.py:150-181, apply_rotary_pos_emb with
 //                        rotate_half): every 64-dim head slice of a token's query and key, in place in the Q | K buffer
-//   bh_swiglu_kernel     gated feed-forward of NomicBert (NomicBertMLP.forward, :266-279): silu(gate) * up over the [gate | up]
-//                        output of ONE GEMM, fp32 math
+//   bh_swiglu_kernel     gated feed-forward of NomicBert (NomicBertMLP.forward, :266-279): silu(gate) * up over the interleaved
+//                        (gate, up) columns of ONE GEMM, fp32 math — the fallback of the GEMM's own fused fold (BH_EPI_SWIGLU)
 #include "bh_device.h"
 #include "bh_kernels.h"
 
@@ -318,23 +318,24 @@ __global__ void __launch_bounds__(256) bh_rotary_kernel(BhRotaryArgs a) {
     *reinterpret_cast<half8*>(x + 32) = o2;
 }
 
-// One thread = 8 consecutive columns: out = g / (1 + exp(-g)) * u  (v_exp_f32 of -g log2 e; |g| large: exp -> inf or 0, the
-// quotient -> 0 or g, both finite).
+// One thread = 8 output columns = 16 consecutive inputs (gate, up, gate, up, ...): out = g / (1 + exp(-g)) * u  (v_exp_f32 of
+// -g log2 e; |g| large: exp -> inf or 0, the quotient -> 0 or g, both finite).  The standalone form of the fold the persistent
+// GEMM does in its epilogue (BH_EPI_SWIGLU): used where that kernel does not apply (small or ragged problems).
 __global__ void __launch_bounds__(256) bh_swiglu_kernel(BhSwigluArgs a) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int per_row = a.f >> 3;
     const long long row = t / per_row;
     if (row >= a.n_rows) return;
     const int c = (int)(t - row * per_row);
-    const _Float16* g = a.gu + (size_t)row * (size_t)(2 * a.f) + (size_t)c * 8;
-    const half8 gv = *reinterpret_cast<const half8*>(g);
-    const half8 uv = *reinterpret_cast<const half8*>(g + a.f);
+    const _Float16* g = a.gu + (size_t)row * (size_t)(2 * a.f) + (size_t)c * 16;
+    const half8 lo = *reinterpret_cast<const half8*>(g);
+    const half8 hi = *reinterpret_cast<const half8*>(g + 8);
     half8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float gf = (float)gv[e];
-        const float sig = 1.0f / (1.0f + __builtin_amdgcn_exp2f(-gf * 1.4426950408889634f));
-        o[e] = (_Float16)(gf * sig * (float)uv[e]);
+    for (int e = 0; e < 4; ++e) {
+        const float g0 = (float)lo[2 * e], g1 = (float)hi[2 * e];
+        o[e] = (_Float16)(g0 / (1.0f + __builtin_amdgcn_exp2f(-g0 * 1.4426950408889634f)) * (float)lo[2 * e + 1]);
+        o[4 + e] = (_Float16)(g1 / (1.0f + __builtin_amdgcn_exp2f(-g1 * 1.4426950408889634f)) * (float)hi[2 * e + 1]);
     }
     *reinterpret_cast<half8*>(a.out + (size_t)row * (size_t)a.f + (size_t)c * 8) = o;
 }

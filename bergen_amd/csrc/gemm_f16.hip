@@ -156,6 +156,11 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
             return hipErrorInvalidValue;
         return bh_gemm_persist(a, BH_EPI_BIAS_ROW | BH_EPI_SEGMAX, 1, stream);
     }
+    if (a.swiglu) {  // gated feed-forward fold: whole 256x256 tiles on the persistent kernel, bias per (interleaved) column
+        if (a.M % 256 || a.N % 256 || a.residual || a.gelu || !(a.bias && a.bias_mode == 1) || a.c_block_rows || g_swap_b != 0)
+            return hipErrorInvalidValue;
+        return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 3, stream);  // (non-temporal burst, like the GELU output)
+    }
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);
     const bool auto_variant = variant == 0;

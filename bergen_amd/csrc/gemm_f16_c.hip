@@ -29,6 +29,9 @@ int n_cu() {
         case BH_EPI_BATCHED:                                                                                      \
             if (P == 1) return bh_gemm_launch_persist<BH_EPI_BATCHED, 1>(a, n_cu(), s);                           \
             break;                                                                                                \
+        case BH_EPI_BIAS_COL | BH_EPI_SWIGLU:                                                                     \
+            if (P == 3) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 3>(a, n_cu(), s);          \
+            break;                                                                                                \
     }                                                                                                             \
     return hipErrorNotSupported;
 

@@ -11,6 +11,9 @@
 #define BH_EPI_GELU 8      // erf-GELU
 #define BH_EPI_SEGMAX 16   // persistent kernel only: no store; relu + per-sequence max into seg_out (SPLADE head)
 #define BH_EPI_BATCHED 32  // persistent kernel only: a.batch problems of one shape in one launch (BhGemmArgs::batch_stride_*)
+#define BH_EPI_SWIGLU 64   // persistent kernel only: the N columns are (gate, up) PAIRS — weight rows interleaved g0, u0, g1, u1, ... —
+                           // and C [M][N / 2] (row stride ldc) = silu(gate) * up: the gated feed-forward of NomicBert folded in the
+                           // epilogue (a lane's 8 consecutive columns are 4 pairs -> one 8-byte store)
 
 namespace bh_gemm {
 

@@ -222,7 +222,8 @@ def canonical_state_dict(cfg, state_dict):
             gate, up = out.pop(pre + "mlp.gate_proj.weight", None), out.pop(pre + "mlp.up_proj.weight", None)
             if gate is None or up is None:
                 raise ValueError(f"nomic_bert state dict lacks layers.{l}.mlp.gate_proj / up_proj")
-            out[pre + "intermediate.dense.weight"] = torch.cat([gate.detach().float(), up.detach().float()], dim=0)
+            # rows interleaved (gate j, up j): one GEMM then yields (gate, up) column pairs, folded in its epilogue
+            out[pre + "intermediate.dense.weight"] = torch.stack([gate.detach().float(), up.detach().float()], dim=1).reshape(2 * f, d)
             for name, n in (("attention.self.query", d), ("attention.self.key", d), ("attention.self.value", d),
                             ("attention.output.dense", d), ("intermediate.dense", 2 * f), ("output.dense", d)):
                 out.setdefault(pre + name + ".bias", torch.zeros(n, dtype=torch.float16))
@@ -450,12 +451,15 @@ def _p(t):
 
 
 def gemm_f16(a, w, bias=None, bias_mode=1, residual=None, gelu=False, variant=0, out=None, repeats=1):
-    """out[M, N] = a[M, K] @ w[N, K]^T (+bias) (+residual) (GELU) on the HIP kernel.  Returns (out, avg_ms)."""
+    """out[M, N] = a[M, K] @ w[N, K]^T (+bias) (+residual) (GELU) on the HIP kernel.  Returns (out, avg_ms).
+    gelu="swiglu": w's rows are (gate, up) pairs and out is [M, N / 2] = silu(gate) * up (the gated fold of the persistent kernel)."""
     assert a.is_cuda and w.is_cuda and a.dtype == torch.float16 and w.dtype == torch.float16
     M, K = a.shape
     N = w.shape[0]
+    fold = gelu == "swiglu"
+    gelu = 2 if fold else int(bool(gelu))
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float16, device=a.device)
+        out = torch.empty((M, N // 2 if fold else N), dtype=torch.float16, device=a.device)
     ms = ctypes.c_float(0)
     torch.cuda.synchronize(a.device)
     _lib.check(_lib.lib().bh_op_gemm_f16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), _p(bias),
@@ -496,7 +500,7 @@ def rotary(qk, pos, n_heads, theta, max_pos=None):
 
 
 def swiglu(gu):
-    """silu(gate) * up over gu [rows, 2 f] fp16 (gate columns, then up columns) -> [rows, f] fp16."""
+    """silu(gate) * up over gu [rows, 2 f] fp16 ((gate, up) column pairs: 2 j, 2 j + 1) -> [rows, f] fp16."""
     assert gu.is_cuda and gu.dtype == torch.float16 and gu.is_contiguous() and gu.shape[1] % 16 == 0
     out = torch.empty((gu.shape[0], gu.shape[1] // 2), dtype=torch.float16, device=gu.device)
     torch.cuda.synchronize(gu.device)

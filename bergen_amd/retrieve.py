@@ -119,6 +119,10 @@ class Retrieve:
         # instantiate model (reference: hydra instantiate, retrieve.py:34).  rag.py hands over an OmegaConf DictConfig;
         # config.instantiate converts that (and any other mapping) and passes an already-built plug-in object through
         self.model = instantiate(init_args)
+        # host-side thread pools (torch intra-op, OpenMP, the tokenizer's rayon pool) follow the container's CPU quota, not the host's
+        # CPU count (utils.cpu_budget: a GPU pod that shows 256 CPUs under a quota of 16 gets frozen by the CFS throttle otherwise);
+        # explicit OMP_NUM_THREADS / RAYON_NUM_THREADS settings of the user win
+        self.cpu_budget = utils.fit_host_pools_to_cpu_budget()
         self._resident = {}  # doc_embeds_path -> (FlatIndex, signature)
         self._searchers = {}
 

@@ -215,8 +215,9 @@ typedef struct bh_encoder_config {
                                 zero position table.  head_dim must be 64 */
     int32_t ffn_gated;       /* 0: H = act(X W1^T + b1), W1 = [intermediate][hidden].  1 (activation 1 = SiLU): gated feed-forward
                                 H = silu(X Wg^T) * (X Wu^T) (NomicBertMLP, modeling_nomic_bert.py:266-279): the tensor
-                                "intermediate.dense.weight" holds the gate rows, then the up rows — [2 * intermediate][hidden] —,
-                                "intermediate.dense.bias" 2 * intermediate entries */
+                                "intermediate.dense.weight" holds gate and up rows INTERLEAVED — row 2 j = gate row j, row
+                                2 j + 1 = up row j, [2 * intermediate][hidden] —, "intermediate.dense.bias" likewise (2 *
+                                intermediate entries): one GEMM yields (gate, up) column pairs, which the GEMM's epilogue folds */
 } bh_encoder_config;
 
 typedef struct bh_encoder bh_encoder;
@@ -294,6 +295,8 @@ void bh_encoder_destroy(bh_encoder* enc);
  * bh_op_gemm_f16: C[M][N] = A[M][K] . B[N][K]^T (+bias: mode 1 per column [N], 2 per row [M])
  * (+residual[M][N]) (erf-GELU), fp16 in/out, fp32 accumulate; K % 64 == 0, ld* % 8 == 0.
  * repeats > 1 times the launches after the first (avg_ms, HIP events on the null stream). */
+/* (gelu = 2: the gated fold instead — B's rows are (gate, up) pairs, C is [M][N / 2] = silu(gate) * up; M, N multiples of 256,
+ * bias per column required) */
 int bh_op_gemm_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                    const void* bias, int32_t bias_mode, const void* residual, int64_t ldr, int32_t M,
                    int32_t N, int32_t K, int32_t gelu, int32_t variant, int32_t repeats, float* avg_ms);
@@ -303,8 +306,8 @@ int bh_op_attention(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, 
                     const int64_t* seq_off_dev, const int32_t* seq_len_dev, int32_t batch,
                     int32_t n_heads, int32_t max_len);
 /* bh_op_rotary: rows of [Q | K] ([n_rows][2 * n_heads * 64] fp16, device) rotated IN PLACE by pos[row] (int32, device) — the
- * rotate-half RoPE of bh_encoder_config.rotary_theta.  bh_op_swiglu: out[n_rows][f] = silu(gu[row][j]) * gu[row][f + j] over
- * gu [n_rows][2 f] fp16 (device).  Kernel-level entry points for the parity tests, like the three around them. */
+ * rotate-half RoPE of bh_encoder_config.rotary_theta.  bh_op_swiglu: out[n_rows][f] = silu(gu[row][2 j]) * gu[row][2 j + 1] over
+ * gu [n_rows][2 f] fp16 (device; (gate, up) column pairs).  Kernel-level entry points for the parity tests, like the three around them. */
 int bh_op_rotary(void* qk, int64_t n_rows, int32_t n_heads, const int32_t* pos, float theta, int32_t max_pos);
 int bh_op_swiglu(const void* gu, void* out, int64_t n_rows, int32_t f);
 int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float eps, const void* gamma,

@@ -108,10 +108,9 @@ def rotary_ref(qk, pos, n_heads, theta):
 
 
 def swiglu_ref(gu):
-    """fp64 reference of bh_op_swiglu: [rows][2 dff] (gate | up) -> silu(gate) * up [rows][dff]."""
+    """fp64 reference of bh_op_swiglu: [rows][2 dff] of (gate, up) column PAIRS -> silu(gate) * up [rows][dff]."""
     gu = np.asarray(gu, np.float64)
-    f = gu.shape[1] // 2
-    return _silu(gu[:, :f]) * gu[:, f:]
+    return _silu(gu[:, 0::2]) * gu[:, 1::2]
 
 
 # seeded synthetic weights live in the product package's bench helpers (no arithmetic of the path)

@@ -37,12 +37,36 @@ def test_swiglu_kernel_matches_oracle():
     from bergen_amd import encoder
     rng = np.random.default_rng(6)
     gu = (rng.standard_normal((515, 2 * 3072)) * 3).astype(np.float16)
-    gu[0, :8] = (-60000, -30, -11, 0, 11, 30, 60000, 1)  # the ends of the range: silu -> 0 or the identity, never NaN
+    gu[0, 0:16:2] = (-60000, -30, -11, 0, 11, 30, 60000, 1)  # gates at the ends of the range: silu -> 0 or the identity, never NaN
+    gu[0, 1:16:2] = 1
     got = encoder.swiglu(h16(gu)).float().cpu().numpy()
     ref = nomic_oracle.swiglu_ref(gu)
     assert np.isfinite(got[:, 8:]).all() and not np.isnan(got).any()
     ok = np.isfinite(ref) & (np.abs(ref) < 60000)
     assert (np.abs(got - ref)[ok] <= 2e-3 * np.abs(ref)[ok] + 1e-3).all(), np.abs(got - ref)[ok].max()
+
+
+def test_gemm_with_the_gated_fold_in_its_epilogue_matches_oracle():
+    """BH_EPI_SWIGLU of the persistent GEMM: weight rows are (gate, up) pairs, the epilogue writes silu(gate) * up — [M][N / 2] —
+    and the [M][N] product never exists.  Against the fp64 product folded by the oracle, and against the unfused pair of kernels
+    (plain GEMM, then bh_swiglu_kernel) on the same operands: the fused form rounds once (fp32 product -> fold -> fp16), the
+    unfused one twice, so the two agree to fp16 round-off, not bit for bit."""
+    from bergen_amd import encoder
+    from oracle import bert_oracle
+    rng = np.random.default_rng(8)
+    for (M, N, K) in ((512, 512, 128), (1024, 6144, 768), (2304, 1024, 192)):
+        a = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+        w = (rng.standard_normal((N, K)) * 0.2).astype(np.float16)
+        b = (rng.standard_normal(N) * 0.5).astype(np.float16)
+        out, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(b), gelu="swiglu")
+        assert tuple(out.shape) == (M, N // 2)
+        ref = nomic_oracle.swiglu_ref(bert_oracle.gemm_ref(a, w, b, 1))
+        got = out.float().cpu().numpy().astype(np.float64)
+        rms = float(np.sqrt((ref ** 2).mean()))
+        assert (np.abs(got - ref) <= 2e-3 * np.abs(ref) + 2e-3 * rms).all(), (M, N, K, np.abs(got - ref).max(), rms)
+        plain, _ = encoder.gemm_f16(h16(a), h16(w), bias=h16(b))
+        two_step = encoder.swiglu(plain).float().cpu().numpy()
+        assert np.abs(two_step - got).max() <= 4e-3 * np.abs(ref).max() + 1e-3
 
 
 def test_encoder_matches_hf_nomic_fixture():
@@ -90,7 +114,11 @@ def test_encoder_nomic_embed_shape_against_oracle():
     enc.set_option("micro_batches", 1)
     one = enc.encode_pooled(kw, "mean")
     assert torch.equal(one, got), "one micro-batch and two must agree bit for bit"
-    print(f"nomic-embed shape: cos {cos:.6f} err {err:.4g}")
+    # the unfused feed-forward (plain GEMM into [rows][2 dff] + the fold kernel: what small batches run) meets the same bound
+    enc.set_option("ffn_fused", 0)
+    unfused = enc.encode_pooled(kw, "mean")
+    cos_u, err_u = _check_embeddings(unfused[torch.tensor(check, device=DEV)], ref, "nomic-embed shape, unfused feed-forward")
+    print(f"nomic-embed shape: fused cos {cos:.6f} err {err:.4g}; unfused cos {cos_u:.6f} err {err_u:.4g}")
     enc.close()
 
 

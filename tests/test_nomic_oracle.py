@@ -72,7 +72,7 @@ def test_padding_does_not_change_real_tokens():
 def test_op_references():
     rng = np.random.default_rng(1)
     gu = rng.standard_normal((5, 16))
-    want = gu[:, :8] / (1 + np.exp(-gu[:, :8])) * gu[:, 8:]
+    want = gu[:, 0::2] / (1 + np.exp(-gu[:, 0::2])) * gu[:, 1::2]  # (gate, up) column pairs
     assert np.allclose(nomic_oracle.swiglu_ref(gu), want)
     qk = rng.standard_normal((3, 2 * 2 * 64))
     pos = np.array([0, 5, 9])
