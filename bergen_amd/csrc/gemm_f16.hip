@@ -36,7 +36,12 @@ __global__ void bh_permlane_probe_kernel(unsigned* out) {
 namespace {
 int g_swap_b = -1;  // -1 unknown, 0 documented direction, 1 the other one
 int g_stagger_phases = 0, g_stagger_pct = 100;  // bench knobs (bh_set_option "gemm_stagger_phases" / "_pct")
+int g_full_line_stores = 1;  // bh_set_option "gemm_full_line_stores" (default on): the persistent kernel's row-major outputs leave as whole
+                             // 128-byte lines through LDS (gemm_f16_persist.h PST bit 32) — bit-identical, BERT-base forward 15.60 -> 14.55 ms
+                             // per 512 passages in the same process (profiles/r04t_ab_full_line_stores.txt)
 }
+
+void bh_gemm_set_full_line_stores(int on) { g_full_line_stores = on != 0; }
 
 void bh_gemm_set_stagger(int phases, int pct) {
     if (phases >= 0) g_stagger_phases = phases;
@@ -190,6 +195,9 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         if (epi & BH_EPI_RESIDUAL) return bh_gemm_generic(a, epi, stream);  // (the encoder adds residuals in LayerNorm)
         variant = 5;  // same tile geometry
     }
+    int pst_eff = pst;
+    if (persist && g_full_line_stores && !a.c_block_rows && (pst == 1 || pst == 3) && (epi == 0 || epi == BH_EPI_BIAS_COL || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU)))
+        pst_eff = pst | 32;
     if (variant < 1 || variant > 5) return hipErrorInvalidValue;
     // interior region with the fast kernel, edge strips with the generic one
     const int bm = kTile[variant].bm, bn = kTile[variant].bn;
@@ -230,10 +238,10 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
                     r.C = t.C + t.N;
                 if (t.bias && t.bias_mode == 1) r.bias = t.bias + t.N;
             }
-            if ((e = bh_gemm_persist(t, epi, pst, stream)) != hipSuccess) return e;
+            if ((e = bh_gemm_persist(t, epi, pst_eff, stream)) != hipSuccess) return e;
             if ((e = run_cfg(1, r, epi, stream)) != hipSuccess) return e;
         } else {
-            e = persist ? bh_gemm_persist(t, epi, pst, stream) : run_cfg(variant, t, epi, stream);
+            e = persist ? bh_gemm_persist(t, epi, pst_eff, stream) : run_cfg(variant, t, epi, stream);
             if (e != hipSuccess) return e;
         }
     }

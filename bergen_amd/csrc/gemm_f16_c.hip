@@ -39,6 +39,8 @@ hipError_t bh_gemm_persist(const BhGemmArgs& a, int epi, int pst, hipStream_t s)
     if (pst == 1) { BH_PERSIST_EPI(1) }
     if (pst == 0) { BH_PERSIST_EPI(0) }
     if (pst == 3) { BH_PERSIST_EPI(3) }
+    if (pst == 33) { BH_PERSIST_EPI(33) }  // 1 + full-line stores through LDS (gemm_f16_persist.h PST bit 32)
+    if (pst == 35) { BH_PERSIST_EPI(35) }  // 3 + the same
     if (pst == 16) { BH_PERSIST_EPI(16) }  // deferred stores + alternating loader teams (needs an even number of stages >= 8)
     if (pst == 5) { BH_PERSIST_EPI(5) }  // bench-only: math, no stores
     if (pst == 9) { BH_PERSIST_EPI(9) }  // bench-only: no epilogue

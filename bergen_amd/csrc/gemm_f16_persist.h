@@ -20,6 +20,11 @@
 // every stage hand-over wait for store acknowledgements); 0 = stores deferred two per stage into the next tile's
 // main loop (kept as an ablation); 2 = non-temporal stores; 4 / 8 = bench-only (results invalid): epilogue math
 // without its stores / no epilogue at all.
+// PST bit 32 (with bit 1 set; row-major C only) = FULL-LINE STORES: a lane leaves the MFMA layout with 8 consecutive columns of ONE
+// row, so a burst store instruction touches 32 rows with 32 bytes each — 32 partial cache lines.  Here every wave passes each
+// 32-row x 64-column part of its output through 4 KiB of LDS of its own (the 32 KiB the ring leaves free; 16-byte chunks XORed with
+// the row: conflict-free both ways; no barrier, a wave's LDS instructions execute in order) and stores it back out as 8 rows x 128
+// bytes per instruction: whole lines.  Same values, same bits.
 // PST bit 16 (with bit 1 clear) = ALTERNATING LOADER TEAMS: the eight waves form two teams of four (one wave per SIMD each);
 // in even stages team 0 issues the WHOLE stage refill (16 LDS-DMA instructions per wave) and team 1 issues four of its
 // deferred stores, in odd stages the roles swap.  Why: the stage hand-over needs "my LDS-DMA loads have landed" =
@@ -332,6 +337,61 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                 bias_row[tm] = 0.f;
                 if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) bias_row[tm] = (float)a.bias[m0 + (wm * TM + tm) * 32 + ql];
             }
+            if constexpr ((PST & 32) != 0) {
+                static_assert((PST & 32) == 0 || ((PST & 1) != 0 && (EPI & (BH_EPI_SEGMAX | BH_EPI_SWIGLU)) == 0), "full-line stores: burst, plain outputs");
+                unsigned char* stg = smem + R * STAGE_BYTES + wave * 4096;  // this wave's 32 rows x 128 bytes
+                half8 bb[TN][2];
+                if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            bb[tn][u] = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
+                }
+                (void)bb;
+                const int rrow = lane >> 3, rch = lane & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
+                _Float16* gptr = c_base + (size_t)(m0 + wm * TM * 32 + rrow) * a.ldc + n0 + wn * TN * 32 + rch * 8;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        floatx16 c = acc[tm][tn];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * u + e]),
+                                                                          __float_as_uint(c[8 * u + 4 + e]), false, false);
+                                c[8 * u + e] = __uint_as_float(r[0]);
+                                c[8 * u + 4 + e] = __uint_as_float(r[1]);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            half8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float v = c[8 * u + e] + bias_row[tm];
+                                if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)bb[tn][u][e];
+                                if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
+                                o[e] = (_Float16)v;
+                            }
+                            const int chunk = tn * 4 + u * 2 + h;  // the lane's 8 columns inside the row's 64
+                            *reinterpret_cast<half8*>(stg + ql * 128 + ((chunk ^ (ql & 7)) << 4)) = o;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own writes; no other wave touches stg)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ rrow) << 4));
+                        half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tm * 32 + 8 * i) * a.ldc);
+                        if constexpr ((PST & 2) != 0)
+                            __builtin_nontemporal_store(v, p);
+                        else
+                            *p = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads have landed before the next part overwrites stg)
+                }
+            } else
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 half8 b8[2];
@@ -445,7 +505,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
 
 template <int EPI, int PST = 0>
 hipError_t bh_gemm_launch_persist(const BhGemmArgs& a, int n_cu, hipStream_t stream) {
-    constexpr size_t smem = 2 * 16 * 4096;  // ring 2 x (8 + 8) pieces
+    constexpr size_t smem = 2 * 16 * 4096 + ((PST & 32) != 0 ? 8 * 4096 : 0);  // ring 2 x (8 + 8) pieces (+ 4 KiB per wave: full-line stores)
     auto kern = bh_gemm_f16_pkernel<EPI, PST>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -24,7 +24,11 @@ kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mas
 res, outs = {v0: [], v1: []}, {}
 for r in range(13):
     for v in (v0, v1):
-        enc.set_option(opt, v)
+        if opt.startswith("gemm_"):  # process-wide GEMM options (bh_set_option)
+            from bergen_amd import _lib
+            _lib.set_option(opt, v)
+        else:
+            enc.set_option(opt, v)
         out = enc.encode_pooled(kw, "mean" if nomic else "cls")
         if r:
             res[v].append(enc.counters()["forward_ms"])

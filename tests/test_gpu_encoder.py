@@ -92,6 +92,30 @@ def test_gemm_persistent_many_tiles_per_block():
                 assert_gemm_close(out, ref, f"persistent v{variant} {M}x{N}x{K} {sorted(kw)}")
 
 
+def test_gemm_full_line_stores_are_bit_identical():
+    """Option gemm_full_line_stores (gemm_f16_persist.h PST bit 32): the persistent kernel's outputs pass through a wave-private
+    LDS buffer and leave as whole 128-byte lines (8 rows per store instruction) instead of 32-byte pieces of 32 rows.  Only the
+    route changes: every epilogue it covers must give the same bits as the direct stores, over shapes with several tiles per
+    workgroup, ragged edges (handled by the other kernels) and K from one stage to 48."""
+    from bergen_amd import _lib, encoder
+    rng = np.random.default_rng(35)
+    try:
+        for (M, N, K) in [(2048, 1024, 64), (4096 + 256, 3072, 768), (1024, 768, 3072), (2560 + 40, 1536 + 24, 192)]:
+            a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
+            bc = rnd16(rng, N)
+            for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)), (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
+                            (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
+                outs = []
+                for on in (0, 1, 1):
+                    _lib.set_option("gemm_full_line_stores", on)
+                    out, _ = encoder.gemm_f16(h16(a), h16(w), **kw)
+                    outs.append(out.clone())
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), f"{M}x{N}x{K} {sorted(kw)}"
+                assert_gemm_close(outs[1], ref, f"full-line stores {M}x{N}x{K} {sorted(kw)}")
+    finally:
+        _lib.set_option("gemm_full_line_stores", 0)
+
+
 def test_gemm_alternating_loader_teams():
     """Variant 33 (gemm_f16_persist.h PST 16): deferred stores with the two four-wave teams of a workgroup alternating
     between refilling the LDS ring and storing — a wave skips the vmcnt wait of a stage it did not load in.  Several tiles per
