@@ -41,7 +41,10 @@ __device__ __forceinline__ float half_lanes_sum(float v) {
 
 // NWV = waves per workgroup: 8 in general, 4 for sequences of at most 128 tokens (half the LDS, twice the
 // workgroups per CU, no idle waves behind the staging barrier).
-template <int NWV>
+// WIDE: the context rows leave as 16-byte stores (two neighbouring 4-column groups joined by one half-lane exchange: a store
+// instruction then covers 32 bytes of each of its 32 rows instead of 16 — the same lesson as the GEMM's output path: the
+// memory system pays per row piece, not per byte); needs the documented direction of v_permlane32_swap (probed by the GEMM).
+template <int NWV, bool WIDE>
 __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NWV;
@@ -216,7 +219,40 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
             }
     }
     const float inv = 1.0f / half_lanes_sum(l_run);
-    if (q0 + ql < len) {
+    if constexpr (WIDE) {
+        // lane (ql, h) holds columns 8 gq + 4 h + 0..3 of every 8-column group gq of a 32-column half dt.  Groups 2 gp and 2 gp + 1:
+        // the lower half-lane hands its part of group 2 gp + 1 to the upper one and takes the upper one's part of group 2 gp ->
+        // lane h owns the 8 consecutive columns 16 gp + 8 h + 0..7.  (Executed by all lanes: the exchange is outside the branch.)
+        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+        typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+        uint4v outv[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                half4 wa, wb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wa[e] = (_Float16)(o[dt][4 * (2 * gp) + e] * inv);
+                    wb[e] = (_Float16)(o[dt][4 * (2 * gp + 1) + e] * inv);
+                }
+                uint2v ua = __builtin_bit_cast(uint2v, wa), ub = __builtin_bit_cast(uint2v, wb);
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    auto r = __builtin_amdgcn_permlane32_swap(ua[w], ub[w], false, false);
+                    ua[w] = r[0];
+                    ub[w] = r[1];
+                }
+                outv[dt][gp] = uint4v{ua[0], ua[1], ub[0], ub[1]};
+            }
+        if (q0 + ql < len) {
+            _Float16* op = a.ctx + (size_t)(t0 + q0 + ql) * a.ldc + head * 64 + 8 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4v*>(op + dt * 32 + 16 * gp) = outv[dt][gp];
+        }
+    } else if (q0 + ql < len) {
         _Float16* op = a.ctx + (size_t)(t0 + q0 + ql) * a.ldc + head * 64 + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -232,8 +268,8 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
 }
 
 namespace {
-template <int NWV>
-hipError_t launch_attn(const BhAttnArgs& a_in, int n_seq, int n_heads, int max_len, hipStream_t stream) {
+template <int NWV, bool WIDE>
+hipError_t launch_attn_w(const BhAttnArgs& a_in, int n_seq, int n_heads, int max_len, hipStream_t stream) {
     if (n_seq <= 0) return hipSuccess;
     const int nkb = (max_len + 31) / 32;
     if (nkb * 8192 > 160 * 1024) return hipErrorInvalidValue;  // sequences longer than 640 tokens
@@ -242,13 +278,20 @@ hipError_t launch_attn(const BhAttnArgs& a_in, int n_seq, int n_heads, int max_l
     const size_t smem = (size_t)nkb * 8192;
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel<NWV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel<NWV, WIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_smem = smem;
     }
-    hipLaunchKernelGGL(bh_attention_kernel<NWV>, dim3(n_heads, n_seq), dim3(64 * NWV), smem, stream, a);
+    hipLaunchKernelGGL((bh_attention_kernel<NWV, WIDE>), dim3(n_heads, n_seq), dim3(64 * NWV), smem, stream, a);
     return hipGetLastError();
+}
+template <int NWV>
+hipError_t launch_attn(const BhAttnArgs& a, int n_seq, int n_heads, int max_len, hipStream_t stream) {
+    // 16-byte context stores where v_permlane32_swap has its documented direction (the GEMM's probe), 8-byte stores otherwise
+    if (n_seq > 0 && bh_gemm_probe_permlane(stream) == hipSuccess && bh_gemm_swap_mode() == 0)
+        return launch_attn_w<NWV, true>(a, n_seq, n_heads, max_len, stream);
+    return launch_attn_w<NWV, false>(a, n_seq, n_heads, max_len, stream);
 }
 }  // namespace
 
