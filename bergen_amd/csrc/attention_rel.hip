@@ -241,7 +241,38 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
                 }
         }
         const float inv = 1.0f / rel_half_lanes_sum(l_run);
-        if (q0 + ql < len) {
+        if (a.wide_stores) {
+            // 16-byte context stores, as in attention.hip (option attention_rel_wide_stores; the exchange runs outside the row branch)
+            typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+            typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+            uint4v outv[2][2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    half4 wa, wb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        wa[e] = (_Float16)(o[dt][4 * (2 * gp) + e] * inv);
+                        wb[e] = (_Float16)(o[dt][4 * (2 * gp + 1) + e] * inv);
+                    }
+                    uint2v ua = __builtin_bit_cast(uint2v, wa), ub = __builtin_bit_cast(uint2v, wb);
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        auto r = __builtin_amdgcn_permlane32_swap(ua[w], ub[w], false, false);
+                        ua[w] = r[0];
+                        ub[w] = r[1];
+                    }
+                    outv[dt][gp] = uint4v{ua[0], ua[1], ub[0], ub[1]};
+                }
+            if (q0 + ql < len) {
+                _Float16* op = a.ctx + (size_t)(t0 + q0 + ql) * a.ldc + head * 64 + 8 * h;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) *reinterpret_cast<uint4v*>(op + dt * 32 + 16 * gp) = outv[dt][gp];
+            }
+        } else if (q0 + ql < len) {
             _Float16* op = a.ctx + (size_t)(t0 + q0 + ql) * a.ldc + head * 64 + 4 * h;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -255,6 +286,11 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
         }
     }
 }
+
+namespace {
+int g_rel_wide_stores = 0;  // bh_set_option "attention_rel_wide_stores": EXPERIMENTAL until its parity test has run on a GPU (round 5)
+}
+void bh_attention_rel_set_wide_stores(int on) { g_rel_wide_stores = on != 0; }
 
 hipError_t bh_launch_attention_rel(const BhAttnArgs& a_in, int batch, int n_heads, int max_len, hipStream_t stream) {
     if (batch <= 0 || max_len <= 0) return hipSuccess;
@@ -272,6 +308,7 @@ hipError_t bh_launch_attention_rel(const BhAttnArgs& a_in, int batch, int n_head
     a.v_lds_off = nkb * 4096;
     a.rel_lds_off = nkb * 8192;
     a.win_lds_off = (int)base;
+    a.wide_stores = (g_rel_wide_stores && bh_gemm_probe_permlane(stream) == hipSuccess && bh_gemm_swap_mode() == 0) ? 1 : 0;
     static size_t attr_smem[2] = {0, 0};
     const void* fn = win ? reinterpret_cast<const void*>(bh_attention_rel_kernel<true>) : reinterpret_cast<const void*>(bh_attention_rel_kernel<false>);
     if (smem > attr_smem[win ? 1 : 0]) {

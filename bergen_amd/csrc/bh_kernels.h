@@ -199,7 +199,9 @@ struct BhAttnArgs {
     float rel_scale = 0.f;          // 1 / sqrt(3 * head_dim)
     int rel_lds_off = 0;            // filled by the launcher: byte offset of the index table in LDS
     int win_lds_off = 0;            // filled by the launcher: byte offset of the waves' position windows in LDS (attention_rel.hip, WIN)
+    int wide_stores = 0;            // filled by the launcher (attention_rel.hip): context rows as 16-byte stores
 };
+void bh_attention_rel_set_wide_stores(int on);  // option "attention_rel_wide_stores" (experimental: default off)
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
                                         int max_len_long, int n_heads, hipStream_t stream, int short_max = 128,

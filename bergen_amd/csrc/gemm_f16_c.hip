@@ -31,6 +31,7 @@ int n_cu() {
             break;                                                                                                \
         case BH_EPI_BIAS_COL | BH_EPI_SWIGLU:                                                                     \
             if (P == 3) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 3>(a, n_cu(), s);          \
+            if (P == 35) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 35>(a, n_cu(), s);        \
             break;                                                                                                \
     }                                                                                                             \
     return hipErrorNotSupported;

@@ -337,8 +337,71 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                 bias_row[tm] = 0.f;
                 if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) bias_row[tm] = (float)a.bias[m0 + (wm * TM + tm) * 32 + ql];
             }
-            if constexpr ((PST & 32) != 0) {
-                static_assert((PST & 32) == 0 || ((PST & 1) != 0 && (EPI & (BH_EPI_SEGMAX | BH_EPI_SWIGLU)) == 0), "full-line stores: burst, plain outputs");
+            if constexpr ((PST & 32) != 0 && (EPI & BH_EPI_SWIGLU) != 0) {
+                // The gated fold through LDS (EXPERIMENTAL: level 2 of option gemm_full_line_stores): a wave's folded part of a tile
+                // is 32 rows x 32 columns = 64-byte row pieces; straight from the registers a store instruction covers 32 rows with
+                // 32 bytes each, through the wave's LDS buffer 16 rows with their whole 64 bytes.
+                static_assert((PST & 32) == 0 || (PST & 1) != 0, "burst stores");
+                unsigned char* stg = smem + R * STAGE_BYTES + wave * 4096;  // 16 windows of 128 bytes = 32 rows x 64 bytes
+                typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+                half8 bb[TN][2];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        bb[tn][u] = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
+                const int rrow = lane >> 2, rch = lane & 3;  // read-back: instruction i takes rows 16 i + rrow, 16-byte chunk rch of 4
+                _Float16* gptr = c_base + (size_t)(m0 + wm * TM * 32 + rrow) * a.ldc + ((n0 + wn * TN * 32) >> 1) + rch * 8;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        floatx16 c = acc[tm][tn];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[8 * u + e]),
+                                                                          __float_as_uint(c[8 * u + 4 + e]), false, false);
+                                c[8 * u + e] = __uint_as_float(r[0]);
+                                c[8 * u + 4 + e] = __uint_as_float(r[1]);
+                            }
+                        half4 fold[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float g = c[8 * u + 2 * e] + bias_row[tm] + (float)bb[tn][u][2 * e];
+                                const float up = c[8 * u + 2 * e + 1] + bias_row[tm] + (float)bb[tn][u][2 * e + 1];
+                                fold[u][e] = (_Float16)(g / (1.0f + __builtin_amdgcn_exp2f(-g * 1.4426950408889634f)) * up);
+                            }
+                        uint2v lo = __builtin_bit_cast(uint2v, fold[0]), hi = __builtin_bit_cast(uint2v, fold[1]);
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            auto r = __builtin_amdgcn_permlane32_swap(lo[w], hi[w], false, false);
+                            lo[w] = r[0];
+                            hi[w] = r[1];
+                        }
+                        const int chunk = tn * 2 + h;  // the lane's 8 folded columns inside the row's 32
+                        *reinterpret_cast<uintx4*>(stg + (ql >> 1) * 128 + ((((ql & 1) << 2) + (chunk ^ ((ql >> 1) & 3))) << 4)) =
+                            uintx4{lo[0], lo[1], hi[0], hi[1]};
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = 16 * i + rrow;
+                        const uintx4 v = *reinterpret_cast<const uintx4*>(stg + (row >> 1) * 128 + ((((row & 1) << 2) + (rch ^ ((row >> 1) & 3))) << 4));
+                        uintx4* p = reinterpret_cast<uintx4*>(gptr + (size_t)(tm * 32 + 16 * i) * a.ldc);
+                        if constexpr ((PST & 2) != 0)
+                            __builtin_nontemporal_store(v, p);
+                        else
+                            *p = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            } else if constexpr ((PST & 32) != 0) {
+                static_assert((PST & 32) == 0 || ((PST & 1) != 0 && (EPI & BH_EPI_SEGMAX) == 0), "full-line stores: burst, plain outputs");
                 unsigned char* stg = smem + R * STAGE_BYTES + wave * 4096;  // this wave's 32 rows x 128 bytes
                 half8 bb[TN][2];
                 if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
@@ -350,7 +413,12 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                 }
                 (void)bb;
                 const int rrow = lane >> 3, rch = lane & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
-                _Float16* gptr = c_base + (size_t)(m0 + wm * TM * 32 + rrow) * a.ldc + n0 + wn * TN * 32 + rch * 8;
+                // (blocked output — c_block_rows, the V^T layout; level 2 of the option, experimental —: a row's 64 columns are one
+                // 128-byte line and consecutive rows are adjacent: 8 rows = 1 KiB contiguous per instruction)
+                const long long ldrow = a.c_block_rows ? 64 : a.ldc;
+                _Float16* gptr = a.c_block_rows
+                                     ? c_base + (size_t)((n0 + wn * TN * 32) >> 6) * a.c_block_rows * 64 + (size_t)(m0 + wm * TM * 32 + rrow) * 64 + rch * 8
+                                     : c_base + (size_t)(m0 + wm * TM * 32 + rrow) * a.ldc + n0 + wn * TN * 32 + rch * 8;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -383,7 +451,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ rrow) << 4));
-                        half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tm * 32 + 8 * i) * a.ldc);
+                        half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tm * 32 + 8 * i) * ldrow);
                         if constexpr ((PST & 2) != 0)
                             __builtin_nontemporal_store(v, p);
                         else

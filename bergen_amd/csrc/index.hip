@@ -362,8 +362,11 @@ int bh_set_option(const char* name, int64_t value) {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");
         bh_gemm_set_stagger((int)value, -1);
     } else if (s == "gemm_full_line_stores") {
-        if (value != 0 && value != 1) return fail(BH_EINVAL, "gemm_full_line_stores must be 0 or 1");
+        if (value < 0 || value > 2) return fail(BH_EINVAL, "gemm_full_line_stores must be 0, 1 or 2 (2 = 1 + the experimental set: blocked V^T output, gated fold)");
         bh_gemm_set_full_line_stores((int)value);
+    } else if (s == "attention_rel_wide_stores") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "attention_rel_wide_stores must be 0 or 1");
+        bh_attention_rel_set_wide_stores((int)value);
     } else if (s == "gemm_stagger_pct") {
         if (value < 1 || value > 400) return fail(BH_EINVAL, "gemm_stagger_pct must be 1..400");
         bh_gemm_set_stagger(-1, (int)value);
