@@ -41,6 +41,9 @@ int g_full_line_stores = 1;  // bh_set_option "gemm_full_line_stores" (default o
                              // per 512 passages in the same process (profiles/r04t_ab_full_line_stores.txt)
 }
 
+int g_gelu_nontemporal = 1;  // bh_set_option "gemm_gelu_nontemporal": the FFN-up (bias + GELU) output bypasses the caches (measured +8 % on that
+                             // GEMM in round 1, when one batch's 421 MB were written at once; an A/B knob since the micro-batches halved that)
+void bh_gemm_set_gelu_nontemporal(int on) { g_gelu_nontemporal = on != 0; }
 void bh_gemm_set_full_line_stores(int level) { g_full_line_stores = level < 0 ? 0 : level > 2 ? 2 : level; }
 
 void bh_gemm_set_stagger(int phases, int pct) {
@@ -191,7 +194,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     const int kt_ = a.K / 64;
     const bool alt_ok = (kt_ & 1) == 0 && kt_ >= 8;
     const int pst = variant == 31 ? 5 : variant == 32 ? 9 : variant == 8 ? 0 : variant == 9 ? 3 : (variant == 33 && alt_ok) ? 16
-                    : (auto_variant && (epi & BH_EPI_GELU)) ? 3 : 1;
+                    : (auto_variant && (epi & BH_EPI_GELU) && g_gelu_nontemporal) ? 3 : 1;
     if (persist) {
         if (epi & BH_EPI_RESIDUAL) return bh_gemm_generic(a, epi, stream);  // (the encoder adds residuals in LayerNorm)
         variant = 5;  // same tile geometry

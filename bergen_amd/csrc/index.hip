@@ -364,6 +364,9 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "gemm_full_line_stores") {
         if (value < 0 || value > 2) return fail(BH_EINVAL, "gemm_full_line_stores must be 0, 1 or 2 (2 = 1 + the experimental set: blocked V^T output, gated fold)");
         bh_gemm_set_full_line_stores((int)value);
+    } else if (s == "gemm_gelu_nontemporal") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "gemm_gelu_nontemporal must be 0 or 1");
+        bh_gemm_set_gelu_nontemporal((int)value);
     } else if (s == "attention_rel_wide_stores") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "attention_rel_wide_stores must be 0 or 1");
         bh_attention_rel_set_wide_stores((int)value);
