@@ -82,3 +82,31 @@ def test_op_references():
     ang = 5 * 1000.0 ** (-np.arange(32) / 32.0)
     want = np.concatenate([x[:, :32] * np.cos(ang) - x[:, 32:] * np.sin(ang), x[:, 32:] * np.cos(ang) + x[:, :32] * np.sin(ang)], -1)
     assert np.allclose(out[1].reshape(4, 64), want)
+
+
+def test_checkpoint_maps_onto_the_bert_shaped_stack():
+    """encoder.canonical_config / canonical_state_dict on a NomicBert checkpoint (no GPU needed): rotary and gating flags, the
+    renamed tensors, zero position table and biases, and gate / up rows INTERLEAVED (row 2 j = gate j, row 2 j + 1 = up j — the
+    layout the GEMM's fold epilogue and bh_swiglu_kernel read; include/bergen_hip.h bh_encoder_config.ffn_gated)."""
+    import torch
+    from bergen_amd import encoder
+    cfg, sd, z = load_tiny()
+    canon = encoder.canonical_config(dict(cfg, model_type="nomic_bert"))
+    assert canon["rotary_theta"] == 1000.0 and canon["ffn_gated"] == 1 and canon["head_dim"] == 64 and canon["position_offset"] == 0
+    out = encoder.canonical_state_dict(canon, {k: torch.from_numpy(v) for k, v in sd.items()})
+    d, f = cfg["hidden_size"], cfg["intermediate_size"]
+    w1 = out["encoder.layer.1.intermediate.dense.weight"].numpy()
+    assert w1.shape == (2 * f, d)
+    assert np.array_equal(w1[0::2], sd["layers.1.mlp.gate_proj.weight"]) and np.array_equal(w1[1::2], sd["layers.1.mlp.up_proj.weight"])
+    assert np.array_equal(out["encoder.layer.0.attention.self.query.weight"].numpy(), sd["layers.0.self_attn.q_proj.weight"])
+    assert np.array_equal(out["encoder.layer.0.output.dense.weight"].numpy(), sd["layers.0.mlp.down_proj.weight"])
+    assert np.array_equal(out["encoder.layer.1.output.LayerNorm.bias"].numpy(), sd["layers.1.post_mlp_layernorm.bias"])
+    assert not out["embeddings.position_embeddings.weight"].any() and out["embeddings.position_embeddings.weight"].shape == (cfg["max_position_embeddings"], d)
+    for name, n in (("attention.self.query", d), ("intermediate.dense", 2 * f), ("output.dense", d)):
+        b = out[f"encoder.layer.0.{name}.bias"]
+        assert b.shape == (n,) and not b.any()
+    assert not any("mlp." in k or "self_attn." in k or k.startswith("layers.") for k in out)
+    # configurations outside the HIP forward pass are refused with a reason (the plug-in then stays on HF torch, loudly)
+    for bad in (dict(hidden_act="gelu"), dict(rope_parameters={"rope_type": "yarn", "rope_theta": 1000.0}), dict(num_attention_heads=4)):
+        with pytest.raises(ValueError):
+            encoder.canonical_config(dict(cfg, model_type="nomic_bert", **bad))
