@@ -36,13 +36,13 @@ __global__ void bh_permlane_probe_kernel(unsigned* out) {
 namespace {
 int g_swap_b = -1;  // -1 unknown, 0 documented direction, 1 the other one
 int g_stagger_phases = 0, g_stagger_pct = 100;  // bench knobs (bh_set_option "gemm_stagger_phases" / "_pct")
+int g_gelu_nontemporal = 1;  // bh_set_option "gemm_gelu_nontemporal": the FFN-up (bias + GELU) output bypasses the caches (measured +8 % on that
+                             // GEMM in round 1, when one batch's 421 MB were written at once; an A/B knob since the micro-batches halved that)
 int g_full_line_stores = 1;  // bh_set_option "gemm_full_line_stores" (default on): the persistent kernel's row-major outputs leave as whole
                              // 128-byte lines through LDS (gemm_f16_persist.h PST bit 32) — bit-identical, BERT-base forward 15.60 -> 14.55 ms
                              // per 512 passages in the same process (profiles/r04t_ab_full_line_stores.txt)
 }
 
-int g_gelu_nontemporal = 1;  // bh_set_option "gemm_gelu_nontemporal": the FFN-up (bias + GELU) output bypasses the caches (measured +8 % on that
-                             // GEMM in round 1, when one batch's 421 MB were written at once; an A/B knob since the micro-batches halved that)
 void bh_gemm_set_gelu_nontemporal(int on) { g_gelu_nontemporal = on != 0; }
 void bh_gemm_set_full_line_stores(int level) { g_full_line_stores = level < 0 ? 0 : level > 2 ? 2 : level; }
 
