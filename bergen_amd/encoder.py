@@ -11,7 +11,10 @@ Drop-in for the HF ``AutoModel`` object the reference stores in ``Dense.model`` 
   * ``.to(device)``, ``.eval()``, ``.half()`` exist because ``Retrieve`` moves ``model.model`` around
     (modules/retrieve.py:78,124,142); the weights live in HBM inside the library and never move.
 
-Weights come from any HF ``BertModel``-architecture module or state_dict (RetroMAE, contriever, e5, bge ...).
+Weights come from any HF ``BertModel``-architecture module or state_dict (RetroMAE, contriever, e5, bge ...), from DistilBERT,
+RoBERTa / XLM-R and DeBERTa-v2 / v3 checkpoints (renamed onto the same stack, `canonical_state_dict`), and from transformers' native
+``NomicBertModel`` (nomic-embed-text-v1.5: rotary positions applied to the Q | K rows after their projection, gate and up rows of the
+gated SiLU feed-forward interleaved into one GEMM whose epilogue folds them).
 There is no CPU path: constructing an encoder without a gfx950 device raises.
 """
 import ctypes
