@@ -75,6 +75,8 @@ def parse_args():
     p.add_argument("--enc-steps", type=int, default=3)
     p.add_argument("--no-splade", action="store_true", help="skip the SPLADE legs (configs[3]: MLM-head encode, sparse search)")
     p.add_argument("--splade-docs", type=int, default=21_000_000, help="documents of the synthetic SPLADE corpus (S4: 21 M, ~180 terms each)")
+    p.add_argument("--splade-queries", type=int, default=2837, help="queries of the SPLADE search leg (kilt_nq dev size; 64 per tile pass)")
+    p.add_argument("--splade-gate-queries", type=int, default=16, help="queries whose complete top-k lists the SPLADE leg recomputes over the whole corpus")
     p.add_argument("--splade-term-seeds", type=int, default=3,
                    help="independent draws of the S4 term-set recipe behind the SPLADE corpus blocks (every block gets fresh weights)")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -333,8 +335,8 @@ def splade_legs(args, device_index):
       (`BertEncoder.encode_splade`; the [B, T, vocab] logits are never materialised);
     * search: SURVEY §8d S4 as stated — synthetic CSR corpus of 21 M documents (V = 30 522, Poisson(180) terms per document
       clipped to [16, 400], Zipf(1.1) term ids drawn without replacement; 21 distinct 1 M-document blocks), 64-query tiles,
-      top-k; roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per tile pass.
-    Self-check on a 200 k-document slice: both HIP kernels agree bit for bit, canonical order, scores recomputed in numpy."""
+      top-k, ALL 2 837 queries of the kilt_nq dev size (45 tile passes); roofline = HBM with algorithmic bytes nnz*4 + (N+1)*8 per
+      tile pass.  Parity gate at full size: the complete lists of 16 queries recomputed over all 21 M documents (SparseStreamGate)."""
     from bergen_amd import BertEncoder, SparseIndex, synth
     out = {}
     cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
@@ -366,80 +368,138 @@ def splade_legs(args, device_index):
         "finite_and_shaped": bool(torch.isfinite(emb.float()).all()) and tuple(emb.shape) == (args.enc_batch, 30522)}
     del emb
     enc.close()
-    V, block = 30522, 1_000_000
+    V = 30522
     dev = torch.device("cuda", device_index)
-    # 21 DISTINCT 1 M-document blocks (round 2 repeated one block 21 times: every document then had 20 exact duplicates and a
-    # query's top-50 collapsed to its top-3 distinct documents, which flattered the threshold filter): the term sets come
-    # from --splade-term-seeds independent draws of the S4 recipe, used in turn, and EVERY block gets its own weights
-    # (log1p(Exp(1)), drawn on the device) — no two documents of the corpus share their scores.
-    n_blocks = (args.splade_docs + block - 1) // block
-    t_gen = time.perf_counter()
-    term_sets = [synth.random_sparse_corpus_device(min(block, args.splade_docs), V, seed=4 + 1000 * j, device=dev)
-                 for j in range(max(1, min(args.splade_term_seeds, n_blocks)))]
-    gen_s = time.perf_counter() - t_gen
-    ix = SparseIndex(args.splade_docs, V, device=device_index)
-    done, b = 0, 0
-    blk = term_sets[0]
-    while done < args.splade_docs:
-        indptr, terms, w0 = term_sets[b % len(term_sets)]
-        m = min(len(indptr) - 1, args.splade_docs - done)
-        nnz_b = int(indptr[m])
-        if b < len(term_sets):
-            w = w0[:nnz_b]
-        else:
-            gw = torch.Generator(device=dev).manual_seed(40_000 + b)
-            w = torch.log1p(torch.empty(nnz_b, device=dev).exponential_(1.0, generator=gw)).half().clamp_(min=0.01).cpu().numpy()
-        ix.upload((indptr[:m + 1], terms[:nnz_b], w))
-        done += m
-        b += 1
-    ix.finalize()
-    qp, qt, qw = synth.random_sparse_corpus_fast(256, V, seed=5, mean_nnz=24, lo=4, hi=64)
+    # 21 DISTINCT 1 M-document blocks (synth.sparse_bench_blocks: term sets from --splade-term-seeds independent draws of the S4
+    # recipe used in turn, fresh weights per block — no two documents share their scores; round 2 repeated one block 21 times,
+    # which flattered the threshold filter).  tests/test_gpu_sparse.py::test_full_size_sparse iterates the same generator and
+    # checks the same search against the oracle; the gate below recomputes complete lists WITHOUT the oracle and without any
+    # kernel of this repository while the blocks stream by.
+    nq = args.splade_queries
+    qp, qt, qw = synth.random_sparse_corpus_fast(nq, V, seed=5, mean_nnz=24, lo=4, hi=64)
     q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    gate = SparseStreamGate(q, sparse_gate_queries(nq, args.splade_gate_queries), args.k, dev)
+    n_blocks = (args.splade_docs + 999_999) // 1_000_000
+    ix = SparseIndex(args.splade_docs, V, device=device_index)
+    t_gen = time.perf_counter()
+    gate_s = 0.0
+    for b, row0, indptr, terms, w in synth.sparse_bench_blocks(args.splade_docs, V, dev, term_seeds=args.splade_term_seeds):
+        ix.upload((indptr, terms, w))
+        t0 = time.perf_counter()
+        gate.add_block(row0, indptr, terms, w)
+        gate_s += time.perf_counter() - t0
+    build_s = time.perf_counter() - t_gen - gate_s
+    ix.finalize()
     ix.search(q[:64], args.k)
     best = None
     for _ in range(3):
         t0 = time.perf_counter()
-        ix.search(q, args.k)
+        res_s, res_i = ix.search(q, args.k)
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, ix.counters())
     dt, c = best
     gbps = c["algorithmic_bytes"] / (c["scan_ms"] * 1e-3) / 1e9
-    # self-check without the oracle (parity proper lives in tests/): on a 200 k-document slice the two independent HIP
-    # kernels (csr_mfma.hip / csr_topk.hip) must agree bit for bit, rows must come in canonical order, and the scores
-    # must equal the canonical score (fp32 of the fp64 sum in term order) recomputed here with numpy
-    from bergen_amd import _lib
-    m = min(len(blk[0]) - 1, 200_000)
-    sub = SparseIndex(m, V, device=device_index)
-    sub.upload((blk[0][:m + 1], blk[1][:blk[0][m]], blk[2][:blk[0][m]]))
-    sub.finalize()
-    s2, i2 = sub.search(q[:8], args.k)
-    _lib.set_option("sparse_kernel", 0)
-    s0, i0 = sub.search(q[:8], args.k)
-    _lib.set_option("sparse_kernel", 1)
-    ok = bool(np.array_equal(i2, i0) and np.array_equal(s2.view(np.uint32), s0.view(np.uint32)))
-    ok &= bool((np.diff(s2, axis=1) <= 0).all())
-    ok &= bool(np.all((np.diff(s2, axis=1) < 0) | (np.diff(i2, axis=1) > 0)))
-    qd = q[:8].astype(np.float64)
-    for a in range(8):
-        for b in range(0, args.k, 7):
-            r = int(i2[a, b])
-            t = blk[1][blk[0][r]:blk[0][r + 1]]
-            w = blk[2][blk[0][r]:blk[0][r + 1]].astype(np.float64)
-            o = np.argsort(t, kind="stable")
-            acc = np.cumsum(qd[a, t[o]] * w[o])
-            ok &= bool(np.float32(acc[-1] if len(acc) else 0.0) == s2[a, b])
+    t0 = time.perf_counter()
+    want_s, want_i = gate.result()
+    gate_s += time.perf_counter() - t0
+    gi = gate.queries
+    exact = bool(np.array_equal(res_i[gi], want_i) and np.array_equal(res_s[gi].view(np.uint32), want_s.view(np.uint32)))
+    d_s, d_i = np.diff(res_s, axis=1), np.diff(res_i, axis=1)
+    ordered = bool((d_s <= 0).all() and np.all((d_s < 0) | (d_i > 0)))
     out["splade_search"] = {
-        "queries_per_s": 256 / dt, "docs": args.splade_docs, "nnz": int(ix.nnz), "scan_ms_per_pass": c["scan_ms"] / c["n_passes"],
-        "corpus": f"{n_blocks} distinct 1M-document blocks: term sets from {len(term_sets)} independent draws of SURVEY §8d S4 "
-                  f"({gen_s:.1f} s to draw), fresh weights per block",
+        "queries_per_s": nq / dt, "queries": nq, "docs": args.splade_docs, "nnz": int(ix.nnz), "passes": int(c["n_passes"]),
+        "scan_ms_per_pass": c["scan_ms"] / c["n_passes"], "search_ms": dt * 1e3, "scan_ms": c["scan_ms"],
+        "corpus": f"{n_blocks} distinct 1M-document blocks: term sets from {min(args.splade_term_seeds, n_blocks)} independent draws "
+                  f"of SURVEY §8d S4, fresh weights per block ({build_s:.1f} s to draw and upload)",
         "roofline": {"bound": "hbm", "kernel": "bh_csr_scan_mfma_kernel", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.traffic_json, "bh_csr_scan_mfma_kernel", args.splade_docs, V),
                      "algorithmic_bytes_per_launch": c["algorithmic_bytes"] / c["n_passes"]},
-        "parity_check": "pass" if ok else "FAIL"}
-    sub.close()
+        "full_list_gate": {"queries": len(gi), "query_indices": [int(x) for x in gi], "docs": args.splade_docs,
+                           "ids_and_fp32_scores_bit_exact": exact, "canonical_order_all_queries": ordered, "seconds": gate_s,
+                           "candidates_per_block": gate.width, "how": SparseStreamGate.HOW},
+        "parity_check": "pass" if exact and ordered else "FAIL"}
     ix.close()
     return out
+
+
+def sparse_gate_queries(nq, n_check=16):
+    """Queries whose complete lists the SPLADE gate recomputes: from the first, a middle and the last 64-query tile, the first
+    and the last query of each included (tests/test_gpu_sparse.py picks the same way)."""
+    n_tiles = -(-nq // 64)
+    tiles = sorted({0, n_tiles // 2, n_tiles - 1})
+    share = [n_check // len(tiles) + (1 if j < n_check % len(tiles) else 0) for j in range(len(tiles))]
+    picks = set()
+    for t, cnt in zip(tiles, share):
+        lo, hi = 64 * t, min(nq, 64 * t + 64)
+        picks.update(np.linspace(lo, hi - 1, max(cnt, 2)).astype(int).tolist())
+    return sorted(picks)
+
+
+class SparseStreamGate:
+    """Complete canonical top-k lists of a few queries over a CSR corpus that streams by block by block — recomputed with plain
+    torch / numpy operations, no kernel of this repository and no oracle (parity proper, against oracle/sparse_oracle.c, is
+    tests/test_gpu_sparse.py::test_full_size_sparse on the same corpus).
+    Per block and query: every document's score as a float64 index_add_ of q[term] * weight (any summation order: within 1e-9
+    of the canonical value), the block's `width` best by that score are the candidates; their CANONICAL scores — fp32 of the
+    float64 sum in increasing term order (include/bergen_hip.h: bh_sparse_search) — are recomputed sequentially on the host.  A
+    member of the global top k is a member of its block's top k, and it is among the candidates unless the unordered sum moved
+    it by more than `width - k` ranks: checked (the last candidate's score must lie below the k-th canonical score by more than
+    the error bound, or the block is re-done four times as wide)."""
+    HOW = ("float64 index_add_ of q[term] * weight per 1M-document block (torch, on the device) -> candidates per query and block; "
+           "canonical scores of the candidates = fp32 of the float64 sum in term order (numpy cumsum), (score desc, row asc), cut k")
+
+    def __init__(self, q_dense_f16, queries, k, device, width=None):
+        self.queries = list(queries)
+        self.k = int(k)
+        self.device = device
+        self.width = int(width) if width else self.k + 14
+        self.qd_host = q_dense_f16[self.queries].astype(np.float64)
+        self.qd = torch.from_numpy(self.qd_host).to(device)
+        self.cands = [[] for _ in self.queries]       # per query: (canonical fp32 score, global row)
+
+    def add_block(self, row0, indptr, terms, w):
+        m = len(indptr) - 1
+        if m == 0:
+            return
+        dev = self.device
+        lens = torch.from_numpy(np.diff(indptr)).to(dev)
+        doc = torch.repeat_interleave(torch.arange(m, device=dev), lens)
+        t_d = torch.from_numpy(terms).to(dev).long()
+        w_d = torch.from_numpy(w).to(dev).double()
+        for a in range(len(self.queries)):
+            approx = torch.zeros(m, dtype=torch.float64, device=dev).index_add_(0, doc, self.qd[a][t_d] * w_d)
+            width = min(self.width, m)
+            while True:
+                top = torch.topk(approx, width)
+                rows = top.indices.cpu().numpy()
+                exact = np.empty(width, np.float32)
+                for j, r in enumerate(rows):
+                    lo, hi = indptr[r], indptr[r + 1]
+                    acc = np.cumsum(self.qd_host[a, terms[lo:hi]] * w[lo:hi].astype(np.float64))
+                    exact[j] = np.float32(acc[-1] if hi > lo else 0.0)
+                if width == m or width <= self.k:
+                    break
+                kth = np.sort(exact)[::-1][self.k - 1]
+                if float(top.values[-1]) + 1e-6 < float(kth):
+                    break
+                if width >= 16384:  # (a block where thousands of documents tie with the k-th score: not a corpus this gate is for)
+                    raise RuntimeError(f"SparseStreamGate: {width} candidates do not separate the top {self.k} of query {self.queries[a]}")
+                width = min(m, width * 4)
+                self.width = max(self.width, width)
+            self.cands[a].append((exact, rows.astype(np.int64) + row0))
+        del doc, t_d, w_d, lens
+
+    def result(self):
+        out_s = np.full((len(self.queries), self.k), -np.inf, np.float32)
+        out_i = np.full((len(self.queries), self.k), -1, np.int64)
+        for a, parts in enumerate(self.cands):
+            s = np.concatenate([p[0] for p in parts])
+            r = np.concatenate([p[1] for p in parts])
+            order = np.lexsort((r, -s.astype(np.float64)))[:self.k]
+            out_s[a, :len(order)] = s[order]
+            out_i[a, :len(order)] = r[order]
+        return out_s, out_i
 
 
 def retrieve_stage_leg(args, device_index):

@@ -195,3 +195,28 @@ def random_sparse_corpus_device(n_docs, vocab, seed, device, mean_nnz=180, lo=16
     w = np.log1p(rng.exponential(1.0, size=terms.size)).astype(np.float16)
     w[w == 0] = np.float16(0.01)
     return indptr, terms, w
+
+
+def sparse_bench_blocks(n_docs, vocab, device, term_seeds=3, block=1_000_000):
+    """The SPLADE corpus of BASELINE configs[3] at its stated size, block by block: DISTINCT blocks of `block`
+    documents whose term sets come from `term_seeds` independent draws of the S4 recipe (random_sparse_corpus_device, seeds
+    4, 1004, 2004, ...) used in turn; the first use of a draw keeps its own weights, every later block gets fresh weights
+    log1p(Exp(1)) drawn on the device (seed 40 000 + block ordinal) — no two documents of the corpus share their scores.
+    Yields (ordinal, first row, indptr int64 [m + 1], terms int32 [nnz], weights fp16 [nnz]) as numpy arrays; bench.py's SPLADE
+    leg and tests/test_gpu_sparse.py::test_full_size_sparse iterate the SAME generator, so the test pins what the bench times."""
+    import torch
+    n_blocks = (n_docs + block - 1) // block
+    sets = [random_sparse_corpus_device(min(block, n_docs), vocab, seed=4 + 1000 * j, device=device)
+            for j in range(max(1, min(term_seeds, n_blocks)))]
+    done = 0
+    for b in range(n_blocks):
+        indptr, terms, w0 = sets[b % len(sets)]
+        m = min(len(indptr) - 1, n_docs - done)
+        nnz_b = int(indptr[m])
+        if b < len(sets):
+            w = w0[:nnz_b]
+        else:
+            gw = torch.Generator(device=device).manual_seed(40_000 + b)
+            w = torch.log1p(torch.empty(nnz_b, device=device).exponential_(1.0, generator=gw)).half().clamp_(min=0.01).cpu().numpy()
+        yield b, done, indptr[:m + 1], terms[:nnz_b], w
+        done += m

@@ -112,21 +112,26 @@ def floats_to_halfs(a):
 
 def sparse_canonical_search(indptr, terms, weights, vocab, q, k, id_offset=0):
     """bh_sparse_search's contract on the CPU (sparse_oracle.c).  CSR documents (indptr int64 [n+1], terms int32,
-    weights fp16 / fp32->fp16), dense queries q [nq, vocab].  Rows are sorted by term id here if they are not."""
+    weights fp16 / fp32->fp16), dense queries q [nq, vocab].  Rows are sorted by term id here if they are not (checked in C:
+    a corpus that arrives sorted — every generator of bergen_amd.synth — is passed through without a copy)."""
     indptr = np.ascontiguousarray(indptr, np.int64)
-    terms = np.ascontiguousarray(terms, np.int32).copy()
-    wb = _as_half_bits(np.asarray(weights)).copy()
-    for r in range(len(indptr) - 1):
-        b, e = indptr[r], indptr[r + 1]
-        o = np.argsort(terms[b:e], kind="stable")
-        terms[b:e] = terms[b:e][o]
-        wb[b:e] = wb[b:e][o]
+    terms = np.ascontiguousarray(terms, np.int32)
+    wb = _as_half_bits(np.asarray(weights))
+    n = len(indptr) - 1
+    lib().oracle_sparse_first_unsorted_row.restype = ctypes.c_int64
+    if lib().oracle_sparse_first_unsorted_row(_p(indptr), _p(terms), ctypes.c_int64(n)) >= 0:
+        terms, wb = terms.copy(), wb.copy()
+        for r in range(n):
+            b, e = indptr[r], indptr[r + 1]
+            o = np.argsort(terms[b:e], kind="stable")
+            terms[b:e] = terms[b:e][o]
+            wb[b:e] = wb[b:e][o]
     qb = _as_half_bits(q)
     nq = qb.shape[0]
     assert qb.shape[1] == vocab
     out_s = np.empty((nq, k), np.float32)
     out_i = np.empty((nq, k), np.int64)
-    lib().oracle_sparse_canonical_search(_p(indptr), _p(terms), _p(wb), ctypes.c_int64(len(indptr) - 1),
+    lib().oracle_sparse_canonical_search(_p(indptr), _p(terms), _p(wb), ctypes.c_int64(n),
                                          ctypes.c_int32(vocab), _p(qb), ctypes.c_int64(nq), ctypes.c_int(k),
                                          ctypes.c_int64(id_offset), _p(out_s), _p(out_i))
     return out_s, out_i

@@ -61,3 +61,14 @@ void oracle_sparse_canonical_search(const int64_t* indptr, const int32_t* terms,
         free(best);
     }
 }
+
+/* A row whose term ids are not strictly increasing (the last such row), or -1: lets the Python binding skip its per-row sort for corpora that
+ * arrive sorted (the 21 M-document streams of tests/test_gpu_sparse.py::test_full_size_sparse). */
+int64_t oracle_sparse_first_unsorted_row(const int64_t* indptr, const int32_t* terms, int64_t n) {
+    int64_t bad = -1;
+#pragma omp parallel for schedule(static) reduction(max : bad)
+    for (int64_t r = 0; r < n; ++r)
+        for (int64_t e = indptr[r] + 1; e < indptr[r + 1]; ++e)
+            if (terms[e] <= terms[e - 1] && r > bad) bad = r;
+    return bad;
+}

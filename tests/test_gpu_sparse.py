@@ -272,3 +272,73 @@ def test_large_k_is_searched_range_by_range(amd, n, V, nq, k, signed, cluster):
     if not signed:
         assert np.array_equal(i[2, :kk] - 11, np.arange(kk))
     ix.close()
+
+
+def sparse_gate_queries(nq, n_check=16):
+    """Queries whose complete lists the full-size gates recompute: from the first, a middle and the last 64-query tile, the
+    first and the last query of each included (the last tile of 2 837 queries holds 21)."""
+    n_tiles = -(-nq // 64)
+    tiles = sorted({0, n_tiles // 2, n_tiles - 1})
+    share = [n_check // len(tiles) + (1 if j < n_check % len(tiles) else 0) for j in range(len(tiles))]
+    picks = set()
+    for t, cnt in zip(tiles, share):
+        lo, hi = 64 * t, min(nq, 64 * t + 64)
+        picks.update(np.linspace(lo, hi - 1, max(cnt, 2)).astype(int).tolist())
+    return sorted(picks)
+
+
+def test_full_size_sparse():
+    """BASELINE configs[3] AT ITS STATED SIZE (round 4's review: nothing above 20 000 documents had been checked against the
+    oracle, and the pre-pass / threshold-table logic of csr_mfma.hip only behaves at scale): the bench's own 21 x 1 M-document
+    corpus (synth.sparse_bench_blocks — the generator bench.py's SPLADE leg iterates) streamed block by block through
+    c_oracle.sparse_canonical_search (models/retrievers/splade.py:55-56 + modules/retrieve.py:152-177 restated), the per-block
+    lists merged with the oracle's merge; against it the COMPLETE top-50 lists of 16 queries of a 2 837-query search (kilt_nq dev
+    size: 45 tile passes; queries from the first, a middle and the last tile) — ids and fp32 score bits.  Then the same corpus as
+    TWO row shards cut inside a block, searched with id offsets and merged by the product's merge (the multi-GPU decomposition):
+    bit-identical to the one-index search for ALL 2 837 queries, and to the oracle for the 16."""
+    import bergen_amd as amd
+    from bergen_amd import _lib
+    _lib.init(0)
+    dev = torch.device("cuda", 0)
+    n_docs = int(os.environ.get("BERGEN_SPARSE_FULL_DOCS", 21_000_000))
+    V, k, nq = 30522, 50, 2837
+    qp, qt, qw = synth.random_sparse_corpus_fast(nq, V, seed=5, mean_nnz=24, lo=4, hi=64)
+    q = synth.csr_to_dense(qp, qt, qw, V).astype(np.float16)
+    gate = sparse_gate_queries(nq, 16)
+    assert len(gate) >= 16 and gate[0] < 64 and gate[-1] >= 64 * (-(-nq // 64) - 1)
+    cut = n_docs // 2 + 12_345 if n_docs > 100_000 else n_docs // 2      # a shard boundary INSIDE a block
+    full = amd.SparseIndex(n_docs, V, device=0)
+    shards = [amd.SparseIndex(cut, V, device=0), amd.SparseIndex(n_docs - cut, V, device=0)]
+    for ix in [full] + shards:
+        ix.set_option("sparse_kernel", 1)
+        ix.set_option("sparse_head", 1)
+    lists_s, lists_i = [], []
+    for b, row0, indptr, terms, w in synth.sparse_bench_blocks(n_docs, V, dev):
+        m = len(indptr) - 1
+        full.upload((indptr, terms, w))
+        for a, z, ix in ((row0, min(row0 + m, cut), shards[0]), (max(row0, cut), row0 + m, shards[1])):
+            if z > a:
+                lo, hi = a - row0, z - row0
+                ix.upload((indptr[lo:hi + 1] - indptr[lo], terms[indptr[lo]:indptr[hi]], w[indptr[lo]:indptr[hi]]))
+        s_b, i_b = c_oracle.sparse_canonical_search(indptr, terms, w, V, q[gate], k, id_offset=row0)
+        lists_s.append(s_b)
+        lists_i.append(i_b)
+    want_s, want_i = c_oracle.merge_topk(np.stack(lists_s), np.stack(lists_i))
+    full.finalize()
+    assert full.rows_uploaded == n_docs
+    s, i = full.search(q, k)
+    c = full.counters()
+    assert c["n_passes"] == -(-nq // 64) and c["n_rows"] == n_docs
+    assert_bit_exact(s[gate], i[gate], want_s, want_i, f"sparse full size: {n_docs} documents, {len(gate)} complete lists of {nq} queries")
+    d_s, d_i = np.diff(s, axis=1), np.diff(i, axis=1)
+    assert (d_s <= 0).all() and np.all((d_s < 0) | (d_i > 0)), "canonical order (score desc, row asc) for every query"
+    assert i.min() >= 0 and i.max() < n_docs
+    full.close()
+    parts = []
+    for ix, off in zip(shards, (0, cut)):
+        ix.finalize()
+        parts.append(ix.search(q, k, id_offset=off))
+        ix.close()
+    m_s, m_i = amd.merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert_bit_exact(m_s, m_i, s, i, "two row shards merged vs one index, all queries")
+    assert_bit_exact(m_s[gate], m_i[gate], want_s, want_i, "two row shards merged vs oracle")
