@@ -1165,6 +1165,31 @@ class HipEnv:
         torch.cuda.synchronize()
 
 
+def rank_line(env, rank, world, lo, hi, dim, build_s):
+    """One stderr line per rank once its shard is resident — device, rows, transport version, free HBM — so that a multi-GPU run
+    that fails later (a collective that never returns, a rank on the wrong device) can be diagnosed from the tail of its log."""
+    try:
+        import torch.distributed as dist
+        backend = str(dist.get_backend()) if world > 1 and dist.is_initialized() else "none"
+        ver = ""
+        if backend == "nccl":
+            try:
+                ver = " rccl " + ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                ver = f" rccl version unavailable ({type(e).__name__})"
+        dev = getattr(env, "device", None)
+        name, free = "cpu", ""
+        if dev is not None and dev.type == "cuda":
+            name = torch.cuda.get_device_name(dev)
+            f, t = torch.cuda.mem_get_info(dev)
+            free = f", HBM free {f / 2**30:.0f} of {t / 2**30:.0f} GiB"
+        print(f"[bench rank {rank}/{world}] pid {os.getpid()} device {dev} ({name}), rows [{lo}, {hi}) x {dim} resident after {build_s:.1f} s, "
+              f"transport {backend}{ver}{free}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset')}",
+              file=sys.stderr, flush=True)
+    except Exception as e:  # noqa: BLE001 — a diagnostic must never take the run down
+        print(f"[bench rank {rank}/{world}] (rank line failed: {e})", file=sys.stderr, flush=True)
+
+
 def launch_ranks_if_needed(args, script=None):
     """`python bench.py --gpus N` typed WITHOUT a launcher (N > 1, no WORLD_SIZE in the environment): start the N ranks here —
     the same `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script>
@@ -1226,6 +1251,7 @@ def run(args, env):
     ix.finalize()
     env.sync()
     build_s = time.perf_counter() - t0
+    rank_line(env, rank, world, lo, hi, dim, build_s)
     # The search runs THROUGH THE STAGE: Retrieve.search_rows is the search half of Retrieve.retrieve (the code a BERGEN
     # pipeline reaches through modules/rag.py:322-329) — single GPU: fused scan + merge, lists written into pinned host
     # memory; N GPUs: the same on this rank's row shard with global row ids, one all-gather of the packed partial lists

@@ -549,7 +549,8 @@ class Retrieve:
                 part = part.contiguous()
                 if on_gpu and not sparse and not part.is_cuda:
                     part = part.to(device)  # (sparse search takes host queries: its host side builds the term tables)
-                res = searcher.search(part, k, broadcast=everywhere)
+                res = searcher.search(part, k, broadcast=everywhere, check=False)
+                searcher.check_last()  # (the status words come down with — or, on ranks without results, instead of — the lists)
                 if res is not None:  # (the searcher reuses its result buffers: .cpu() of a device tensor copies, host tensors are cloned)
                     parts.append((res[0].cpu(), res[1].cpu()) if res[0].is_cuda else (res[0].clone(), res[1].clone()))
             if not parts:
