@@ -123,6 +123,9 @@ def test_scan_roofline_accounts_for_paired_unpaired_and_tail_launches():
     assert r["hbm_bytes_needed_per_launch"] == n * d * 2.0 + 2 * (256 * d * 2.0 + 256 * k * 12.0) and r["traffic"] is None
     assert r["unpaired_launch"]["launches"] == steps and abs(r["unpaired_launch"]["avg_launch_ms"] - 7.3) < 1e-9
     assert abs(r["tail_pass"]["avg_launch_ms"] - 5.0) < 1e-9
+    # the figure that cannot be misread: the larger of (bytes the launch must move) / time / peak and flops / time / peak
+    assert r["algorithmic_frac"] == r["frac"] and r["binding_resource"] == "mfma"
+    assert abs(r["frac_binding"] - 2.0 * 2 * 256 * n * d / 13.4e-3 / 1e12 / 2500.0) < 1e-9 and r["frac_binding"] < r["frac"]
     # pairing off (or a library that does not report it): one pass per launch, the tail pass taken out of the average
     c1 = {"query_tile": 256, "n_passes": 12, "tail_query_tile": 128, "shader_mhz": 1500.0}
     r1 = bench.scan_roofline({"scan_ms": steps * (11 * 7.3 + 5.0), "tail_scan_ms": steps * 5.0}, c1, steps, n, d, k, "missing.json")
@@ -137,3 +140,21 @@ def test_scan_roofline_accounts_for_paired_unpaired_and_tail_launches():
     passes = {i // 256 for i in idx}
     assert {0, 1, 9, 10, 11} <= passes and len(idx) <= 32
     assert {i // 256 for i in bench.gate_queries(2837, c1, 32)} == {0, 6, 10, 11}
+
+
+def test_secondary_summary_flattens_the_other_legs_into_the_roofline_object():
+    """The driver's record keeps `roofline` in full and only the key names of the other legs: bench.secondary_summary puts their
+    headline scalars inside it; a leg that did not run (or failed) shows up as None, never as a KeyError."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {"passages_per_s": 35000.123456, "encoder_roofline": {"frac": 0.33}, "encoder": {"ms_per_step_kernels": 14.2, "steps": 10},
+           "splade_search": {"queries_per_s": 16000.0, "queries": 2837, "roofline": {"frac": 0.52},
+                             "full_list_gate": {"ids_and_fp32_scores_bit_exact": True}},
+           "config5": {"error": "boom"}, "parity_check": "pass",
+           "rerank": {"bert_large_shape": {"pairs_per_s": 5000.0, "roofline": {"frac": 0.1}}}}
+    sec = bench.secondary_summary(out)
+    assert sec["passages_per_s"] == 35000.1235 and sec["encoder_frac"] == 0.33 and sec["splade_full_list_gate"] is True
+    assert sec["config5_queries_per_s"] is None and sec["e5_large_frac"] is None and sec["rerank_bert_frac"] == 0.1
+    assert sec["rerank_deberta_pairs_per_s"] is None and sec["parity_check_all_legs"] == "pass" and sec["splade_queries"] == 2837
+    import json
+    assert len(json.dumps(sec)) < 2000
