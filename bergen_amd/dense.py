@@ -31,8 +31,9 @@ def encoder_backend(model):
     return "hip" if isinstance(model, BertEncoder) else "hf"
 
 
-def _native_encoder(model):
+def _native_encoder(model, require_native=None):
     """Move an HF BertModel-architecture encoder onto the hand-written gfx950 forward pass.
+    require_native (or BERGEN_AMD_REQUIRE_NATIVE=1 in the environment): raise instead of falling back to the HF module.
 
     On a GPU box every BERT-architecture checkpoint (all dense retrievers of the reference's
     config/retriever/*.yaml except repllama) runs on bergen_amd.BertEncoder; BERGEN_AMD_ENCODER=hf keeps the
@@ -51,11 +52,25 @@ def _native_encoder(model):
     else:
         why = BertEncoder.unsupported_reason(model)
     if why is None:
-        return BertEncoder.from_hf(model, device=torch.cuda.current_device())
+        try:
+            return BertEncoder.from_hf(model, device=torch.cuda.current_device())
+        except (ValueError, TypeError, KeyError) as exc:
+            # the configuration looked like one the kernels cover but the checkpoint's tensors do not fit it (names of a remote
+            # modelling file, a missing tensor): that is a reason to stay on HF, not a crash of a run that worked before
+            why = f"conversion of the checkpoint failed: {type(exc).__name__}: {exc}"
     name = getattr(getattr(model, "config", None), "_name_or_path", None) or type(model).__name__
+    if require_native is None:
+        require_native = os.environ.get("BERGEN_AMD_REQUIRE_NATIVE", "0") not in ("", "0", "false", "False")
+    if require_native:
+        raise RuntimeError(f"bergen_amd: encoder {name} cannot run on the HIP forward pass ({why}) and require_native is set: "
+                           f"refusing to fall back to the HF torch implementation")
     if (name, why) not in _warned:
         _warned.add((name, why))
         log.warning("bergen_amd: encoder %s stays on the HF torch implementation (%s); the HIP forward pass is NOT in use", name, why)
+    try:
+        model._bergen_amd_fallback_reason = why
+    except Exception:  # noqa: BLE001 — (an object that refuses attributes: the log line above is the record)
+        pass
     return model
 
 
@@ -209,18 +224,20 @@ class Dense(Retriever):
     """
 
     def __init__(self, model_name, max_len, pooler, similarity, prompt_q=None, prompt_d=None,
-                 query_encoder_name=None, model=None, query_encoder=None, tokenizer=None):
+                 query_encoder_name=None, model=None, query_encoder=None, tokenizer=None, require_native=None):
+        # require_native (not a reference kwarg; also BERGEN_AMD_REQUIRE_NATIVE=1): raise when an encoder cannot run on the HIP
+        # forward pass instead of keeping its HF torch module with a warning
         self.model_name = model_name
         if model is None or tokenizer is None:
             from transformers import AutoModel, AutoTokenizer
         if model is None:
             model = AutoModel.from_pretrained(self.model_name, torch_dtype=torch.float16, trust_remote_code=True)
-        self.model = _native_encoder(model)
+        self.model = _native_encoder(model, require_native)
         if query_encoder is not None:
-            self.query_encoder = _native_encoder(query_encoder)
+            self.query_encoder = _native_encoder(query_encoder, require_native)
         elif query_encoder_name:
             self.query_encoder = _native_encoder(AutoModel.from_pretrained(query_encoder_name, torch_dtype=torch.float16,
-                                                                           trust_remote_code=True))
+                                                                           trust_remote_code=True), require_native)
         else:
             self.query_encoder = self.model  # otherwise symmetric (dense.py:19-20)
         self.tokenizer = tokenizer if tokenizer is not None else AutoTokenizer.from_pretrained(self.model_name)
@@ -238,6 +255,11 @@ class Dense(Retriever):
     def backend(self):
         """'hip' when the document encoder runs on the hand-written kernels, 'hf' when it stayed on torch."""
         return encoder_backend(self.model)
+
+    @property
+    def fallback_reason(self):
+        """Why the document encoder is NOT on the HIP forward pass (None when it is)."""
+        return None if self.backend == "hip" else getattr(self.model, "_bergen_amd_fallback_reason", "injected torch module")
 
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):

@@ -71,6 +71,74 @@ def _cfg_get(config):
         (lambda k, dflt=None: getattr(config, k, dflt))
 
 
+def _nomic_hub_config(get):
+    """The configuration of the HUB form of NomicBert — what `AutoModel.from_pretrained("nomic-ai/nomic-embed-text-v1.5",
+    trust_remote_code=True)` (reference models/retrievers/dense.py:16) builds: the checkpoint's auto_map selects the remote
+    `NomicBertModel`, whose config class extends GPT2Config (n_embd / n_head / n_layer / n_inner / n_positions,
+    activation_function "swiglu", rotary_emb_*, *_bias flags, prenorm, use_rms_norm) — onto the fields the kernels need.  The remote
+    modelling file is not available offline; the field meanings follow the published config.json of that checkpoint and the weight
+    mapping transformers itself ships for it (conversion_mapping.py "nomic_bert").  Everything the HIP forward pass does not
+    compute is refused by name, so the caller falls back to the HF module instead of computing something else."""
+    def need(*names):
+        for n in names:
+            v = get(n)
+            if v is not None:
+                return v
+        raise ValueError(f"nomic_bert hub configuration without {' / '.join(names)}")
+    act = str(get("activation_function", "swiglu"))
+    if act != "swiglu":
+        raise ValueError(f"nomic_bert activation_function {act!r} (swiglu only: the gated SiLU feed-forward)")
+    if float(get("rotary_emb_fraction", 0.0) or 0.0) != 1.0:
+        raise ValueError(f"nomic_bert rotary_emb_fraction {get('rotary_emb_fraction')!r} (1.0 only: every head dim rotates; 0 = a position table)")
+    for flag in ("rotary_emb_interleaved", "prenorm", "use_rms_norm", "causal", "parallel_block"):
+        if get(flag, False):
+            raise ValueError(f"nomic_bert {flag} is set (the HIP forward pass is the post-LN, rotate-half, bidirectional block)")
+    if get("rotary_emb_scale_base", None):
+        raise ValueError("nomic_bert rotary_emb_scale_base is set (xpos scaling)")
+    if get("moe_every_n_layers", 0) or get("num_experts", 0) and int(get("num_experts")) > 1:
+        raise ValueError("nomic_bert mixture-of-experts feed-forward")
+    max_pos = int(need("n_positions", "max_position_embeddings"))
+    if get("rotary_scaling_factor", None):
+        # dynamic NTK scaling changes the rotary base only for sequences LONGER than max_trained_positions; up to there the plain
+        # table holds, so the encoder simply does not accept longer sequences (bh_encoder_forward: "sequence too long")
+        max_pos = min(max_pos, int(get("max_trained_positions", 2048) or 2048))
+    return dict(hidden_size=int(need("n_embd", "hidden_size")), num_attention_heads=int(need("n_head", "num_attention_heads")),
+                num_hidden_layers=int(need("n_layer", "num_hidden_layers")), intermediate_size=int(need("n_inner", "intermediate_size")),
+                hidden_act="silu", type_vocab_size=int(get("type_vocab_size", 2) or 0) or 1,
+                layer_norm_eps=float(need("layer_norm_epsilon", "layer_norm_eps")), position_offset=0,
+                rotary_theta=float(get("rotary_emb_base", 1000.0) or 1000.0), ffn_gated=1, max_position_embeddings_override=max_pos)
+
+
+def _nomic_hub_names(sd):
+    """Hub-form NomicBert tensor names -> transformers' native names, the mapping transformers itself applies when it loads that
+    checkpoint into its own class (conversion_mapping.py, "nomic_bert": encoder.layers -> layers, emb_ln -> embeddings.LayerNorm,
+    attn.out_proj -> self_attn.o_proj, fc11 -> up_proj, fc12 -> gate_proj, fc2 -> down_proj, norm1 / norm2 -> post_attention /
+    post_mlp layernorm, attn.Wqkv chunked along dim 0 into q | k | v).  A dict already in native form passes through."""
+    if not any(".attn.Wqkv." in k or k.startswith("emb_ln.") or ".mlp.fc11." in k for k in sd):
+        return sd
+    out = {}
+    for key, t in sd.items():
+        if key.startswith("encoder.layers."):
+            key = "layers." + key[len("encoder.layers."):]
+        if key.startswith("emb_ln."):
+            key = "embeddings.LayerNorm." + key[len("emb_ln."):]
+        for a, b in ((".attn.out_proj.", ".self_attn.o_proj."), (".mlp.fc11.", ".mlp.up_proj."), (".mlp.fc12.", ".mlp.gate_proj."),
+                     (".mlp.fc2.", ".mlp.down_proj."), (".norm1.", ".post_attention_layernorm."), (".norm2.", ".post_mlp_layernorm.")):
+            if a in key:
+                key = key.replace(a, b)
+                break
+        if ".attn.Wqkv." in key:
+            if t.shape[0] % 3:
+                raise ValueError(f"{key}: {tuple(t.shape)} is not q | k | v stacked along dim 0")
+            for part, piece in zip(("q_proj", "k_proj", "v_proj"), torch.chunk(t, 3, dim=0)):
+                out[key.replace(".attn.Wqkv.", f".self_attn.{part}.")] = piece
+            continue
+        if ".attn.rotary_emb." in key:
+            continue  # (inv_freq buffers: a function of the base, rebuilt in the library)
+        out[key] = t
+    return out
+
+
 def canonical_config(config):
     """HF config of a BERT-family model -> the fields the kernels need, under BERT's names.  Raises ValueError with the
     reason when the architecture is outside what the HIP forward pass computes."""
@@ -119,21 +187,27 @@ def canonical_config(config):
     elif mt == "nomic_bert":
         # NomicBert (config/retriever/nomic-embed-text-v1.5.yaml; transformers modeling_nomic_bert.py): BERT's post-LN block with
         # rotary positions instead of a position table, bias-free projections and a gated SiLU feed-forward
-        rope = get("rope_parameters") or {}
-        rope_get = rope.get if isinstance(rope, dict) else (lambda k, dflt=None: getattr(rope, k, dflt))
-        rtype = rope_get("rope_type", "default") or "default"
-        if rtype != "default":
-            raise ValueError(f"nomic_bert rope_type {rtype!r} (default only)")
-        theta = float(rope_get("rope_theta", None) or get("rope_theta", None) or get("rotary_emb_base", None) or 1000.0)
-        if str(get("hidden_act", "silu")) != "silu":
-            raise ValueError(f"nomic_bert hidden_act {get('hidden_act')!r} (silu only)")
-        hd_cfg = get("head_dim", None)
-        if hd_cfg not in (None, int(get("hidden_size")) // int(get("num_attention_heads"))):
-            raise ValueError(f"nomic_bert head_dim {hd_cfg} != hidden_size / num_attention_heads")
-        c = dict(hidden_size=get("hidden_size"), num_attention_heads=get("num_attention_heads"),
-                 num_hidden_layers=get("num_hidden_layers"), intermediate_size=get("intermediate_size"),
-                 hidden_act="silu", type_vocab_size=get("type_vocab_size", 2), layer_norm_eps=get("layer_norm_eps", 1e-12),
-                 position_offset=0, rotary_theta=theta, ffn_gated=1)
+        if get("n_embd") is not None or get("activation_function") is not None or get("rotary_emb_fraction") is not None:
+            c = _nomic_hub_config(get)
+        else:
+            rope = get("rope_parameters") or {}
+            rope_get = rope.get if isinstance(rope, dict) else (lambda k, dflt=None: getattr(rope, k, dflt))
+            rtype = rope_get("rope_type", "default") or "default"
+            if rtype != "default":
+                raise ValueError(f"nomic_bert rope_type {rtype!r} (default only)")
+            theta = float(rope_get("rope_theta", None) or get("rope_theta", None) or get("rotary_emb_base", None) or 1000.0)
+            if str(get("hidden_act", "silu")) != "silu":
+                raise ValueError(f"nomic_bert hidden_act {get('hidden_act')!r} (silu only)")
+            for field in ("hidden_size", "num_attention_heads", "num_hidden_layers", "intermediate_size"):
+                if get(field) is None:
+                    raise ValueError(f"nomic_bert configuration without {field} (neither transformers' native form nor the hub's)")
+            hd_cfg = get("head_dim", None)
+            if hd_cfg not in (None, int(get("hidden_size")) // int(get("num_attention_heads"))):
+                raise ValueError(f"nomic_bert head_dim {hd_cfg} != hidden_size / num_attention_heads")
+            c = dict(hidden_size=get("hidden_size"), num_attention_heads=get("num_attention_heads"),
+                     num_hidden_layers=get("num_hidden_layers"), intermediate_size=get("intermediate_size"),
+                     hidden_act="silu", type_vocab_size=get("type_vocab_size", 2), layer_norm_eps=get("layer_norm_eps", 1e-12),
+                     position_offset=0, rotary_theta=theta, ffn_gated=1)
     elif mt == "distilbert":
         c = dict(hidden_size=get("dim"), num_attention_heads=get("n_heads"), num_hidden_layers=get("n_layers"),
                  intermediate_size=get("hidden_dim"), hidden_act=get("activation", "gelu"), type_vocab_size=1,
@@ -150,7 +224,8 @@ def canonical_config(config):
         pet = get("position_embedding_type", "absolute")
         if pet not in (None, "absolute"):
             raise ValueError(f"position_embedding_type {pet!r}")
-    c.update(vocab_size=get("vocab_size"), max_position_embeddings=get("max_position_embeddings"), model_type=mt)
+    c.update(vocab_size=get("vocab_size"), max_position_embeddings=c.pop("max_position_embeddings_override", None) or get("max_position_embeddings"),
+             model_type=mt)
     if c["hidden_act"] != ("silu" if c.get("ffn_gated") else "gelu"):
         raise ValueError(f"hidden_act {c['hidden_act']!r} (erf-GELU only)")
     d, nh = int(c["hidden_size"]), int(c["num_attention_heads"])
@@ -170,6 +245,14 @@ def canonical_state_dict(cfg, state_dict):
     narrower than 64 dims (see bh_encoder_config.head_dim).  Returns {name: tensor}."""
     mt, d, nh, hd = cfg["model_type"], int(cfg["hidden_size"]), int(cfg["num_attention_heads"]), int(cfg["head_dim"])
     out = {}
+    if mt == "nomic_bert":
+        stripped = {}
+        for name, t in state_dict.items():
+            for pre in ("nomic_bert.", "bert.", "model."):
+                if name.startswith(pre):
+                    name = name[len(pre):]
+            stripped[name] = t
+        state_dict = _nomic_hub_names(stripped)
     for name, t in state_dict.items():
         key = name
         for pre in ("bert.", "distilbert.", "roberta.", "deberta.", "nomic_bert.", "model."):
@@ -227,6 +310,11 @@ def canonical_state_dict(cfg, state_dict):
                 raise ValueError(f"nomic_bert state dict lacks layers.{l}.mlp.gate_proj / up_proj")
             # rows interleaved (gate j, up j): one GEMM then yields (gate, up) column pairs, folded in its epilogue
             out[pre + "intermediate.dense.weight"] = torch.stack([gate.detach().float(), up.detach().float()], dim=1).reshape(2 * f, d)
+            gb, ub = out.pop(pre + "mlp.gate_proj.bias", None), out.pop(pre + "mlp.up_proj.bias", None)
+            if gb is not None or ub is not None:  # (mlp_fc1_bias checkpoints: interleaved like the rows they belong to)
+                gb = torch.zeros(f) if gb is None else gb.detach().float()
+                ub = torch.zeros(f) if ub is None else ub.detach().float()
+                out[pre + "intermediate.dense.bias"] = torch.stack([gb, ub], dim=1).reshape(2 * f)
             for name, n in (("attention.self.query", d), ("attention.self.key", d), ("attention.self.value", d),
                             ("attention.output.dense", d), ("intermediate.dense", 2 * f), ("output.dense", d)):
                 out.setdefault(pre + name + ".bias", torch.zeros(n, dtype=torch.float16))

@@ -68,7 +68,8 @@ class Retrieve:
                  search_rank=None,
                  search_world=None,
                  search_results="all",
-                 loader="threads"):
+                 loader="threads",
+                 require_native=False):
         # encode_rank / encode_world: multi-GPU encoding.  The reference's only multi-GPU mechanism is
         # torch.nn.DataParallel around the encoder (dense.py:32-35: scatter inputs, re-broadcast every weight and
         # gather [B, T, d] outputs to GPU 0 on every forward).  Here each of `encode_world` processes (one per GPU)
@@ -119,6 +120,12 @@ class Retrieve:
         # instantiate model (reference: hydra instantiate, retrieve.py:34).  rag.py hands over an OmegaConf DictConfig;
         # config.instantiate converts that (and any other mapping) and passes an already-built plug-in object through
         self.model = instantiate(init_args)
+        # require_native: a run on an architecture the HIP forward pass does not cover (gte-*-v1.5, jina-v2, repllama ...) keeps its
+        # HF torch encoder with one warning by default; with this switch the stage refuses to start instead (the plug-ins take the
+        # same switch themselves — Dense(require_native=True), BERGEN_AMD_REQUIRE_NATIVE=1 — and then fail at load time)
+        if require_native and getattr(self.model, "backend", "hip") != "hip":
+            raise RuntimeError(f"bergen_amd.Retrieve(require_native=True): the encoder of {getattr(self.model, 'model_name', self.model)!r} "
+                               f"runs on the HF torch implementation ({getattr(self.model, 'fallback_reason', None) or 'see the warning above'})")
         # host-side thread pools (torch intra-op, OpenMP, the tokenizer's rayon pool) follow the container's CPU quota, not the host's
         # CPU count (utils.cpu_budget: a GPU pod that shows 256 CPUs under a quota of 16 gets frozen by the CFS throttle otherwise);
         # explicit OMP_NUM_THREADS / RAYON_NUM_THREADS settings of the user win

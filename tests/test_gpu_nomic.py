@@ -143,3 +143,36 @@ def test_dense_from_a_nomic_checkpoint_directory_matches_the_reference_dense(tmp
     d = embs["doc"] / np.linalg.norm(embs["doc"], axis=1, keepdims=True)
     assert np.abs(q @ d.T - z["ref_cosine_fp32"]).max() < 5e-3
     assert np.array_equal(np.argmax(q @ d.T, axis=1), np.argmax(z["ref_cosine_fp32"], axis=1))
+
+
+def test_hub_form_checkpoint_runs_on_the_hip_path_with_identical_embeddings():
+    """The hub form of nomic-embed-text-v1.5 (remote-code tensor names attn.Wqkv / mlp.fc11 / fc12 / fc2 / norm1 / norm2 / emb_ln, GPT2-style
+    config: what reference dense.py:16 builds with trust_remote_code=True) engages the same kernels as transformers' native form: the
+    committed nomic_tiny fixture with its tensors renamed gives the SAME embeddings, bit for bit, and a model object carrying that
+    config + state dict is accepted by Dense's selection (backend 'hip')."""
+    from bergen_amd import BertEncoder, dense
+    from test_nomic_hub import hub_config, to_hub_names
+    cfg, sd, z = load_tiny()
+    native = _native(dict(cfg, model_type="nomic_bert"), sd)
+    hub = BertEncoder(hub_config(cfg), {k: torch.from_numpy(np.asarray(v)) for k, v in to_hub_names(sd).items()}, device=0)
+    kw = {k: torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "token_type_ids")}
+    a, b = native.encode_pooled(kw, "mean"), hub.encode_pooled(kw, "mean")
+    assert torch.equal(a, b)
+    ref = nomic_oracle.encode(sd, cfg, z["input_ids"], z["attention_mask"], z["token_type_ids"])
+    _check_embeddings(b, ref, "hub-form NomicBert vs oracle")
+    native.close()
+    hub.close()
+
+    class RemoteModel:  # what the remote class hands over: .config + .state_dict()
+        class config:
+            pass
+
+        def state_dict(self):
+            return {k: torch.from_numpy(np.asarray(v)) for k, v in to_hub_names(sd).items()}
+
+    for k, v in hub_config(cfg).items():
+        setattr(RemoteModel.config, k, v)
+    enc = dense._native_encoder(RemoteModel(), require_native=True)
+    assert dense.encoder_backend(enc) == "hip"
+    assert torch.equal(enc.encode_pooled(kw, "mean"), a)
+    enc.close()
