@@ -9,7 +9,9 @@ P@1 / recall@k are averaged over the queries present in BOTH the run and the qre
 
 The reference computes the two measures with ``pytrec_eval`` (third-party, unpinned, not installed in this
 image); they are restated here with trec_eval's definitions:
-  * documents are ranked by score descending, ties by document id descending (trec_eval's comp_sim_docno);
+  * documents are ranked by score descending, ties by document id descending (trec_eval's comp_sim_docno); the score is compared
+    as a C float (trec_eval stores `float sim`; pytrec_eval narrows the Python float on the way in), so two scores that differ
+    only beyond fp32 tie;
   * relevant = judged with relevance >= 1;
   * P_1 = [top-ranked document is relevant];  recall_k = (relevant documents in the top k) / (relevant documents).
 """
@@ -35,6 +37,14 @@ def max_passage_run(query_ids, doc_ids, scores):
     return run
 
 
+def _as_c_float(x):
+    import struct
+    try:
+        return struct.unpack("f", struct.pack("f", float(x)))[0]
+    except OverflowError:  # beyond fp32's range: +-inf, as a C cast gives
+        return float("inf") if x > 0 else float("-inf")
+
+
 def ranking_metrics(run, qrel, top_k=5):
     """Mean P_1 and recall_{top_k} over the queries in both `run` and `qrel` (trec_eval definitions)."""
     p1_sum = rec_sum = 0.0
@@ -44,8 +54,8 @@ def ranking_metrics(run, qrel, top_k=5):
         if judged is None:
             continue
         rel = {d for d, r in judged.items() if r >= 1}
-        ranked = sorted(docs.items(), key=lambda kv: kv[0], reverse=True)  # ties: document id descending ...
-        ranked.sort(key=lambda kv: kv[1], reverse=True)                     # ... under a stable sort by score
+        ranked = sorted(docs.items(), key=lambda kv: str(kv[0]).encode(), reverse=True)  # ties: document id descending (strcmp: bytes) ...
+        ranked.sort(key=lambda kv: _as_c_float(kv[1]), reverse=True)                      # ... under a stable sort by the fp32 score
         top = [d for d, _ in ranked]
         p1_sum += 1.0 if top and top[0] in rel else 0.0
         rec_sum += (sum(1 for d in top[:top_k] if d in rel) / len(rel)) if rel else 0.0

@@ -18,7 +18,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "liboracle.so")
-        srcs = [os.path.join(_HERE, f) for f in ("flat_ip_oracle.c", "sparse_oracle.c")]
+        srcs = [os.path.join(_HERE, f) for f in ("flat_ip_oracle.c", "sparse_oracle.c", "trec_eval_oracle.c")]
         if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs):
             build()
         _LIB = ctypes.CDLL(path)
@@ -135,3 +135,27 @@ def sparse_canonical_search(indptr, terms, weights, vocab, q, k, id_offset=0):
                                          ctypes.c_int32(vocab), _p(qb), ctypes.c_int64(nq), ctypes.c_int(k),
                                          ctypes.c_int64(id_offset), _p(out_s), _p(out_i))
     return out_s, out_i
+
+
+def trec_eval_mean_metrics(run, qrel, top_k=5):
+    """utils.eval_retrieval_kilt's two numbers (utils.py:275,294-297) through trec_eval_oracle.c: per topic of `run` that `qrel` also
+    holds, P_1 and recall_{top_k} by trec_eval's rules; means over those topics, max(1, n) in the denominator like the reference.
+    run: {q_id: {doc_id: score}}, qrel: {q_id: {doc_id: int relevance}}.  Returns ({'P_1': .., 'recall_k': ..}, n_topics)."""
+    f = lib().oracle_trec_eval_topic
+    p_sum = r_sum = 0.0
+    n = 0
+    for q_id, docs in run.items():
+        judged = qrel.get(q_id)
+        if judged is None:
+            continue
+        dn = [str(d).encode() for d in docs]
+        sims = (ctypes.c_double * max(1, len(dn)))(*[float(v) for v in docs.values()])
+        jn = [str(d).encode() for d in judged]
+        rels = (ctypes.c_int * max(1, len(jn)))(*[int(v) for v in judged.values()])
+        p1, rk = ctypes.c_double(0), ctypes.c_double(0)
+        f((ctypes.c_char_p * max(1, len(dn)))(*dn), sims, ctypes.c_int(len(dn)), (ctypes.c_char_p * max(1, len(jn)))(*jn), rels,
+          ctypes.c_int(len(jn)), ctypes.c_int(int(top_k)), ctypes.byref(p1), ctypes.byref(rk))
+        p_sum += p1.value
+        r_sum += rk.value
+        n += 1
+    return {"P_1": p_sum / max(1, n), f"recall_{top_k}": r_sum / max(1, n)}, n
