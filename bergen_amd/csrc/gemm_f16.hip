@@ -45,6 +45,8 @@ int g_full_line_stores = 1;  // bh_set_option "gemm_full_line_stores" (default o
 
 void bh_gemm_set_gelu_nontemporal(int on) { g_gelu_nontemporal = on != 0; }
 void bh_gemm_set_full_line_stores(int level) { g_full_line_stores = level < 0 ? 0 : level > 2 ? 2 : level; }
+int g_static_prio = 0;  // bh_set_option "gemm_static_prio": PST bit 64 of the persistent kernel on its full-line-store paths
+void bh_gemm_set_static_prio(int on) { g_static_prio = on != 0; }
 
 void bh_gemm_set_stagger(int phases, int pct) {
     if (phases >= 0) g_stagger_phases = phases;
@@ -168,7 +170,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         if (a.M % 256 || a.N % 256 || a.residual || a.gelu || !(a.bias && a.bias_mode == 1) || a.c_block_rows || g_swap_b != 0)
             return hipErrorInvalidValue;
         // (non-temporal burst, like the GELU output; level 2 of gemm_full_line_stores, experimental: 64-byte row pieces through LDS)
-        return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? 35 : 3, stream);
+        return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? (g_static_prio ? 99 : 35) : 3, stream);
     }
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);
@@ -205,6 +207,7 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     // level 2 (EXPERIMENTAL until its bit-identity test has run on a GPU): the blocked V^T output too — bias per row, rows of 64 columns
     // that are whole 128-byte lines already, 8 of them = 1 KiB contiguous per store instruction
     if (persist && g_full_line_stores >= 2 && a.c_block_rows && pst == 1 && (epi == 0 || epi == BH_EPI_BIAS_ROW)) pst_eff = pst | 32;
+    if (persist && g_static_prio && (pst_eff == 33 || pst_eff == 35)) pst_eff |= 64;
     if (variant < 1 || variant > 5) return hipErrorInvalidValue;
     // interior region with the fast kernel, edge strips with the generic one
     const int bm = kTile[variant].bm, bn = kTile[variant].bn;

@@ -55,6 +55,13 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int ql = lane & 31, h = lane >> 5;
+    // PST bit 64 = STATIC PRIORITY for the younger half of the workgroup (option gemm_static_prio): the two waves of a SIMD are
+    // arbitrated by priority, then age, and the second-dispatched half (waves 4-7) loses every VALU / LDS issue slot to its older
+    // partner at the start of each segment; one s_setprio 1 for that half, no flips inside the loop (cdna_hip_programming.md T5,
+    // static form).  The branch is on a wave-uniform value: s_setprio ignores EXEC.
+    if constexpr ((PST & 64) != 0) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
 
     // ---- this block's tiles: XCD x (= block % 8) owns a contiguous range of the (m-major, n-minor) tile order;
     // its blocks j = block / 8 take tiles start + j, start + j + G/8, ... so that the XCD's CUs work on

@@ -165,7 +165,8 @@ struct bh_index {
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> events;
     bh_counters counters{};
-    int last_shape_nq = -1, last_shape_k = -1;  // the previous search's shape and GPU time: when to stop sleeping between polls (spin_sync)
+    int last_shape_nq = -1, last_shape_k = -1;  // the previous search's shape (queries, k, rows searched: search_large_k runs range views) and
+    int64_t last_shape_rows = -1;                // GPU time: when to stop sleeping between polls (spin_sync)
     double last_shape_ms = 0.0;
     int opt_override[sizeof(g_option_defs) / sizeof(g_option_defs[0])];  // kUnset = inherit (bh_index_set_option)
 
@@ -196,20 +197,23 @@ Options effective_options(const bh_index* ix) {
 // every search over a whole corpus) and the wake-up costs 1-2 ms, 2 % of the headline search.  A full-speed spin for the
 // whole search would hold a host core per rank (8 ranks per node next to tokenizer workers), so: spin for the first
 // 200 us (short searches), then poll every 50 us with the thread asleep in between (wake-up latency <= ~0.1 ms on an idle host, a
-// few per cent of a core) — until 80 % of `expect_ms` (the duration of the handle's previous search of this shape) have gone by:
-// from there the thread spins without sleeping.  On a host loaded by other tenants a 50 us sleep can come back milliseconds late
+// few per cent of a core) — between 80 % and 130 % of `expect_ms` (the duration of the handle's previous search of this shape over
+// this many rows) the thread spins without sleeping.  On a host loaded by other tenants a 50 us sleep can come back milliseconds late
 // (round 4: a 97 ms step around 87 ms of kernels on a box at load average 100), and only the last sleep of a search costs
-// anything.  The blocking wait takes over after 10 s.
+// anything.  The window is bounded: a search that runs LONGER than the last one (a fall-back pass, the GPU shared with an encoder
+// or with other ranks) goes back to 50 us sleeps past 130 % instead of holding a host core for up to 10 s — eight ranks spinning
+// under a 16-CPU quota are the CFS throttling utils.cpu_budget exists to avoid.  The blocking wait takes over after 10 s.
 hipError_t spin_sync(hipStream_t st, double expect_ms = 0.0) {
     const auto t0 = std::chrono::steady_clock::now();
     const auto spin_from = std::chrono::microseconds((long long)(expect_ms * 800.0));
+    const auto spin_until = std::chrono::microseconds((long long)(expect_ms * 1300.0));
     for (unsigned n = 0;; ++n) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
         if ((n & 15u) != 15u) continue;
         const auto waited = std::chrono::steady_clock::now() - t0;
         if (waited > std::chrono::seconds(10)) return hipStreamSynchronize(st);
-        if (waited > std::chrono::microseconds(200) && (expect_ms <= 0.0 || waited < spin_from))
+        if (waited > std::chrono::microseconds(200) && (expect_ms <= 0.0 || waited < spin_from || waited > spin_until))
             std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
@@ -361,6 +365,8 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "gemm_stagger_phases") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");
         bh_gemm_set_stagger((int)value, -1);
+    } else if (s == "gemm_static_prio") {
+        bh_gemm_set_static_prio((int)value);
     } else if (s == "gemm_full_line_stores") {
         if (value < 0 || value > 2) return fail(BH_EINVAL, "gemm_full_line_stores must be 0, 1 or 2 (2 = 1 + the experimental set: blocked V^T output, gated fold)");
         bh_gemm_set_full_line_stores((int)value);
@@ -777,7 +783,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         for (int p = std::max(0, n_pass - 2); p < n_pass; ++p) HIP_TRY(hipStreamWaitEvent(st, ix->event(2 + 4 * p + 3), 0));
     }
     HIP_TRY(hipEventRecord(ev_end, st));
-    HIP_TRY(spin_sync(st, (ix->last_shape_nq == nq && ix->last_shape_k == k) ? ix->last_shape_ms : 0.0));
+    HIP_TRY(spin_sync(st, (ix->last_shape_nq == nq && ix->last_shape_k == k && ix->last_shape_rows == ix->n_rows) ? ix->last_shape_ms : 0.0));
     // ---- exactness: queries the certificate could not prove go through the exact scan (certify.hip)
     int64_t n_uncert = 0, n_filter_passes = 0, n_filter_rows = 0;
     double exact_ms = 0;
@@ -949,6 +955,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     c.total_ms = tot + exact_ms;
     ix->last_shape_nq = nq;
     ix->last_shape_k = k;
+    ix->last_shape_rows = ix->n_rows;
     ix->last_shape_ms = tot;
     c.algorithmic_bytes = alg_bytes;
     c.uncertified_queries = n_uncert;

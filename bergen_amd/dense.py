@@ -159,22 +159,36 @@ def fast_tokenize(tokenizer, texts, max_len):
         backend = getattr(tokenizer, "backend_tokenizer", None)
         if backend is None or not getattr(tokenizer, "is_fast", False) or not hasattr(tokenizer, "set_truncation_and_padding"):
             return None
+        if len(texts) == 0:
+            return None  # (the HF call answers an empty batch; nothing to gain here)
         names = list(getattr(tokenizer, "model_input_names", ["input_ids", "token_type_ids", "attention_mask"]))
         pad_id = getattr(tokenizer, "pad_token_id", None)
-        ragged = (pad_id is not None and getattr(tokenizer, "padding_side", "right") == "right"
-                  and getattr(tokenizer, "_bergen_amd_ragged_ok", True))
         # Ragged form (right padding with a known pad id): the backend only truncates; the padded [B, T] matrix, the mask and
         # the all-zero type ids of single sequences are built here with numpy from the ids alone.  The Python objects of a batch
         # (every id of every field of every Encoding becomes a Python int, under the GIL) are what the tokeniser THREADS of
         # the encode stage fight the forward-pass thread over: ids-only without pad tokens is a fifth of the padded three-field form.
+        # Ragged or padded is decided ONCE per tokenizer, under the lock, from a probe encoding (a single text must come back with
+        # all-zero type ids — true of every BERT / RoBERTa post-processor template) and never flips afterwards: the backend's
+        # configuration is then the same in every call, so no thread reconfigures it while another one encodes (PyO3 "Already
+        # borrowed"), and no thread can be handed unpadded rows by a configuration another thread chose.
         with _TOKENIZER_CONFIG_LOCK:
+            ragged = getattr(tokenizer, "_bergen_amd_ragged_ok", None)
+            if ragged is None:
+                ragged = pad_id is not None and getattr(tokenizer, "padding_side", "right") == "right"
+                if ragged:
+                    probe = backend.encode("a", add_special_tokens=True)
+                    ragged = not any(probe.type_ids)
+                try:
+                    tokenizer._bergen_amd_ragged_ok = bool(ragged)
+                except Exception:  # noqa: BLE001 — (an object that refuses attributes: padded form, which needs no memory)
+                    ragged = False
             tokenizer.set_truncation_and_padding(padding_strategy=PaddingStrategy.DO_NOT_PAD if ragged else PaddingStrategy.LONGEST,
                                                  truncation_strategy=TruncationStrategy.LONGEST_FIRST,
                                                  max_length=max_len, stride=0, pad_to_multiple_of=None, padding_side=None)
         encode = getattr(backend, "encode_batch_fast", None) or backend.encode_batch  # (_fast: no offsets, the fields used here are the same)
         encs = encode(list(texts), add_special_tokens=True)
         out = {}
-        if ragged and encs and (not any(encs[0].type_ids) and not any(encs[-1].type_ids)):
+        if ragged:
             import itertools
             rows = [e.ids for e in encs]
             lens = np.fromiter((len(r) for r in rows), dtype=np.int64, count=len(rows))
@@ -188,16 +202,6 @@ def fast_tokenize(tokenizer, texts, max_len):
             if "attention_mask" in names:
                 out["attention_mask"] = torch.from_numpy(mask.astype(np.int64))
             return BatchEncoding(out)
-        if ragged:  # (type ids that are not all zero for single texts: keep the backend's own fields, padded by the backend —
-            # from now on for every call on this tokenizer: the configuration must not flip between threads' calls)
-            try:
-                tokenizer._bergen_amd_ragged_ok = False
-            except Exception:  # noqa: BLE001
-                pass
-            with _TOKENIZER_CONFIG_LOCK:
-                tokenizer.set_truncation_and_padding(padding_strategy=PaddingStrategy.LONGEST, truncation_strategy=TruncationStrategy.LONGEST_FIRST,
-                                                     max_length=max_len, stride=0, pad_to_multiple_of=None, padding_side=None)
-            encs = encode(list(texts), add_special_tokens=True)
         if "input_ids" in names or True:
             out["input_ids"] = torch.from_numpy(np.array([e.ids for e in encs], dtype=np.int64))
         if "token_type_ids" in names:

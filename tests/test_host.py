@@ -179,6 +179,25 @@ def test_fast_tokenize_equals_the_hf_call():
         for k in want.keys():
             assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), (k, max_len)
     assert fast_tokenize(object(), texts, 16) is None  # not a fast tokenizer: the caller falls back to the HF call
+    # the ragged / padded form is decided once per tokenizer and never flips: an empty batch decides nothing and is
+    # left to the HF call; many threads tokenising at once never see another thread's configuration
+    assert tok._bergen_amd_ragged_ok is True
+    assert fast_tokenize(tok, [], 16) is None and tok._bergen_amd_ragged_ok is True
+    import concurrent.futures
+    want = tok(texts, padding="longest", truncation="longest_first", max_length=32, return_tensors="pt")
+    with concurrent.futures.ThreadPoolExecutor(8) as pool:
+        outs = list(pool.map(lambda _: fast_tokenize(tok, texts, 32), range(48)))
+    assert all(o is not None and all(torch.equal(o[k], want[k]) for k in want.keys()) for o in outs)
+    # a tokenizer whose single-text encodings carry non-zero type ids stays on the padded form, for good
+    tok2, _ = ut1_fixture.tokenizer_for([str(w) for w in z["words"]])
+    from tokenizers import processors
+    tok2.backend_tokenizer.post_processor = processors.TemplateProcessing(
+        single="[CLS]:1 $A:1 [SEP]:1", pair="[CLS]:1 $A:1 [SEP]:1 $B:1 [SEP]:1",
+        special_tokens=[("[CLS]", tok2.cls_token_id), ("[SEP]", tok2.sep_token_id)])
+    got2 = fast_tokenize(tok2, texts[:5], 16)
+    want2 = tok2(texts[:5], padding="longest", truncation="longest_first", max_length=16, return_tensors="pt")
+    assert tok2._bergen_amd_ragged_ok is False and all(torch.equal(got2[k], want2[k]) for k in want2.keys())
+    assert int(got2["token_type_ids"].max()) == 1
 
 
 def test_piecewise_tokeniser_threads_give_the_whole_batch_result(monkeypatch):
