@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(512, 2) bh_attention_rel_kernel(BhAttnArgs a) 
 }
 
 namespace {
-int g_rel_wide_stores = 0;  // bh_set_option "attention_rel_wide_stores": EXPERIMENTAL until its parity test has run on a GPU (round 5)
+int g_rel_wide_stores = 1;  // bh_set_option "attention_rel_wide_stores" (default on since round 5: bit-identical to the 8-byte stores, tests/test_gpu_store_paths.py)
 }
 void bh_attention_rel_set_wide_stores(int on) { g_rel_wide_stores = on != 0; }
 

@@ -174,7 +174,6 @@ hipError_t bh_gemm_probe_permlane(hipStream_t stream);
 int bh_gemm_swap_mode();
 void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of the first round of blocks
 void bh_gemm_set_gelu_nontemporal(int on);      // A/B knob: non-temporal stores of the bias + GELU output (default on)
-void bh_gemm_set_static_prio(int on);           // persistent kernel: s_setprio 1 for waves 4-7, once (gemm_f16_persist.h PST bit 64)
 void bh_gemm_set_full_line_stores(int on);      // persistent kernel: outputs through LDS as whole 128-byte lines (gemm_f16_persist.h PST bit 32)
 
 struct BhAttnArgs {
@@ -203,7 +202,7 @@ struct BhAttnArgs {
     int win_lds_off = 0;            // filled by the launcher: byte offset of the waves' position windows in LDS (attention_rel.hip, WIN)
     int wide_stores = 0;            // filled by the launcher (attention_rel.hip): context rows as 16-byte stores
 };
-void bh_attention_rel_set_wide_stores(int on);  // option "attention_rel_wide_stores" (experimental: default off)
+void bh_attention_rel_set_wide_stores(int on);  // option "attention_rel_wide_stores" (default on since round 5; 0 = 8-byte stores)
 hipError_t bh_launch_attention(const BhAttnArgs& a, int batch, int n_heads, int max_len, hipStream_t stream);
 hipError_t bh_launch_attention_bucketed(const BhAttnArgs& a, const int* seq_idx_dev, int n_short, int n_long,
                                         int max_len_long, int n_heads, hipStream_t stream, int short_max = 128,

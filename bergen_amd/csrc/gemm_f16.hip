@@ -38,15 +38,13 @@ int g_swap_b = -1;  // -1 unknown, 0 documented direction, 1 the other one
 int g_stagger_phases = 0, g_stagger_pct = 100;  // bench knobs (bh_set_option "gemm_stagger_phases" / "_pct")
 int g_gelu_nontemporal = 1;  // bh_set_option "gemm_gelu_nontemporal": the FFN-up (bias + GELU) output bypasses the caches (measured +8 % on that
                              // GEMM in round 1, when one batch's 421 MB were written at once; an A/B knob since the micro-batches halved that)
-int g_full_line_stores = 1;  // bh_set_option "gemm_full_line_stores" (default on): the persistent kernel's row-major outputs leave as whole
+int g_full_line_stores = 2;  // bh_set_option "gemm_full_line_stores" (default 2 = every output path; 1 = the row-major outputs only, 0 = off): the persistent kernel's row-major outputs leave as whole
                              // 128-byte lines through LDS (gemm_f16_persist.h PST bit 32) — bit-identical, BERT-base forward 15.60 -> 14.55 ms
                              // per 512 passages in the same process (profiles/r04t_ab_full_line_stores.txt)
 }
 
 void bh_gemm_set_gelu_nontemporal(int on) { g_gelu_nontemporal = on != 0; }
 void bh_gemm_set_full_line_stores(int level) { g_full_line_stores = level < 0 ? 0 : level > 2 ? 2 : level; }
-int g_static_prio = 0;  // bh_set_option "gemm_static_prio": PST bit 64 of the persistent kernel on its full-line-store paths
-void bh_gemm_set_static_prio(int on) { g_static_prio = on != 0; }
 
 void bh_gemm_set_stagger(int phases, int pct) {
     if (phases >= 0) g_stagger_phases = phases;
@@ -169,8 +167,8 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     if (a.swiglu) {  // gated feed-forward fold: whole 256x256 tiles on the persistent kernel, bias per (interleaved) column
         if (a.M % 256 || a.N % 256 || a.residual || a.gelu || !(a.bias && a.bias_mode == 1) || a.c_block_rows || g_swap_b != 0)
             return hipErrorInvalidValue;
-        // (non-temporal burst, like the GELU output; level 2 of gemm_full_line_stores, experimental: 64-byte row pieces through LDS)
-        return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? (g_static_prio ? 99 : 35) : 3, stream);
+        // (non-temporal burst, like the GELU output; level 2 of gemm_full_line_stores: 64-byte row pieces through LDS)
+        return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? 35 : 3, stream);
     }
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);
@@ -204,10 +202,10 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
     int pst_eff = pst;
     if (persist && g_full_line_stores && !a.c_block_rows && (pst == 1 || pst == 3) && (epi == 0 || epi == BH_EPI_BIAS_COL || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU)))
         pst_eff = pst | 32;
-    // level 2 (EXPERIMENTAL until its bit-identity test has run on a GPU): the blocked V^T output too — bias per row, rows of 64 columns
+    // level 2 (the default since round 5: bit-identical to level 1, tests/test_gpu_store_paths.py; BERT-base forward 14.40 -> 14.29 ms, NomicBert
+    // 20.49 -> 19.15 ms, profiles/r05a_ab_full_line_level2.txt): the blocked V^T output too — bias per row, rows of 64 columns
     // that are whole 128-byte lines already, 8 of them = 1 KiB contiguous per store instruction
     if (persist && g_full_line_stores >= 2 && a.c_block_rows && pst == 1 && (epi == 0 || epi == BH_EPI_BIAS_ROW)) pst_eff = pst | 32;
-    if (persist && g_static_prio && (pst_eff == 33 || pst_eff == 35)) pst_eff |= 64;
     if (variant < 1 || variant > 5) return hipErrorInvalidValue;
     // interior region with the fast kernel, edge strips with the generic one
     const int bm = kTile[variant].bm, bn = kTile[variant].bn;

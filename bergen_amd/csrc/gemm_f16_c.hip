@@ -32,7 +32,6 @@ int n_cu() {
         case BH_EPI_BIAS_COL | BH_EPI_SWIGLU:                                                                     \
             if (P == 3) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 3>(a, n_cu(), s);          \
             if (P == 35) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 35>(a, n_cu(), s);        \
-            if (P == 99) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 99>(a, n_cu(), s);        \
             break;                                                                                                \
     }                                                                                                             \
     return hipErrorNotSupported;
@@ -43,8 +42,6 @@ hipError_t bh_gemm_persist(const BhGemmArgs& a, int epi, int pst, hipStream_t s)
     if (pst == 3) { BH_PERSIST_EPI(3) }
     if (pst == 33) { BH_PERSIST_EPI(33) }  // 1 + full-line stores through LDS (gemm_f16_persist.h PST bit 32)
     if (pst == 35) { BH_PERSIST_EPI(35) }  // 3 + the same
-    if (pst == 97) { BH_PERSIST_EPI(97) }  // 33 + static priority for waves 4-7 (PST bit 64; option gemm_static_prio)
-    if (pst == 99) { BH_PERSIST_EPI(99) }  // 35 + the same
     if (pst == 16) { BH_PERSIST_EPI(16) }  // deferred stores + alternating loader teams (needs an even number of stages >= 8)
     if (pst == 5) { BH_PERSIST_EPI(5) }  // bench-only: math, no stores
     if (pst == 9) { BH_PERSIST_EPI(9) }  // bench-only: no epilogue

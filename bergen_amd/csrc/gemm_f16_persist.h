@@ -55,14 +55,6 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int ql = lane & 31, h = lane >> 5;
-    // PST bit 64 = STATIC PRIORITY for the younger half of the workgroup (option gemm_static_prio): the two waves of a SIMD are
-    // arbitrated by priority, then age, and the second-dispatched half (waves 4-7) loses every VALU / LDS issue slot to its older
-    // partner at the start of each segment; one s_setprio 1 for that half, no flips inside the loop (cdna_hip_programming.md T5,
-    // static form).  The branch is on a wave-uniform value: s_setprio ignores EXEC.
-    if constexpr ((PST & 64) != 0) {
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    }
-
     // ---- this block's tiles: XCD x (= block % 8) owns a contiguous range of the (m-major, n-minor) tile order;
     // its blocks j = block / 8 take tiles start + j, start + j + G/8, ... so that the XCD's CUs work on
     // neighbouring tiles at the same time
@@ -345,7 +337,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                 if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) bias_row[tm] = (float)a.bias[m0 + (wm * TM + tm) * 32 + ql];
             }
             if constexpr ((PST & 32) != 0 && (EPI & BH_EPI_SWIGLU) != 0) {
-                // The gated fold through LDS (EXPERIMENTAL: level 2 of option gemm_full_line_stores): a wave's folded part of a tile
+                // The gated fold through LDS (level 2 of option gemm_full_line_stores, the default since round 5): a wave's folded part of a tile
                 // is 32 rows x 32 columns = 64-byte row pieces; straight from the registers a store instruction covers 32 rows with
                 // 32 bytes each, through the wave's LDS buffer 16 rows with their whole 64 bytes.
                 static_assert((PST & 32) == 0 || (PST & 1) != 0, "burst stores");
@@ -420,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                 }
                 (void)bb;
                 const int rrow = lane >> 3, rch = lane & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
-                // (blocked output — c_block_rows, the V^T layout; level 2 of the option, experimental —: a row's 64 columns are one
+                // (blocked output — c_block_rows, the V^T layout; level 2 of the option —: a row's 64 columns are one
                 // 128-byte line and consecutive rows are adjacent: 8 rows = 1 KiB contiguous per instruction)
                 const long long ldrow = a.c_block_rows ? 64 : a.ldc;
                 _Float16* gptr = a.c_block_rows

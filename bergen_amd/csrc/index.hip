@@ -365,10 +365,8 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "gemm_stagger_phases") {
         if (value < 0 || value > 64) return fail(BH_EINVAL, "gemm_stagger_phases must be 0..64");
         bh_gemm_set_stagger((int)value, -1);
-    } else if (s == "gemm_static_prio") {
-        bh_gemm_set_static_prio((int)value);
     } else if (s == "gemm_full_line_stores") {
-        if (value < 0 || value > 2) return fail(BH_EINVAL, "gemm_full_line_stores must be 0, 1 or 2 (2 = 1 + the experimental set: blocked V^T output, gated fold)");
+        if (value < 0 || value > 2) return fail(BH_EINVAL, "gemm_full_line_stores must be 0, 1 or 2 (1 = row-major outputs, 2 = the default: + blocked V^T output and gated fold)");
         bh_gemm_set_full_line_stores((int)value);
     } else if (s == "gemm_gelu_nontemporal") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "gemm_gelu_nontemporal must be 0 or 1");

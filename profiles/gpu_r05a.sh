@@ -6,11 +6,11 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"; mkdir -p gpurun_out
 export TMPDIR=/tmp
 F="grep -v amdgpu.ids"
-timeout 400 python -m pytest tests/test_gpu_nccl.py "tests/test_gpu_sparse.py::test_full_size_sparse" tests/test_gpu_nomic.py tests/test_gpu_experimental.py \
+timeout 400 python -m pytest tests/test_gpu_nccl.py "tests/test_gpu_sparse.py::test_full_size_sparse" tests/test_gpu_nomic.py tests/test_gpu_store_paths.py \
     -m gpu -q --tb=short -p no:cacheprovider --timeout 300 --durations=8 2>&1 | $F | tail -40 | cut -c1-400 | tee gpurun_out/r05a_pytest_new.txt
 timeout 90 python profiles/enc_ab_option.py gemm_full_line_stores 1 2 2>&1 | $F | tee gpurun_out/r05a_ab_full_line_level2.txt
 ENC_ARCH=nomic timeout 90 python profiles/enc_ab_option.py gemm_full_line_stores 1 2 2>&1 | $F | tee -a gpurun_out/r05a_ab_full_line_level2.txt
-timeout 90 python profiles/enc_ab_option.py gemm_static_prio 0 1 2>&1 | $F | tee gpurun_out/r05a_ab_static_prio.txt
+# (this call also A/B-ed a static s_setprio for waves 4-7 of the persistent GEMM — 14.352 vs 14.366 ms, nothing: profiles/r05a_ab_static_prio.txt; the knob was removed)
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_r05a_enc" -o enc -- python "$REPO/profiles/enc_trace.py" bert 10 > "$REPO/gpurun_out/r05a_enc_trace.log" 2>&1; echo "rocprof exit $?")
 find gpurun_out/prof_r05a_enc -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r05a_encoder_kernel_stats.csv
 rm -rf gpurun_out/prof_r05a_enc

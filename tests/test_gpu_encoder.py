@@ -106,14 +106,14 @@ def test_gemm_full_line_stores_are_bit_identical():
             for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)), (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
                             (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
                 outs = []
-                for on in (0, 1, 1):
+                for on in (0, 1, 2):
                     _lib.set_option("gemm_full_line_stores", on)
                     out, _ = encoder.gemm_f16(h16(a), h16(w), **kw)
                     outs.append(out.clone())
                 assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), f"{M}x{N}x{K} {sorted(kw)}"
                 assert_gemm_close(outs[1], ref, f"full-line stores {M}x{N}x{K} {sorted(kw)}")
     finally:
-        _lib.set_option("gemm_full_line_stores", 0)
+        _lib.set_option("gemm_full_line_stores", 2)  # (the library default)
 
 
 def test_gemm_alternating_loader_teams():

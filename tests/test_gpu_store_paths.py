@@ -1,7 +1,9 @@
-"""GPU: store paths that were finished in the last GPU seconds of round 4.  They passed here once (profiles/r04w_experimental.txt: both
-tests green; profiles/r04x_ab_level2.txt: BERT-base forward 14.35 -> 14.27 ms at level 2, identical embeddings) but have not been
-through the whole suite as DEFAULTS, so the library keeps them off (options gemm_full_line_stores = 2, attention_rel_wide_stores = 1)
-and these tests pin their bit-identity with the default paths.  Every one of them is pure data movement."""
+"""GPU: the output paths that leave the kernels as whole cache lines, against the plain paths — every one of them is pure data
+movement, so the outputs must be identical bit for bit.  Options gemm_full_line_stores (0 = 32-byte row pieces straight from the MFMA
+layout, 1 = row-major outputs through LDS as 128-byte lines, 2 = the default since round 5: also the blocked V^T output and the gated
+fold's 64-byte rows) and attention_rel_wide_stores (DeBERTa attention: 16-byte context stores, default on).  Round 4 finished level 2 in its last GPU
+seconds and left it off; round 5 ran it through the whole GPU suite and flipped the defaults (profiles/r05a_ab_full_line_level2.txt: BERT-base forward
+14.40 -> 14.29 ms, NomicBert 20.49 -> 19.15 ms, identical embeddings)."""
 import numpy as np
 import pytest
 import torch
@@ -42,7 +44,7 @@ def test_blocked_vt_and_fold_through_lds_are_bit_identical():
             assert bool(torch.isfinite(outs[2][0].float()).all())
             enc.close()
     finally:
-        _lib.set_option("gemm_full_line_stores", 1)
+        _lib.set_option("gemm_full_line_stores", 2)
 
 
 def test_deberta_attention_wide_stores_are_bit_identical():
@@ -69,5 +71,5 @@ def test_deberta_attention_wide_stores_are_bit_identical():
         assert np.array_equal(narrow.view(np.uint32), wide.view(np.uint32))
         assert np.abs(wide - deberta_oracle.cross_encode(sd, cfg, ids, mask)).max() <= 3e-2
     finally:
-        _lib.set_option("attention_rel_wide_stores", 0)
+        _lib.set_option("attention_rel_wide_stores", 1)
         enc.close()
