@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BERGEN_HIP_LIB", os.path.join(_HERE, "lib", "libbergen_hip.so"))
 
-BH_VERSION = 141  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
+BH_VERSION = 142  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
 
 BH_OK = 0
 BH_EINVAL = -1
@@ -29,7 +29,7 @@ BH_METRIC_COS = 1
 
 
 class _Sized(ctypes.Structure):
-    """Structs whose first field is `struct_size` (include/bergen_hip.h, BH_VERSION 141): set on construction."""
+    """Structs whose first field is `struct_size` (include/bergen_hip.h, BH_VERSION 142): set on construction."""
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
@@ -93,6 +93,8 @@ class bh_encoder_counters(_Sized):
         ("packed_rows", ctypes.c_int64),
         ("forward_ms", ctypes.c_double),
         ("flops", ctypes.c_double),
+        ("ln_fused", ctypes.c_int32),   # since BH_VERSION 142
+        ("reserved0", ctypes.c_int32),
     ]
 
 

@@ -163,7 +163,21 @@ struct BhGemmArgs {
     // reads A + b * batch_stride_a, B + b * batch_stride_b and writes C + b * batch_stride_c (strides in elements)
     int batch;
     long long batch_stride_a, batch_stride_b, batch_stride_c;
+    // Fused LayerNorm (persistent kernel with full-line stores only; encoder.hip option ln_fused):
+    //   ln_stats != null (BH_EPI_LNA): the token operand (A rows with bias_mode 1, B rows = C columns with bias_mode 2) is a
+    //     pre-LayerNorm tensor; ln_stats = float2 (mean, 1 / sqrt(var + eps)) per token, ln_c[f] = sum_k W'[f][k] per output feature of
+    //     the FOLDED weight operand W' = W o gamma, `bias` = the folded bias b + W beta.
+    //   stats_out != null (BH_EPI_RESLN; bias_mode 1, `residual` set): C = fp16(A B^T + bias) + R with R = residual, or — res_stats
+    //     set — (residual - mean) rstd res_gamma + res_beta; stats_out[row][N / 64] float2 (sum, sum of squares) of the stored row
+    //     over each 64-column slice.
+    const float* ln_stats;
+    const _Float16* ln_c;
+    const float* res_stats;
+    const _Float16 *res_gamma, *res_beta;
+    float* stats_out;
 };
+// whether bh_launch_gemm_f16 would run an M x N problem on the persistent kernel's full-line-store path (the fused-LayerNorm epilogues exist there only)
+bool bh_gemm_ln_fusable(int M, int N, bool blocked_out);
 // variant 0 = auto; see gemm_f16.hip for the explicit tile configurations
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a, int variant, hipStream_t stream);
 // C_b = A_b . B_b^T for b < a.batch, whole 256 x 256 tiles only (M, N % 256 == 0, K % 64 == 0), no bias / residual / GELU:
@@ -232,6 +246,28 @@ struct BhLnArgs {
     const _Float16 *gamma, *beta;
 };
 hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t stream);
+
+// Fused LayerNorm (encoder.hip, option ln_fused): the two small kernels beside the GEMM epilogues of gemm_f16_persist.h.
+//   bh_launch_ln_fold      once per weight, at commit: W'[n][k] = fp16(W[n][k] gamma[k]), c[n] = fp16(sum_k W'[n][k]) (the sum of the
+//                          ROUNDED values the MFMA multiplies), b'[n] = fp16(bias[n] + sum_k W[n][k] beta[k]) (fp32 sums)
+//   bh_launch_ln_finalize  per producing GEMM: stats[row] = (mean, 1 / sqrt(var + eps)) from the row's n_part (sum, sum of squares)
+//                          slices, added in slot order (bit-reproducible); var = E[x^2] - mean^2, clamped at 0
+struct BhLnFoldArgs {
+    const _Float16* w;      // [n][k]
+    const _Float16 *gamma, *beta, *bias;  // [k], [k], [n]
+    _Float16* w_out;        // [n][k]
+    _Float16 *c_out, *bias_out;  // [n]
+    int n, k;
+};
+hipError_t bh_launch_ln_fold(const BhLnFoldArgs& a, hipStream_t stream);
+struct BhLnFinalizeArgs {
+    const float* partial;   // [n_rows][n_part] float2
+    float* stats;           // [n_rows] float2
+    long long n_rows;
+    int n_part, d;
+    float eps;
+};
+hipError_t bh_launch_ln_finalize(const BhLnFinalizeArgs& a, hipStream_t stream);
 
 // rotary positions (NomicBert; bh_encoder_config.rotary_theta): rows of [Q | K] rotated in place by their token index
 struct BhRotaryArgs {

@@ -39,6 +39,12 @@ struct Layer {
     _Float16 *w1 = nullptr, *b1 = nullptr;  // [dff][d], [dff]
     _Float16 *w2 = nullptr, *b2 = nullptr;  // [d][dff], [d]
     _Float16 *ln2g = nullptr, *ln2b = nullptr;
+    // fused LayerNorm (option ln_fused; built at commit, bh_launch_ln_fold): weights whose token operand arrives UN-normalised, folded with
+    // the gain of the LayerNorm in front of them — Q | K and V with the previous layer's output LayerNorm (layers >= 1), FFN-up with
+    // this layer's attention-output LayerNorm — plus c = row sums of the folded weight and the folded bias
+    _Float16 *wqk_f = nullptr, *cqk = nullptr, *bqk_f = nullptr;
+    _Float16 *wv_f = nullptr, *cv = nullptr, *bv_f = nullptr;
+    _Float16 *w1_f = nullptr, *c1 = nullptr, *b1_f = nullptr;
 };
 
 int round_up(long long v, int m) { return (int)((v + m - 1) / m * m); }
@@ -61,6 +67,16 @@ struct bh_encoder {
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
     BhDevBuf<_Float16> GU;       // gated feed-forward (cfg.ffn_gated), unfused form: [rows][2 dff] = (gate, up) column pairs of ONE GEMM, folded into H by bh_swiglu_kernel
+    // Fused LayerNorm (option "ln_fused", default 1; BERT-type stacks: no gated feed-forward, no disentangled attention).  The 24
+    // LayerNorm passes of a 12-layer forward (each reads two activation tensors and writes one: 316 MB for 512 passages, 11 % of the
+    // forward's stream time in profiles/r05a_encoder_kernel_stats.csv) disappear: the output-projection and FFN-down GEMMs add the
+    // residual in their epilogue, store the PRE-LayerNorm sum z and the per-row (sum, sum of squares) of what they stored; a tiny
+    // kernel turns those into (mean, rstd) per row; the GEMMs that consume LN(z) read z itself against weights folded with the
+    // LayerNorm's gain and finish the normalisation algebraically in their epilogue (gemm_f16_persist.h BH_EPI_LNA / BH_EPI_RESLN).
+    // Only the last layer's output is normalised by the LayerNorm kernel (the poolers and heads read it).
+    int ln_fused = 1;
+    _Float16* ln_arena = nullptr;
+    BhDevBuf<float> LNP, S1, S2;  // per-row partial (sum, sum of squares) slices [rows][d / 64][2]; (mean, rstd) of z1 / z2 [rows][2]
     int ffn_fused = 1;           // option "ffn_fused": the persistent GEMM folds the pairs in its epilogue where it applies (0: always GU + fold kernel)
     int n_cu = 256;
     BhDevBuf<float> rot;         // rotary positions (cfg.rotary_theta > 0): [max_position][64] = 32 cosines | 32 sines per position
@@ -214,6 +230,70 @@ int build_mlm_slots(bh_encoder* e) {
     return BH_OK;
 }
 
+// Folded weights of the fused LayerNorm (see bh_encoder::ln_fused): their own arena, filled on the device at commit.
+int build_ln_folds(bh_encoder* e) {
+    const bh_encoder_config& c = e->cfg;
+    const size_t d = c.hidden, dff = c.intermediate, da = (size_t)c.n_heads * 64;
+    BH_HIP_TRY(hipSetDevice(e->device));
+    if (!e->ln_arena) {
+        const size_t per_layer = (2 * da * d + 4 * da) + (da * d + 2 * da) + (dff * d + 2 * dff) + 9 * 8;
+        BH_HIP_TRY(hipMalloc((void**)&e->ln_arena, per_layer * c.n_layers * sizeof(_Float16)));
+        _Float16* p = e->ln_arena;
+        auto take = [&](size_t n) {
+            _Float16* r = p;
+            p += (n + 7) / 8 * 8;
+            return r;
+        };
+        for (int l = 0; l < c.n_layers; ++l) {
+            Layer& L = e->layers[l];
+            L.wqk_f = take(2 * da * d);
+            L.cqk = take(2 * da);
+            L.bqk_f = take(2 * da);
+            L.wv_f = take(da * d);
+            L.cv = take(da);
+            L.bv_f = take(da);
+            L.w1_f = take(dff * d);
+            L.c1 = take(dff);
+            L.b1_f = take(dff);
+        }
+    }
+    for (int l = 0; l < c.n_layers; ++l) {
+        Layer& L = e->layers[l];
+        BhLnFoldArgs f{};
+        f.k = (int)d;
+        if (l > 0) {  // the layer input is LN2 of the previous layer
+            const Layer& P = e->layers[l - 1];
+            f.gamma = P.ln2g;
+            f.beta = P.ln2b;
+            f.w = L.wqk;
+            f.bias = L.bqk;
+            f.w_out = L.wqk_f;
+            f.c_out = L.cqk;
+            f.bias_out = L.bqk_f;
+            f.n = (int)(2 * da);
+            BH_HIP_TRY(bh_launch_ln_fold(f, e->stream));
+            f.w = L.wv;
+            f.bias = L.bv;
+            f.w_out = L.wv_f;
+            f.c_out = L.cv;
+            f.bias_out = L.bv_f;
+            f.n = (int)da;
+            BH_HIP_TRY(bh_launch_ln_fold(f, e->stream));
+        }
+        f.gamma = L.ln1g;
+        f.beta = L.ln1b;
+        f.w = L.w1;
+        f.bias = L.b1;
+        f.w_out = L.w1_f;
+        f.c_out = L.c1;
+        f.bias_out = L.b1_f;
+        f.n = (int)dff;
+        BH_HIP_TRY(bh_launch_ln_fold(f, e->stream));
+    }
+    BH_HIP_TRY(hipStreamSynchronize(e->stream));
+    return BH_OK;
+}
+
 constexpr int kMaxLabels = 16;
 
 int build_cls_slots(bh_encoder* e) {
@@ -249,6 +329,13 @@ int gemm(bh_encoder* e, const _Float16* A, long long lda, const _Float16* B, lon
     g.N = N;
     g.K = K;
     g.gelu = gelu;
+    BH_HIP_TRY(bh_launch_gemm_f16(g, e->gemm_variant, on ? on : e->stream));
+    return BH_OK;
+}
+
+// the same with every field the caller set kept (the fused-LayerNorm arguments)
+int gemm_args(bh_encoder* e, BhGemmArgs g, hipStream_t on) {
+    g.bias_mode = g.bias ? g.bias_mode : 0;
     BH_HIP_TRY(bh_launch_gemm_f16(g, e->gemm_variant, on ? on : e->stream));
     return BH_OK;
 }
@@ -354,6 +441,7 @@ void bh_encoder_destroy(bh_encoder* e) {
     if (e->rel_arena) (void)hipFree(e->rel_arena);
     if (e->arena) (void)hipFree(e->arena);
     if (e->mlm_arena) (void)hipFree(e->mlm_arena);
+    if (e->ln_arena) (void)hipFree(e->ln_arena);
     if (e->cls_arena) (void)hipFree(e->cls_arena);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -452,6 +540,10 @@ int bh_encoder_commit(bh_encoder* e) {
         }
         e->has_mlm = true;  // a missing decoder bias stays zero
     }
+    if (!e->cfg.ffn_gated && e->rel_span == 0) {
+        int rc = build_ln_folds(e);
+        if (rc) return rc;
+    }
     e->committed = true;
     return BH_OK;
 }
@@ -466,6 +558,11 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
     if (std::string(name) == "attn_side_stream") {
         if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "attn_side_stream must be 0 or 1");
         e->attn_side_stream = (int)value;
+        return BH_OK;
+    }
+    if (std::string(name) == "ln_fused") {
+        if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "ln_fused must be 0 or 1");
+        e->ln_fused = (int)value;
         return BH_OK;
     }
     if (std::string(name) == "ffn_fused") {
@@ -695,6 +792,22 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         for (int m = 0; m < n_mb; ++m) need_gu = need_gu || !ffn_fused(row_split[m + 1] - row_split[m]);
         if (need_gu && (rc = e->GU.ensure(M * 2 * dff))) return rc;
     }
+    // fused LayerNorm (bh_encoder::ln_fused): only where EVERY GEMM of every micro-batch runs on the persistent kernel's full-line-store
+    // path (whole 256 x 256 tiles filling more than half the chip: a rerank batch of 32 pairs does not) — one decision per forward pass,
+    // so that the micro-batches of a pass, and passes that differ only in their micro-batch count, compute the same bits
+    bool fuse_ln = e->ln_fused && e->ln_arena != nullptr && !c.ffn_gated && e->rel_span == 0 && e->gemm_variant == 0 && (da % 256 == 0) &&
+                   bh_gemm_probe_permlane(st) == hipSuccess;
+    for (int m = 0; m < n_mb && fuse_ln; ++m) {
+        const int rows = (int)(row_split[m + 1] - row_split[m]);
+        fuse_ln = bh_gemm_ln_fusable(rows, (int)d, false) && bh_gemm_ln_fusable((int)da, rows, true) && bh_gemm_ln_fusable(rows, (int)(2 * da), false) &&
+                  bh_gemm_ln_fusable(rows, (int)dff, false);
+    }
+    const int ln_parts = (int)(d / 64);
+    if (fuse_ln) {
+        if ((rc = e->LNP.ensure(M * ln_parts * 2))) return rc;
+        if ((rc = e->S1.ensure(M * 2))) return rc;
+        if ((rc = e->S2.ensure(M * 2))) return rc;
+    }
     if ((rc = e->ibuf.ensure(ib.size()))) return rc;
     if ((rc = e->seq_off.ensure(batch))) return rc;
     const size_t out_elems = pool == 2 ? (size_t)batch * seq_len * d : pool == 3 ? (size_t)batch * c.vocab_size
@@ -778,11 +891,50 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             BH_HIP_TRY(hipEventRecord(evf, ls));  // (the layer input X is final; the previous layer's attention has read VT)
             BH_HIP_TRY(hipStreamWaitEvent(vs, evf, 0));
         }
-        if ((rc = gemm(e, L.wv, d, Xp, d, VTp, m_pad, da, rows, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0,
-                       fork ? vs : ls)))
+        // fused LayerNorm, layers >= 1: X holds the previous layer's PRE-LayerNorm output z2 with its row statistics in S2 — the
+        // projections read z2 against the folded weights and normalise in their epilogue (tokens = C columns of V^T, C rows of Q | K)
+        const bool ln_in = fuse_ln && l > 0;
+        float* S1p = fuse_ln ? e->S1.p + r0 * 2 : nullptr;
+        float* S2p = fuse_ln ? e->S2.p + r0 * 2 : nullptr;
+        float* LNPp = fuse_ln ? e->LNP.p + r0 * (size_t)ln_parts * 2 : nullptr;
+        if (ln_in) {
+            BhGemmArgs g{};
+            g.A = L.wv_f;
+            g.lda = d;
+            g.B = Xp;
+            g.ldb = d;
+            g.C = VTp;
+            g.ldc = m_pad;
+            g.c_block_rows = da;
+            g.M = (int)da;
+            g.N = rows;
+            g.K = (int)d;
+            g.bias = L.bv_f;
+            g.bias_mode = 2;
+            g.ln_stats = S2p;
+            g.ln_c = L.cv;
+            if ((rc = gemm_args(e, g, fork ? vs : ls))) return rc;
+        } else if ((rc = gemm(e, L.wv, d, Xp, d, VTp, m_pad, da, rows, d, L.bv, 2, nullptr, 0, 0, /*c_block_rows=*/vt_blocked ? da : 0,
+                              fork ? vs : ls)))
             return rc;
         if (fork) BH_HIP_TRY(hipEventRecord(evj, vs));
-        if ((rc = gemm(e, Xp, d, L.wqk, d, QKp, 2 * da, rows, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
+        if (ln_in) {
+            BhGemmArgs g{};
+            g.A = Xp;
+            g.lda = d;
+            g.B = L.wqk_f;
+            g.ldb = d;
+            g.C = QKp;
+            g.ldc = 2 * da;
+            g.M = rows;
+            g.N = (int)(2 * da);
+            g.K = (int)d;
+            g.bias = L.bqk_f;
+            g.bias_mode = 1;
+            g.ln_stats = S2p;
+            g.ln_c = L.cqk;
+            if ((rc = gemm_args(e, g, ls))) return rc;
+        } else if ((rc = gemm(e, Xp, d, L.wqk, d, QKp, 2 * da, rows, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
         if (c.rotary_theta > 0.f) {  // rotary positions: queries and keys of this micro-batch's rows, in place, by their token index
             BhRotaryArgs ra{};
             ra.qk = QKp;
@@ -870,6 +1022,91 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
                 BH_HIP_TRY(hipEventRecord(e->ev_join, e->side));
                 BH_HIP_TRY(hipStreamWaitEvent(ls, e->ev_join, 0));
             }
+        }
+        if (fuse_ln) {
+            // z1 = ctx Wo^T + bo + (layer input, normalised on the fly from z2 and S2 for layers >= 1) -> Y, its row sums -> LNP -> S1
+            BhLnFinalizeArgs fa{};
+            fa.partial = LNPp;
+            fa.n_rows = rows;
+            fa.n_part = ln_parts;
+            fa.d = (int)d;
+            fa.eps = c.ln_eps;
+            BhGemmArgs g{};
+            g.A = CTXp;
+            g.lda = da;
+            g.B = L.wo;
+            g.ldb = da;
+            g.C = Yp;
+            g.ldc = d;
+            g.M = rows;
+            g.N = (int)d;
+            g.K = (int)da;
+            g.bias = L.bo;
+            g.bias_mode = 1;
+            g.residual = Xp;
+            g.ldr = d;
+            if (l > 0) {
+                g.res_stats = S2p;
+                g.res_gamma = e->layers[l - 1].ln2g;
+                g.res_beta = e->layers[l - 1].ln2b;
+            }
+            g.stats_out = LNPp;
+            if ((rc = gemm_args(e, g, ls))) return rc;
+            fa.stats = S1p;
+            BH_HIP_TRY(bh_launch_ln_finalize(fa, ls));
+            // H = GELU(LN1(z1) W1^T + b1): z1 against the folded weight, normalised in the epilogue
+            BhGemmArgs u{};
+            u.A = Yp;
+            u.lda = d;
+            u.B = L.w1_f;
+            u.ldb = d;
+            u.C = Hp;
+            u.ldc = dff;
+            u.M = rows;
+            u.N = (int)dff;
+            u.K = (int)d;
+            u.bias = L.b1_f;
+            u.bias_mode = 1;
+            u.gelu = 1;
+            u.ln_stats = S1p;
+            u.ln_c = L.c1;
+            if ((rc = gemm_args(e, u, ls))) return rc;
+            // z2 = H W2^T + b2 + LN1(z1) (on the fly) -> X, its row sums -> LNP -> S2
+            BhGemmArgs w{};
+            w.A = Hp;
+            w.lda = dff;
+            w.B = L.w2;
+            w.ldb = dff;
+            w.C = Xp;
+            w.ldc = d;
+            w.M = rows;
+            w.N = (int)d;
+            w.K = (int)dff;
+            w.bias = L.b2;
+            w.bias_mode = 1;
+            w.residual = Yp;
+            w.ldr = d;
+            w.res_stats = S1p;
+            w.res_gamma = L.ln1g;
+            w.res_beta = L.ln1b;
+            w.stats_out = LNPp;
+            if ((rc = gemm_args(e, w, ls))) return rc;
+            if (l + 1 < c.n_layers) {
+                fa.stats = S2p;
+                BH_HIP_TRY(bh_launch_ln_finalize(fa, ls));
+            } else {  // the stack's output is read by poolers and heads: the one LayerNorm pass that remains
+                BhLnArgs la{};
+                la.in = Xp;
+                la.residual = nullptr;
+                la.out = Xp;
+                la.n_rows = rows;
+                la.d = d;
+                la.eps = c.ln_eps;
+                la.gamma = L.ln2g;
+                la.beta = L.ln2b;
+                BH_HIP_TRY(bh_launch_layernorm(la, ls));
+            }
+            return BH_OK;
         }
         // attention output projection, then LayerNorm(projection + layer input)
         if ((rc = gemm(e, CTXp, da, L.wo, da, Yp, d, rows, d, da, L.bo, 1, nullptr, 0, 0, 0, ls))) return rc;
@@ -1016,6 +1253,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     k.real_tokens = real_tokens;
     k.packed_rows = m_pad;
     k.forward_ms = ms;
+    k.ln_fused = fuse_ln ? 1 : 0;
     // algorithmic flops over REAL tokens: per layer 8 T d^2 + 4 T d dff (projections; 6 T d dff with a gated feed-forward: gate,
     // up and down) + 4 sum(len^2) d (attention)
     k.flops = (double)c.n_layers *

@@ -282,6 +282,56 @@ hipError_t bh_launch_embed_ln(const BhEmbedArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(bh_embed_ln_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+// one wave per weight row: k is a multiple of 64 (bh_encoder_create)
+__global__ void __launch_bounds__(256) bh_ln_fold_kernel(BhLnFoldArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.n) return;
+    const _Float16* w = a.w + (size_t)n * a.k;
+    _Float16* wo = a.w_out + (size_t)n * a.k;
+    float csum = 0.f, bsum = 0.f;
+    for (int k = lane; k < a.k; k += 64) {
+        const float wv = (float)w[k];
+        const _Float16 f = (_Float16)(wv * (float)a.gamma[k]);
+        wo[k] = f;
+        csum += (float)f;
+        bsum = fmaf(wv, (float)a.beta[k], bsum);
+    }
+    csum = wave_sum(csum);
+    bsum = wave_sum(bsum);
+    if (lane == 0) {
+        a.c_out[n] = (_Float16)csum;
+        a.bias_out[n] = (_Float16)((a.bias ? (float)a.bias[n] : 0.f) + bsum);
+    }
+}
+
+__global__ void __launch_bounds__(256) bh_ln_finalize_kernel(BhLnFinalizeArgs a) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.n_rows) return;
+    const float2* p = reinterpret_cast<const float2*>(a.partial) + (size_t)row * a.n_part;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < a.n_part; ++j) {
+        const float2 v = p[j];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float inv = 1.0f / (float)a.d;
+    const float mean = s1 * inv;
+    const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+    reinterpret_cast<float2*>(a.stats)[row] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
+}
+
+hipError_t bh_launch_ln_fold(const BhLnFoldArgs& a, hipStream_t st) {
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_ln_fold_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t bh_launch_ln_finalize(const BhLnFinalizeArgs& a, hipStream_t st) {
+    if (a.n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bh_ln_finalize_kernel, dim3((unsigned)((a.n_rows + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t st) {
     if (a.n_rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(bh_layernorm_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);

@@ -118,6 +118,15 @@ hipError_t bh_launch_gemm_f16_batched(const BhGemmArgs& a_in, hipStream_t stream
     return bh_gemm_persist(a, BH_EPI_BATCHED, 1, stream);
 }
 
+static int gemm_cu_count();
+bool bh_gemm_ln_fusable(int M, int N, bool blocked_out) {
+    // the auto dispatch of bh_launch_gemm_f16: persistent kernel for more than half a round of whole 256 x 256 tiles, documented
+    // swap direction, full-line stores on (level 2 for the blocked V^T output)
+    if (M <= 0 || N <= 0 || (M & 255) || (N & 255) || g_swap_b != 0) return false;
+    if (g_full_line_stores < (blocked_out ? 2 : 1)) return false;
+    return (long long)(M / 256) * (N / 256) * 2 > gemm_cu_count();
+}
+
 static int gemm_cu_count() {
     static int cached = 0;
     int dev = 0;
@@ -169,6 +178,21 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
             return hipErrorInvalidValue;
         // (non-temporal burst, like the GELU output; level 2 of gemm_full_line_stores: 64-byte row pieces through LDS)
         return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? 35 : 3, stream);
+    }
+    if (a.ln_stats || a.stats_out) {
+        // fused LayerNorm: whole 256 x 256 tiles on the persistent kernel's full-line-store path, nothing else (the caller asks
+        // bh_gemm_ln_fusable first and keeps the separate LayerNorm kernel otherwise)
+        if (!bh_gemm_ln_fusable(a.M, a.N, a.c_block_rows != 0) || !a.bias || (variant != 0 && variant != 7))
+            return hipErrorNotSupported;
+        if (a.stats_out) {
+            if (a.ln_stats || a.bias_mode != 1 || !a.residual || a.gelu || a.c_block_rows || (a.res_stats && (!a.res_gamma || !a.res_beta)))
+                return hipErrorInvalidValue;
+            return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_RESLN, 33, stream);
+        }
+        if (!a.ln_c || a.residual) return hipErrorInvalidValue;
+        if (a.bias_mode == 2) return a.gelu ? hipErrorNotSupported : bh_gemm_persist(a, BH_EPI_BIAS_ROW | BH_EPI_LNA, 33, stream);
+        if (a.gelu) return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_GELU | BH_EPI_LNA, g_gelu_nontemporal ? 35 : 33, stream);
+        return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_LNA, 33, stream);
     }
     const bool epi_fast = epi == 0 || epi == BH_EPI_BIAS_COL || epi == BH_EPI_BIAS_ROW ||
                           epi == (BH_EPI_BIAS_COL | BH_EPI_RESIDUAL) || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU);

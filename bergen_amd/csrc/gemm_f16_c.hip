@@ -29,6 +29,19 @@ int n_cu() {
         case BH_EPI_BATCHED:                                                                                      \
             if (P == 1) return bh_gemm_launch_persist<BH_EPI_BATCHED, 1>(a, n_cu(), s);                           \
             break;                                                                                                \
+        case BH_EPI_BIAS_COL | BH_EPI_LNA:                                                                        \
+            if (P == 33) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_LNA, 33>(a, n_cu(), s);           \
+            break;                                                                                                \
+        case BH_EPI_BIAS_ROW | BH_EPI_LNA:                                                                        \
+            if (P == 33) return bh_gemm_launch_persist<BH_EPI_BIAS_ROW | BH_EPI_LNA, 33>(a, n_cu(), s);           \
+            break;                                                                                                \
+        case BH_EPI_BIAS_COL | BH_EPI_GELU | BH_EPI_LNA:                                                          \
+            if (P == 35) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_GELU | BH_EPI_LNA, 35>(a, n_cu(), s); \
+            if (P == 33) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_GELU | BH_EPI_LNA, 33>(a, n_cu(), s); \
+            break;                                                                                                \
+        case BH_EPI_BIAS_COL | BH_EPI_RESLN:                                                                      \
+            if (P == 33) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_RESLN, 33>(a, n_cu(), s);         \
+            break;                                                                                                \
         case BH_EPI_BIAS_COL | BH_EPI_SWIGLU:                                                                     \
             if (P == 3) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 3>(a, n_cu(), s);          \
             if (P == 35) return bh_gemm_launch_persist<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, 35>(a, n_cu(), s);        \

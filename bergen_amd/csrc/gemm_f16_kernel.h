@@ -15,6 +15,11 @@
                            // and C [M][N / 2] (row stride ldc) = silu(gate) * up: the gated feed-forward of NomicBert folded in the
                            // epilogue (a lane's 8 consecutive columns are 4 pairs -> one 8-byte store)
 
+#define BH_EPI_LNA 128     // persistent kernel, full-line stores: the token operand is a pre-LayerNorm tensor, the LayerNorm is applied
+                           // algebraically in the epilogue (gemm_f16_persist.h; BhGemmArgs::ln_stats / ln_c, folded weights and bias)
+#define BH_EPI_RESLN 256   // persistent kernel, full-line stores: + residual rows (normalised on the fly when res_stats is set), and the
+                           // per-row (sum, sum of squares) of the stored outputs into BhGemmArgs::stats_out
+
 namespace bh_gemm {
 
 // erf-GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x), as ONE sigmoid of an odd polynomial:

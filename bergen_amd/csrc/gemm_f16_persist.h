@@ -401,9 +401,26 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                 }
             } else if constexpr ((PST & 32) != 0) {
                 static_assert((PST & 32) == 0 || ((PST & 1) != 0 && (EPI & BH_EPI_SEGMAX) == 0), "full-line stores: burst, plain outputs");
+                // FUSED LayerNorm (encoder.hip, option ln_fused; the two bits are independent):
+                //   BH_EPI_LNA    the token operand of this GEMM is an UN-NORMALISED pre-LayerNorm tensor z and the weight operand was
+                //                 folded with the LayerNorm's gain (W' = W o gamma): LN(z) W^T + b = rstd (z W'^T - mu c) + b', c = sum_k W'
+                //                 (a.ln_c), b' = b + W beta (a.bias), (mu, rstd) per token (a.ln_stats: float2 per token).  Tokens are
+                //                 the C rows (bias per column) or, for the transposed V projection, the C columns (bias per row).
+                //   BH_EPI_RESLN  C = fp16(A B^T + bias) + R, R = the residual rows a.residual, normalised on the fly when a.res_stats
+                //                 is set: (r - mu) rstd gamma + beta; the sum and the sum of squares of every output row over this
+                //                 wave's 64 columns go to a.stats_out[row][N / 64 slots] (fixed slots, no atomics: bit-reproducible).
+                //                 Done on the READ-BACK side of the LDS transposition: whole 128-byte lines of residual and output.
+                constexpr bool LNA = (EPI & BH_EPI_LNA) != 0, RESLN = (EPI & BH_EPI_RESLN) != 0;
+                constexpr bool TOK_COLS = LNA && (EPI & BH_EPI_BIAS_ROW) != 0;  // tokens along the columns (V^T projection)
+                static_assert(!LNA || (EPI & (BH_EPI_BIAS_COL | BH_EPI_BIAS_ROW)) != 0, "the folded bias comes with the fold");
+                static_assert(!RESLN || ((EPI & BH_EPI_BIAS_ROW) == 0 && (EPI & BH_EPI_GELU) == 0), "residual epilogue: row-major, bias per column");
                 unsigned char* stg = smem + R * STAGE_BYTES + wave * 4096;  // this wave's 32 rows x 128 bytes
+                // (the per-column vectors: hoisted out of the tile's loops in the plain epilogues — 16 registers —; the fused-LayerNorm
+                // epilogues, which also hold statistics and residual rows, re-read theirs per 32 x 32 part from L1: 128 accumulator
+                // registers of 256 leave no room for 32 more)
+                constexpr bool HOIST = !LNA && !RESLN;
                 half8 bb[TN][2];
-                if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
+                if constexpr ((EPI & BH_EPI_BIAS_COL) != 0 && HOIST) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -420,6 +437,16 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                                      : c_base + (size_t)(m0 + wm * TM * 32 + rrow) * a.ldc + n0 + wn * TN * 32 + rch * 8;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
+                    float ln_mu = 0.f, ln_rstd = 1.f, ln_cm = 0.f;
+                    if constexpr (LNA && !TOK_COLS) {
+                        const float2 st2 = reinterpret_cast<const float2*>(a.ln_stats)[m0 + (wm * TM + tm) * 32 + ql];
+                        ln_mu = st2.x;
+                        ln_rstd = st2.y;
+                    }
+                    if constexpr (TOK_COLS) ln_cm = (float)a.ln_c[m0 + (wm * TM + tm) * 32 + ql];
+                    (void)ln_mu;
+                    (void)ln_rstd;
+                    (void)ln_cm;
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         floatx16 c = acc[tm][tn];
@@ -434,11 +461,41 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                             }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            half8 o;
+                            float tmu[8], trs[8];  // TOK_COLS: the statistics of this lane's 8 tokens (columns)
+                            if constexpr (TOK_COLS) {
+                                const floatx4* sp = reinterpret_cast<const floatx4*>(a.ln_stats) + (size_t)(n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h)) / 2;
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    const floatx4 t4 = sp[q4];
+                                    tmu[2 * q4] = t4[0];
+                                    trs[2 * q4] = t4[1];
+                                    tmu[2 * q4 + 1] = t4[2];
+                                    trs[2 * q4 + 1] = t4[3];
+                                }
+                            }
+                            (void)tmu;
+                            (void)trs;
+                            half8 o, bcol, ccol;
+                            if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
+                                if constexpr (HOIST)
+                                    bcol = bb[tn][u];
+                                else
+                                    bcol = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
+                                if constexpr (LNA) ccol = *reinterpret_cast<const half8*>(a.ln_c + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
+                            }
+                            (void)bcol;
+                            (void)ccol;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                float v = c[8 * u + e] + bias_row[tm];
-                                if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)bb[tn][u][e];
+                                float v = c[8 * u + e];
+                                if constexpr (TOK_COLS)
+                                    v = trs[e] * (v - tmu[e] * ln_cm) + bias_row[tm];
+                                else if constexpr (LNA)
+                                    v = ln_rstd * (v - ln_mu * (float)ccol[e]) + (float)bcol[e];
+                                else {
+                                    v += bias_row[tm];
+                                    if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)bcol[e];
+                                }
                                 if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
                                 o[e] = (_Float16)v;
                             }
@@ -449,8 +506,40 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own writes; no other wave touches stg)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ rrow) << 4));
+                        half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ rrow) << 4));
                         half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tm * 32 + 8 * i) * ldrow);
+                        if constexpr (RESLN) {
+                            const int row = m0 + wm * TM * 32 + tm * 32 + 8 * i + rrow;
+                            const half8 r8 = *reinterpret_cast<const half8*>(a.residual + (size_t)row * a.ldr + n0 + wn * TN * 32 + rch * 8);
+                            float rr[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) rr[e] = (float)r8[e];
+                            if (a.res_stats) {
+                                // (gain and shift of the residual's LayerNorm for this lane's 8 read-back columns: re-read per row
+                                // group from L1 rather than held in 8 registers across the tile)
+                                const float2 rs = reinterpret_cast<const float2*>(a.res_stats)[row];
+                                const half8 rg = *reinterpret_cast<const half8*>(a.res_gamma + n0 + wn * TN * 32 + rch * 8);
+                                const half8 rbeta = *reinterpret_cast<const half8*>(a.res_beta + n0 + wn * TN * 32 + rch * 8);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) rr[e] = (rr[e] - rs.x) * rs.y * (float)rg[e] + (float)rbeta[e];
+                            }
+                            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                v[e] = (_Float16)((float)v[e] + rr[e]);
+                                const float zf = (float)v[e];  // the statistics describe what is STORED
+                                s1 += zf;
+                                s2 = fmaf(zf, zf, s2);
+                            }
+                            // the 8 lanes of a row (rch = 0 .. 7) are neighbours: xor-butterfly, every lane ends with the row's sums
+#pragma unroll
+                            for (int o2 = 1; o2 < 8; o2 <<= 1) {
+                                s1 += __shfl_xor(s1, o2, 64);
+                                s2 += __shfl_xor(s2, o2, 64);
+                            }
+                            if (rch == 0)
+                                reinterpret_cast<float2*>(a.stats_out)[(size_t)row * (a.N >> 6) + ((n0 + wn * TN * 32) >> 6)] = make_float2(s1, s2);
+                        }
                         if constexpr ((PST & 2) != 0)
                             __builtin_nontemporal_store(v, p);
                         else

@@ -35,8 +35,9 @@ extern "C" {
  * bh_encoder_set_rel_index (DeBERTa); 141 = 0.1.4.1 (round 4): bh_counters grew paired_scan_ms / paired_launches at its END (option
  * pair256) and bh_encoder_config grew rotary_theta / ffn_gated at its END (NomicBert: rotary positions, gated SiLU feed-forward;
  * a shorter struct reads as plain BERT) + bh_op_rotary / bh_op_swiglu; a caller built against 140 keeps working memory-wise
- * (struct_size) but must be rebuilt to pass the version check. */
-#define BH_VERSION 141
+ * (struct_size) but must be rebuilt to pass the version check; 142 = 0.1.4.2 (round 5): bh_encoder_counters grew ln_fused at its END
+ * (whether the last forward pass ran with the LayerNorms fused into the GEMM epilogues: encoder option "ln_fused"). */
+#define BH_VERSION 142
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -233,6 +234,11 @@ typedef struct bh_encoder_counters {
     double flops;         /* ALGORITHMIC flops over real tokens:
                              n_layers * (T*(8 d^2 + 4 d d_ff) + 4 d sum(len_s^2))
                              (+ T*(2 d^2 + 2 d vocab) for pool 3) */
+    /* ---- since BH_VERSION 142 ---- */
+    int32_t ln_fused;     /* 1 = the last forward pass ran WITHOUT standalone LayerNorm passes between its GEMMs (residual add +
+                             row statistics in the producing GEMM's epilogue, normalisation folded into the consuming GEMM: option
+                             "ln_fused", BERT-type stacks, batches whose GEMMs fill the chip); 0 = one LayerNorm kernel per LayerNorm */
+    int32_t reserved0;
 } bh_encoder_counters;
 
 /* Allocate an encoder (weights + workspace live in HBM, owned by the library).  Replaces

@@ -467,3 +467,88 @@ def test_encoder_with_outlier_features_against_oracle():
         assert err[:, ordinary].max() <= bound, f"{mode}: ordinary features off by {err[:, ordinary].max():.4g} (bound {bound:.4g})"
         assert (err[:, hot] <= 3e-2 * np.abs(ref[:, hot]).max()).all(), f"{mode}: outlier features off by {err[:, hot].max():.4g}"
     enc.close()
+
+
+def test_fused_layernorm_matches_the_separate_layernorm_kernels_and_the_oracle():
+    """Option ln_fused (default on; encoder.hip): for batches whose GEMMs fill the chip the LayerNorm passes between the GEMMs disappear —
+    the output-projection / FFN-down epilogues add the residual, store the pre-LayerNorm sum and its per-row (sum, sum of squares); the
+    Q | K, V^T and FFN-up GEMMs read that tensor against weights folded with the LayerNorm's gain and normalise in their epilogue
+    (LN(z) W^T + b = rstd (z W'^T - mean c) + b').  Same mathematics, different rounding points — tolerances, written here:
+      fused vs separate kernels   cosine >= 0.9999 per embedding, |difference| <= 1.5e-2 * max|embedding|   (fp16 round-off of 3 layers)
+      fused vs the fp32 oracle    the encoder bound of this file (cosine >= 0.999, 3e-2 * max)
+    and the counters must SAY which path ran (a batch too small for the persistent GEMMs keeps the separate kernels)."""
+    cfg = dict(vocab_size=2000, hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=3072,
+               max_position_embeddings=256, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=81)
+    # LayerNorm gains and shifts far from (1, 0), and a hidden state with a mean far from 0: what the fold has to get right
+    rng = np.random.default_rng(82)
+    for k in list(sd):
+        if k.endswith("LayerNorm.weight"):
+            sd[k] = (1.0 + 0.5 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+        elif k.endswith("LayerNorm.bias"):
+            sd[k] = (0.3 * rng.standard_normal(sd[k].shape) + 0.2).astype(np.float32)
+        elif k.endswith("output.dense.bias"):
+            sd[k] = (sd[k] + 0.5).astype(np.float32)   # shifts the mean of z = dense(x) + residual
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=270, max_len=200, seed=83, min_len=30)
+    assert int(mask.sum()) > 28000
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(types)}
+    out = {}
+    for fused in (1, 0):
+        enc.set_option("ln_fused", fused)
+        out[fused] = (enc.encode_pooled(kw, "mean").float().cpu().numpy(), enc.encode_pooled(kw, "cls").float().cpu().numpy(),
+                      enc(**kw)[0].float().cpu().numpy())
+        assert enc.counters()["ln_fused"] == fused, "the counters must report the path that ran"
+    for a, b, what in zip(out[1], out[0], ("mean", "cls", "hidden states")):
+        a2, b2 = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+        keep = np.abs(b2).sum(1) > 0   # (padding positions of the hidden-state output are zero in both)
+        cos = (a2[keep] * b2[keep]).sum(1) / (np.linalg.norm(a2[keep], axis=1) * np.linalg.norm(b2[keep], axis=1))
+        assert cos.min() >= 0.9999, f"{what}: min cosine fused vs separate {cos.min():.6f}"
+        assert np.abs(a2 - b2).max() <= 1.5e-2 * np.abs(b2).max(), f"{what}: max |difference| {np.abs(a2 - b2).max():.4g}"
+        assert np.isfinite(a2).all()
+    # the oracle on a subset of the sequences (the forward pass is batch-composition invariant; 270 sequences would take minutes)
+    sub = slice(0, 24)
+    ref = bert_oracle.encode(sd, cfg, ids[sub], mask[sub], types[sub], pooler="mean")
+    _check_embeddings(torch.from_numpy(out[1][0][sub]), ref, "fused LayerNorm vs the oracle")
+    _check_embeddings(torch.from_numpy(out[0][0][sub]), ref, "separate LayerNorm vs the oracle")
+    # bit-identical across micro-batch counts and run to run (fixed statistic slots, no atomics)
+    enc.set_option("ln_fused", 1)
+    enc.set_option("micro_batches", 1)
+    one = enc.encode_pooled(kw, "mean").cpu()
+    assert enc.counters()["ln_fused"] == 1
+    enc.set_option("micro_batches", 2)
+    two = enc.encode_pooled(kw, "mean").cpu()
+    assert torch.equal(one, two) and torch.equal(two, enc.encode_pooled(kw, "mean").cpu())
+    # a batch whose GEMMs do not fill the chip keeps the separate kernels — and says so
+    small = {k_: v[:12] for k_, v in kw.items()}
+    e_small = enc.encode_pooled(small, "mean").float().cpu().numpy()
+    assert enc.counters()["ln_fused"] == 0
+    _check_embeddings(torch.from_numpy(e_small), bert_oracle.encode(sd, cfg, ids[:12], mask[:12], types[:12], pooler="mean"), "small batch")
+    enc.close()
+
+
+def test_fused_layernorm_on_the_other_stacks():
+    """The fused path under the things that sit around it: RoBERTa-style position offsets, the SPLADE head and the classification
+    head (both read the LAST layer's output, the one LayerNorm pass that stays), a d = 1024 / 16-head geometry (16 statistic slices per row)."""
+    rng = np.random.default_rng(91)
+    cfg = dict(vocab_size=1500, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+               max_position_embeddings=200, type_vocab_size=2, layer_norm_eps=1e-5, hidden_act="gelu")
+    sd = bert_oracle.random_bert(cfg, seed=92)
+    synth_mod = __import__("bergen_amd.synth", fromlist=["x"])
+    synth_mod.random_cls_head(cfg, seed=93, num_labels=1, sd=sd)
+    ids, mask, types = bert_oracle.random_batch(cfg, batch=190, max_len=180, seed=94, min_len=40)
+    enc = _native(cfg, sd)
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(types)}
+    res = {}
+    for fused in (1, 0):
+        enc.set_option("ln_fused", fused)
+        res[fused] = (enc.encode_pooled(kw, "mean").float().cpu().numpy(), enc.classify(kw).float().cpu().numpy())
+        assert enc.counters()["ln_fused"] == fused
+    a, b = res[1][0], res[0][0]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert cos.min() >= 0.9999 and np.abs(a - b).max() <= 1.5e-2 * np.abs(b).max(), (cos.min(), np.abs(a - b).max())
+    assert np.abs(res[1][1] - res[0][1]).max() <= 2e-2 * max(1.0, np.abs(res[0][1]).max())
+    sub = slice(0, 10)
+    _check_embeddings(torch.from_numpy(a[sub]), bert_oracle.encode(sd, cfg, ids[sub], mask[sub], types[sub], pooler="mean"), "d = 1024 fused vs oracle")
+    enc.close()
+    del rng
