@@ -34,6 +34,15 @@
 // stages (~3 us) to be acknowledged, and a wave that only stored does not wait at all.  The stores of a tile (128 KiB per
 // workgroup, 5 us as a burst with every CU bursting at the same time) then drain under the next tile's MFMAs.
 // Needs an even number of stages >= 8 per tile (K = 768: 12, K = 3072: 48): the team roles are then the same in every tile.
+namespace bh_gemm {
+// v = the value of `x` in the lane DPP control CTRL names (all rows, all banks, bound_ctrl: no lane is without a source here)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xF, 0xF, true));
+}
+}  // namespace bh_gemm
+using bh_gemm::dpp_f32;
+
 template <int EPI, int PST = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -428,22 +437,56 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                             bb[tn][u] = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
                 }
                 (void)bb;
-                const int rrow = lane >> 3, rch = lane & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
+                // (fused-LayerNorm epilogues: the read-back lane coordinates come from an OPAQUE copy of the lane id — otherwise hipcc
+                // computes the per-lane residual / statistics addresses before the main loop and carries them across it in scratch)
+                // (... and the lane id itself is re-derived with v_mbcnt: two instructions instead of a register kept — spilled — across the main loop)
+                int lane_e = lane;
+                if constexpr (!HOIST) {
+                    lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    asm volatile("" : "+v"(lane_e));
+                }
+                const int rrow = lane_e >> 3, rch = lane_e & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
+                const int qlx = lane_e & 31, hx = lane_e >> 5;    // (= ql, h; opaque in the fused-LayerNorm epilogues, see above)
                 // (blocked output — c_block_rows, the V^T layout; level 2 of the option —: a row's 64 columns are one
                 // 128-byte line and consecutive rows are adjacent: 8 rows = 1 KiB contiguous per instruction)
                 const long long ldrow = a.c_block_rows ? 64 : a.ldc;
                 _Float16* gptr = a.c_block_rows
                                      ? c_base + (size_t)((n0 + wn * TN * 32) >> 6) * a.c_block_rows * 64 + (size_t)(m0 + wm * TM * 32 + rrow) * 64 + rch * 8
                                      : c_base + (size_t)(m0 + wm * TM * 32 + rrow) * a.ldc + n0 + wn * TN * 32 + rch * 8;
+                // TOK_COLS: the statistics of this wave's 64 tokens (columns) sit one token per LANE (one coalesced 512-byte load per
+                // tile); an element's (mean, rstd) comes out of its token's lane with v_readlane — the loads of 4 x 64 bytes per 8
+                // columns that this replaces were L2 round trips in the innermost loop (measured: the V^T GEMM 38 % slower)
+                float lane_mu = 0.f, lane_rstd = 1.f;
+                if constexpr (TOK_COLS) {
+                    const float2 st2 = reinterpret_cast<const float2*>(a.ln_stats)[n0 + wn * TN * 32 + lane_e];
+                    lane_mu = st2.x;
+                    lane_rstd = st2.y;
+                }
+                (void)lane_mu;
+                (void)lane_rstd;
+                // RESLN: the residual rows (and their statistics) of the NEXT 32-row part are requested while this part is converted,
+                // transposed and stored: 4 row groups x (16-byte residual piece + float2) per lane in flight, double-buffered over tm
+                half8 rres[2][4];
+                auto res_prefetch = [&](int buf, int tm_) {
+                    if constexpr (RESLN) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = m0 + wm * TM * 32 + tm_ * 32 + 8 * i + rrow;
+                            rres[buf][i] = *reinterpret_cast<const half8*>(a.residual + (size_t)row * a.ldr + n0 + wn * TN * 32 + rch * 8);
+                        }
+                    }
+                };
+                res_prefetch(0, 0);
+                (void)rres;
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     float ln_mu = 0.f, ln_rstd = 1.f, ln_cm = 0.f;
                     if constexpr (LNA && !TOK_COLS) {
-                        const float2 st2 = reinterpret_cast<const float2*>(a.ln_stats)[m0 + (wm * TM + tm) * 32 + ql];
+                        const float2 st2 = reinterpret_cast<const float2*>(a.ln_stats)[m0 + (wm * TM + tm) * 32 + qlx];
                         ln_mu = st2.x;
                         ln_rstd = st2.y;
                     }
-                    if constexpr (TOK_COLS) ln_cm = (float)a.ln_c[m0 + (wm * TM + tm) * 32 + ql];
+                    if constexpr (TOK_COLS) ln_cm = (float)a.ln_c[m0 + (wm * TM + tm) * 32 + qlx];
                     (void)ln_mu;
                     (void)ln_rstd;
                     (void)ln_cm;
@@ -461,35 +504,29 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                             }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            float tmu[8], trs[8];  // TOK_COLS: the statistics of this lane's 8 tokens (columns)
-                            if constexpr (TOK_COLS) {
-                                const floatx4* sp = reinterpret_cast<const floatx4*>(a.ln_stats) + (size_t)(n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h)) / 2;
-#pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) {
-                                    const floatx4 t4 = sp[q4];
-                                    tmu[2 * q4] = t4[0];
-                                    trs[2 * q4] = t4[1];
-                                    tmu[2 * q4 + 1] = t4[2];
-                                    trs[2 * q4 + 1] = t4[3];
-                                }
-                            }
-                            (void)tmu;
-                            (void)trs;
+
                             half8 o, bcol, ccol;
                             if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
                                 if constexpr (HOIST)
                                     bcol = bb[tn][u];
                                 else
-                                    bcol = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
-                                if constexpr (LNA) ccol = *reinterpret_cast<const half8*>(a.ln_c + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + h));
+                                    bcol = *reinterpret_cast<const half8*>(a.bias + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + hx));
+                                if constexpr (LNA) ccol = *reinterpret_cast<const half8*>(a.ln_c + n0 + (wn * TN + tn) * 32 + 8 * (2 * u + hx));
                             }
                             (void)bcol;
                             (void)ccol;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 float v = c[8 * u + e];
-                                if constexpr (TOK_COLS)
-                                    v = trs[e] * (v - tmu[e] * ln_cm) + bias_row[tm];
+                                if constexpr (TOK_COLS) {
+                                    // this lane's token: column tn*32 + 16 u + 8 hx + e of the wave's 64 = lane t0 (+ 8 for the upper half-lanes)
+                                    const int t0 = tn * 32 + 16 * u + e;
+                                    const float m_lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lane_mu), t0));
+                                    const float m_hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lane_mu), t0 + 8));
+                                    const float r_lo = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lane_rstd), t0));
+                                    const float r_hi = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lane_rstd), t0 + 8));
+                                    v = (hx ? r_hi : r_lo) * (v - (hx ? m_hi : m_lo) * ln_cm) + bias_row[tm];
+                                }
                                 else if constexpr (LNA)
                                     v = ln_rstd * (v - ln_mu * (float)ccol[e]) + (float)bcol[e];
                                 else {
@@ -499,10 +536,20 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                                 if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
                                 o[e] = (_Float16)v;
                             }
-                            const int chunk = tn * 4 + u * 2 + h;  // the lane's 8 columns inside the row's 64
-                            *reinterpret_cast<half8*>(stg + ql * 128 + ((chunk ^ (ql & 7)) << 4)) = o;
+                            const int chunk = tn * 4 + u * 2 + hx;  // the lane's 8 columns inside the row's 64
+                            *reinterpret_cast<half8*>(stg + qlx * 128 + ((chunk ^ (qlx & 7)) << 4)) = o;
                         }
                     }
+                    // (the next part's residual rows: requested here, where this part's 32 accumulator registers have just died)
+                    if (tm + 1 < TM) res_prefetch((tm + 1) & 1, tm + 1);
+                    float2 rstt[4];  // (the residual rows' statistics: a 270 KB array three tiles of a row strip share — L2 hits, requested together)
+                    if constexpr (RESLN) {
+                        if (a.res_stats) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rstt[i] = reinterpret_cast<const float2*>(a.res_stats)[m0 + wm * TM * 32 + tm * 32 + 8 * i + rrow];
+                        }
+                    }
+                    (void)rstt;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own writes; no other wave touches stg)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -510,14 +557,14 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                         half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tm * 32 + 8 * i) * ldrow);
                         if constexpr (RESLN) {
                             const int row = m0 + wm * TM * 32 + tm * 32 + 8 * i + rrow;
-                            const half8 r8 = *reinterpret_cast<const half8*>(a.residual + (size_t)row * a.ldr + n0 + wn * TN * 32 + rch * 8);
+                            const half8 r8 = rres[tm & 1][i];
                             float rr[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) rr[e] = (float)r8[e];
                             if (a.res_stats) {
-                                // (gain and shift of the residual's LayerNorm for this lane's 8 read-back columns: re-read per row
-                                // group from L1 rather than held in 8 registers across the tile)
-                                const float2 rs = reinterpret_cast<const float2*>(a.res_stats)[row];
+                                // (gain and shift of the residual's LayerNorm for this lane's 8 read-back columns: re-read from L1 per
+                                // row group rather than held in 8 registers across the tile)
+                                const float2 rs = rstt[i];
                                 const half8 rg = *reinterpret_cast<const half8*>(a.res_gamma + n0 + wn * TN * 32 + rch * 8);
                                 const half8 rbeta = *reinterpret_cast<const half8*>(a.res_beta + n0 + wn * TN * 32 + rch * 8);
 #pragma unroll
@@ -531,12 +578,14 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_pkernel(BhGemmArgs a) {
                                 s1 += zf;
                                 s2 = fmaf(zf, zf, s2);
                             }
-                            // the 8 lanes of a row (rch = 0 .. 7) are neighbours: xor-butterfly, every lane ends with the row's sums
-#pragma unroll
-                            for (int o2 = 1; o2 < 8; o2 <<= 1) {
-                                s1 += __shfl_xor(s1, o2, 64);
-                                s2 += __shfl_xor(s2, o2, 64);
-                            }
+                            // the 8 lanes of a row (rch = 0 .. 7) are neighbours: two quad butterflies and one half-row mirror, all DPP
+                            // (VALU; the ds_bpermute form of __shfl_xor cost ~3 us per tile in dependent LDS round trips)
+                            s1 += dpp_f32<0xB1>(s1);   // quad_perm [1, 0, 3, 2]
+                            s2 += dpp_f32<0xB1>(s2);
+                            s1 += dpp_f32<0x4E>(s1);   // quad_perm [2, 3, 0, 1]
+                            s2 += dpp_f32<0x4E>(s2);
+                            s1 += dpp_f32<0x141>(s1);  // row_half_mirror: lane i <-> 7 - i of its 8
+                            s2 += dpp_f32<0x141>(s2);
                             if (rch == 0)
                                 reinterpret_cast<float2*>(a.stats_out)[(size_t)row * (a.N >> 6) + ((n0 + wn * TN * 32) >> 6)] = make_float2(s1, s2);
                         }

@@ -18,7 +18,11 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # tracked scores per query block of its shared bound (RB = 2) do not fit beside 24 x 2 pinned query fragments; the variant
 # without tracking (256 slots of one row) would loosen the bound from rank ~430 to rank ~1 570 and quadruple the candidates.
 # Its tile loop is checked instruction by instruction in test_scan256_isa.py; lists of 64 and 128 are spill-free and checked here)
-ALLOW_SCRATCH = re.compile(r"bh_gemm_f16_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi[1-9]"
+# (bh_gemm_f16_pkernel<BIAS_COL | RESLN, 33>, the residual + LayerNorm-statistics epilogue of round 5: ONE dword per lane, a loop-invariant the
+# epilogue needs, is parked in scratch before the main loop and read back once after it — no scratch instruction between the first and the last
+# MFMA of the kernel; capped below)
+ALLOW_SCRATCH = re.compile(r"bh_gemm_f16_pkernelILi257ELi33E"
+                           r"|bh_gemm_f16_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi[1-9]"
                            r"|bh_scan_topk256_kernelILi24ELi256E"
                            r"|bh_scan_topk256_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi[1-9]"
                            r"|bh_scan_topk256_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi0ELi(0|2|3)E"
@@ -71,6 +75,9 @@ def test_production_kernels_do_not_spill():
     for name, u in results["scan_topk256.hip"].items():
         if re.search(r"bh_scan_topk256_kernelILi24ELi256ELi12ELi3ELi4ELb[01]ELi0E", name):
             assert u.get("ScratchSize", 0) <= 32, f"{name}: {u.get('ScratchSize')} bytes/lane of scratch"
+    for name, u in results["gemm_f16_c.hip"].items():
+        if "pkernelILi257ELi33E" in name:
+            assert u.get("ScratchSize", 0) <= 8, f"{name}: {u.get('ScratchSize')} bytes/lane of scratch"
     # occupancy assumptions of the launch geometry
     pk = {n: u for n, u in results["gemm_f16_c.hip"].items() if "pkernel" in n}
     assert pk and all(u["Occupancy"] >= 2 for u in pk.values())          # 8 waves per CU on 4 SIMDs
