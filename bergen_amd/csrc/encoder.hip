@@ -67,14 +67,22 @@ struct bh_encoder {
     // workspace
     BhDevBuf<_Float16> X, Y, QK, VT, CTX, H, OUT;
     BhDevBuf<_Float16> GU;       // gated feed-forward (cfg.ffn_gated), unfused form: [rows][2 dff] = (gate, up) column pairs of ONE GEMM, folded into H by bh_swiglu_kernel
-    // Fused LayerNorm (option "ln_fused", default 1; BERT-type stacks: no gated feed-forward, no disentangled attention).  The 24
+    // Fused LayerNorm (option "ln_fused", default 0 — see the end of this comment; BERT-type stacks: no gated feed-forward, no disentangled attention).  The 24
     // LayerNorm passes of a 12-layer forward (each reads two activation tensors and writes one: 316 MB for 512 passages, 11 % of the
     // forward's stream time in profiles/r05a_encoder_kernel_stats.csv) disappear: the output-projection and FFN-down GEMMs add the
     // residual in their epilogue, store the PRE-LayerNorm sum z and the per-row (sum, sum of squares) of what they stored; a tiny
     // kernel turns those into (mean, rstd) per row; the GEMMs that consume LN(z) read z itself against weights folded with the
     // LayerNorm's gain and finish the normalisation algebraically in their epilogue (gemm_f16_persist.h BH_EPI_LNA / BH_EPI_RESLN).
     // Only the last layer's output is normalised by the LayerNorm kernel (the poolers and heads read it).
-    int ln_fused = 1;
+    // MEASURED SLOWER, hence OFF by default (round 5, same process, alternating; profiles/r05b_first_* and r05b_second_*): BERT-base 512
+    // passages 14.41 -> 14.67 ms, e5-large shape 44.75 -> 45.94 ms — although bh_layernorm_kernel (10.9 % of the forward's stream time)
+    // is gone from the trace.  Why: the persistent GEMM's epilogue is the one place of this design where latency is not hidden — both waves
+    // of every SIMD are in it at the same time and the CU holds no other workgroup —, so the residual rows it now has to READ (128 KB per
+    // tile, 16 dependent round trips before prefetching, 4 after) cost +18 us per tile of the K = 768 output projection (a 13 us tile), and
+    // the 46 statistics kernels per forward queue behind the other stream's persistent workgroups (43 us each on average).  The second
+    // version (residual rows one part ahead, DPP reductions, lane-resident token statistics: V^T back to parity) recovered a third of it.
+    // What would have to change: the residual landing in LDS by LDS-DMA during the main loop's last stages — there is no LDS left for it.
+    int ln_fused = 0;
     _Float16* ln_arena = nullptr;
     BhDevBuf<float> LNP, S1, S2;  // per-row partial (sum, sum of squares) slices [rows][d / 64][2]; (mean, rstd) of z1 / z2 [rows][2]
     int ffn_fused = 1;           // option "ffn_fused": the persistent GEMM folds the pairs in its epilogue where it applies (0: always GU + fold kernel)

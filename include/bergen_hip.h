@@ -237,7 +237,8 @@ typedef struct bh_encoder_counters {
     /* ---- since BH_VERSION 142 ---- */
     int32_t ln_fused;     /* 1 = the last forward pass ran WITHOUT standalone LayerNorm passes between its GEMMs (residual add +
                              row statistics in the producing GEMM's epilogue, normalisation folded into the consuming GEMM: option
-                             "ln_fused", BERT-type stacks, batches whose GEMMs fill the chip); 0 = one LayerNorm kernel per LayerNorm */
+                             "ln_fused" = 1 — off by default: measured 2 % slower —, BERT-type stacks, batches whose GEMMs fill the chip);
+                             0 = one LayerNorm kernel per LayerNorm */
     int32_t reserved0;
 } bh_encoder_counters;
 
