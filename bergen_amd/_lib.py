@@ -62,6 +62,9 @@ class bh_counters(_Sized):
         ("paired_scan_ms", ctypes.c_double),
         ("paired_launches", ctypes.c_int32),
         ("reserved1", ctypes.c_int32),
+        ("balanced_scan_ms", ctypes.c_double),   # since BH_VERSION 142
+        ("balanced_queries", ctypes.c_int32),
+        ("reserved2", ctypes.c_int32),
     ]
 
 

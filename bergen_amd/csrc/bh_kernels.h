@@ -25,6 +25,11 @@ struct BhScanArgs {
     int pair_window;         // qsplit = 2: a workgroup may run at most this many tiles ahead of its partner (0 = free-running)
     int dyn_tiles;           // scan_topk256: tiles handed out in chunks by a claim counter instead of round robin
     bh_u64* clk;             // optional diagnostics [grid][8] phase stamps + BH_TL_WORDS timeline words (scan_topk256.hip)
+    // scan_topk256: queries of the tile that EXIST (0 = all of them).  A wave whose queries all lie beyond that count neither reads
+    // fragments nor issues MFMAs nor filters — it keeps its share of the LDS-DMA refill, the rendezvous and the pacing / claim duties.
+    // [1] = the second pass of a paired launch; qtile2 (optional) = that pass's query tile when it does not sit 256 rows behind qtile.
+    int nq_valid[2] = {0, 0};
+    const _Float16* qtile2 = nullptr;
     // filter pass of the exactness fall-back (bh_launch_filter_scan; unused by the top-k scans)
     const float* fix_thr = nullptr;  // [128] a row qualifies for query q iff its MFMA score >= fix_thr[q] (+inf: unused query)
     unsigned* fix_cnt = nullptr;     // [128] qualifying rows per query, zeroed by the caller; may exceed fix_cap (overflow)

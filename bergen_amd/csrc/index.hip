@@ -63,6 +63,7 @@ struct Options {
     int tail128 = 1;  // scan_topk256: a last pass of at most 128 queries runs on the 128-query kernel (5.6 instead of 7.2 ms at 21 M x 768)
     int err_scale = 1;  // test-only: multiplies the certificate's error bound (forces queries through the fall-back)
     int filter256 = 1;  // exact fall-back: filter passes of 256 queries on scan_topk256.hip where it applies (0: 128 queries on scan_topk.hip)
+    int balance_tail = 1;  // scan_topk256 + pair256: the remainder of a query set (more than one tile, fewer than two) as ONE balanced paired launch (search_device_lists)
     int pair256 = 1;    // scan_topk256: workgroups b and b ^ 8 (same XCD) walk the same tiles for two 256-query passes of one launch (1 = paced every 16 tiles, 2 = free-running, 3 = paced with the non-temporal stream policy of the unpaired launches)
 };
 
@@ -93,6 +94,7 @@ const OptionDef g_option_defs[] = {
     {"workgroups_per_cu", &Options::workgroups_per_cu, 1, 1, {-1, -1, -1, -1}, "workgroups_per_cu must be 1 (LDS ring fills the CU)"},
     {"filter256", &Options::filter256, 0, 1, {-1, -1, -1, -1}, "filter256 must be 0 or 1"},
     {"pair256", &Options::pair256, 0, 3, {-1, -1, -1, -1}, "pair256 must be 0..3"},
+    {"balance_tail", &Options::balance_tail, 0, 1, {-1, -1, -1, -1}, "balance_tail must be 0 or 1"},
 };
 constexpr int kUnset = INT32_MIN;  // per-handle override table: "inherit the process-wide value"
 
@@ -573,6 +575,28 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         passes.push_back({q0, qs});
         q0 += bq * qs;
     }
+    // BALANCED REMAINDER (option balance_tail, default on; scan_topk256 with paired launches): when the queries left behind the last
+    // full pair of passes are more than one tile (bq < R < 2 bq — 2 837 = 5 x 512 + 277), they used to run as a full pass alone on the
+    // whole chip plus a tail pass on the 128-query kernel (7.1 + 4.9 ms, the tail another corpus read for 21 queries).  Now they are
+    // cut into two passes of about R / 2 queries — the first a whole number of 32-query waves — that run as ONE more paired launch:
+    // the corpus is read once for both, and the waves of a workgroup that hold no query at all sit the tiles out (BhScanArgs::
+    // nq_valid: no fragment reads, no MFMAs, no filter), so each half-grid carries half the matrix work of a full pass.  The second
+    // pass's query tile starts where the first one's queries end (BhScanArgs::qtile2): the query buffer stays contiguous.
+    int bal_first = -1, bal_nq[2] = {0, 0};  // pass index of the balanced pair (its first pass) and the two passes' query counts
+    if (use256 && qs_max == 1 && opt.balance_tail != 0 && opt.pair256 != 0 && opt.ablate == 0 && grid == 256 && (int)passes.size() >= 2 &&
+        bh_scan256_pair_supports(dp, kp) && (dp != 1024 || opt.ring_variant == 0 || opt.ring_variant == 5)) {
+        const int np = (int)passes.size();
+        const int n_full_pairs = (np - 2) / 2 * 2 == np - 2 ? (np - 2) / 2 : -1;  // the last two passes must be a pair of their own
+        const int rem = nq - (np - 2) * bq;                                        // queries of the last two passes: bq < rem <= 2 bq
+        if (n_full_pairs >= 0 && rem > bq && rem < 2 * bq) {
+            const int per_wave = bq / 8;
+            bal_nq[0] = ((rem + 1) / 2 + per_wave - 1) / per_wave * per_wave;      // whole waves: the tile behind them belongs to the next pass
+            if (bal_nq[0] > bq) bal_nq[0] = bq;
+            bal_nq[1] = rem - bal_nq[0];
+            bal_first = np - 2;
+            passes[(size_t)np - 1].first = passes[(size_t)np - 2].first + bal_nq[0];
+        }
+    }
     const int n_pass = (int)passes.size();
     const int64_t nq_pad = (int64_t)((nq + bq - 1) / bq) * bq;
 
@@ -617,7 +641,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     if (!ev_begin || !ev_end) return fail(BH_EHIP, "hipEventCreate failed");
     // scan_topk256: a last pass of at most 128 queries (2 837 = 11 x 256 + 21) runs on the 128-query kernel — the same
     // corpus pass costs 5.6 instead of 7.2 ms there —, as a group of its own (its lists are 128 queries wide)
-    const bool tail128 = grouped && use256 && bq == 256 && opt.tail128 && opt.ablate == 0 && nq % bq != 0 && nq % bq <= 128;
+    const bool tail128 = grouped && use256 && bq == 256 && opt.tail128 && opt.ablate == 0 && nq % bq != 0 && nq % bq <= 128 && bal_first < 0;
     const int n_main = tail128 ? n_pass - 1 : n_pass;
     // option pair256 (scan_topk256.hip, ABL bit 128): the main passes two at a time in ONE launch — each pass on half the grid, the
     // partner workgroups of the two passes on one XCD walking the same tiles, so that a corpus line leaves HBM once per 512
@@ -631,7 +655,9 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         bool paired;
     };
     std::vector<Group> groups;
-    for (int g0 = 0; g0 < n_paired; g0 += 2 * group) groups.push_back({g0, std::min(n_paired, g0 + 2 * group), true});
+    const int n_paired_full = bal_first >= 0 ? bal_first : n_paired;  // (the balanced pair is merged pass by pass: its passes do not start bq apart)
+    for (int g0 = 0; g0 < n_paired_full; g0 += 2 * group) groups.push_back({g0, std::min(n_paired_full, g0 + 2 * group), true});
+    if (bal_first >= 0) groups.push_back({bal_first, bal_first + 2, true});
     for (int g0 = n_paired; g0 < n_main; g0 += group) groups.push_back({g0, std::min(n_main, g0 + group), false});
     const int n_group = grouped ? (int)groups.size() + (tail128 ? 1 : 0) : n_pass;
     for (int p = 0; p < n_group; ++p)
@@ -702,6 +728,14 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
             for (int p = g0; p < g1; p += paired ? 2 : 1) {
                 BhScanArgs sa = scan_args(p, ix->partial.p + (size_t)(p - g0) * pass_elems);
                 if (paired) {  // passes p and p + 1: queries, threshold blocks and list sets behind each other
+                    if (p == bal_first) {
+                        sa.nq_valid[0] = bal_nq[0];
+                        sa.nq_valid[1] = bal_nq[1];
+                        sa.qtile2 = ix->qbuf.p + (size_t)passes[(size_t)p + 1].first * dp;
+                    } else {
+                        sa.nq_valid[0] = bq;
+                        sa.nq_valid[1] = std::min(bq, nq - passes[(size_t)p + 1].first);
+                    }
                     sa.qsplit = 2;
                     sa.pair_window = opt.pair256 == 2 ? 0 : 1;
                     // the partner finds a line in L2 only if the first reader's request left it there: the stream of a paired
@@ -710,6 +744,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
                     HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
                     HIP_TRY(bh_launch_scan256_paired(sa, dp, kp, grid, st));
                 } else {
+                    sa.nq_valid[0] = std::min(bq, nq - passes[(size_t)p].first);
                     HIP_TRY(launch_scan(sa));
                 }
                 // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d
@@ -718,6 +753,10 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 1), st));
             const int q0 = passes[g0].first;
             const int nq_group = std::min(nq, passes[g1 - 1].first + bq) - q0;
+            if (g0 == bal_first) {  // the balanced pair: one merge per pass (the second pass's queries start bal_nq[0], not bq, behind the first's)
+                HIP_TRY(bh_launch_merge_rescore(merge_args(q0, bq, grid / 2, ix->partial.p, 0), kp, bal_nq[0], st));
+                HIP_TRY(bh_launch_merge_rescore(merge_args(passes[(size_t)g0 + 1].first, bq, grid / 2, ix->partial.p + pass_elems, 0), kp, bal_nq[1], st));
+            } else
             HIP_TRY(bh_launch_merge_rescore(merge_args(q0, bq, paired ? grid / 2 : grid, ix->partial.p, (long long)pass_elems), kp, nq_group, st));
             HIP_TRY(hipEventRecord(ix->event(2 + 4 * gi + 3), st));
         }
@@ -938,6 +977,8 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     c.merge_ms = 0;
     c.paired_scan_ms = 0;
     c.paired_launches = n_paired / 2;
+    c.balanced_scan_ms = 0;
+    c.balanced_queries = bal_first >= 0 ? bal_nq[0] + bal_nq[1] : 0;
     for (int p = 0; p < n_group; ++p) {
         float ms = 0;
         // grouped: the group's scans back to back (launch gaps included), then its one merge; paired: per pass, the merge
@@ -945,6 +986,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
         HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p), ix->event(2 + 4 * p + 1)));
         c.scan_ms += ms;
         if (grouped && p < (int)groups.size() && groups[(size_t)p].paired) c.paired_scan_ms += ms;
+        if (grouped && p < (int)groups.size() && bal_first >= 0 && groups[(size_t)p].p0 == bal_first) c.balanced_scan_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ix->event(2 + 4 * p + (grouped ? 1 : 2)), ix->event(2 + 4 * p + 3)));
         c.merge_ms += ms;
     }
@@ -1045,6 +1087,8 @@ int search_large_k(bh_index* ix, const void* q_dev, int32_t q_dtype, int32_t nq,
         total.exact_rows_rescored += c.exact_rows_rescored;
         total.paired_scan_ms += c.paired_scan_ms;
         total.paired_launches += c.paired_launches;
+        total.balanced_scan_ms += c.balanced_scan_ms;
+        total.balanced_queries += c.balanced_queries;
         total.query_tile = c.query_tile;
         total.n_workgroups = c.n_workgroups;
         total.k_padded = c.k_padded;

@@ -207,9 +207,17 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         G >>= 1;
         b_pass = (bc & 7) | ((bc >> 4) << 3);
         b = h * G + b_pass;
-        a.qtile += (size_t)h * (8 * 16 * NB) * (NK32 * 32);
+        a.qtile = (h != 0 && a.qtile2 != nullptr) ? a.qtile2 : a.qtile + (size_t)h * (8 * 16 * NB) * (NK32 * 32);
         a.gthr += (size_t)h * ((size_t)(8 * 16 * NB) * (BH_SLOTS256 + 1) + 4);
+        if (h != 0) a.nq_valid[0] = a.nq_valid[1];
     }
+    // A wave without a single existing query (a tile of fewer than 256 queries: the remainder of a query set, balanced over the two
+    // passes of a paired launch by index.hip) leaves the matrix pipe and the LDS read ports to the waves that have some: no fragment
+    // reads, no MFMAs, no filter.  It still issues its lines of every refill, meets every rendezvous and (wave 7) paces and claims.
+    // (compiled out — every wave scans — in the filter pass of the exact fall-back, whose unused queries carry a +inf threshold)
+    constexpr bool IDLE_WAVES = (ABL & 64) == 0;
+    const int nq_here = __builtin_amdgcn_readfirstlane(a.nq_valid[0]);
+    const bool wave_on = !IDLE_WAVES || nq_here <= 0 || wave * (16 * NB) < nq_here;  // wave-uniform; tested ONCE, in front of the tile loop
     auto gthr_pass = [&]() -> unsigned* { return a.gthr; };  // (paired: moved to the pass's block above)
     const int q16 = lane & 15, lg = lane >> 4;
 
@@ -429,6 +437,112 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
         bool boot = nboot > 0;
         int tj = 0;  // tile of the bootstrap / of the current run
         int i = 0;   // tiles scanned so far (threshold exchange schedule)
+        // the bookkeeping between two tiles (bootstrap / run / exchange counters, the paired launch's checkpoints, the claim of the next
+        // run, the switch to it): shared by the scanning loop and the idle loop below; true = the workgroup's tiles are done
+        auto next_tile = [&]() -> bool {
+            ++tj;
+            if (boot) {
+                if (tj == nboot) {
+                    boot = false;
+                    tj = 0;
+                }
+                return false;
+            }
+            ++i;
+            if (i > n_tiles) return true;  // (cannot happen: a workgroup never scans more tiles than there are; keeps a logic error from hanging the GPU)
+            if constexpr (PAIRED) {
+                // Checkpoint every BH_PAIR_CKPT (16) tiles of the round-robin run: wave 7 publishes the count and starts the load of the
+                // partner's word (LDS-DMA into the word behind the claim word: no register is in flight; the rendezvous of
+                // the next tile waits for it with the refill); one tile later it reads the word and, if the partner has not
+                // reached the checkpoint, polls until it has.  The other waves wait at the next rendezvous meanwhile.
+                // Nothing of this lives in registers across the tile loop: the workgroup's progress pointer is parked in LDS
+                // (null = not paced), the partner's word is 32 bytes away from it (bc ^ 8; the block is 64-byte aligned).
+                if (run_stride != 1 && wave == 7 && (i & (BH_PAIR_CKPT - 2)) == 0 && i > 1) {
+                    const unsigned long long ppv = *(volatile unsigned long long*)(lds_claim + 2);
+                    unsigned pv = *(volatile unsigned*)(lds_claim + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragment reads in flight land too: no register moves)
+                    const unsigned long long pp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ppv >> 32)) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ppv);
+                    if (pp != 0ull) {
+                        unsigned* mine = reinterpret_cast<unsigned*>(pp);
+                        const unsigned* theirs = reinterpret_cast<const unsigned*>(pp ^ 32ull);
+                        if ((i & 1) == 0) {
+                            if (opaque_lane() == 0) {
+                                __hip_atomic_fetch_max(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)theirs,
+                                                                 (__attribute__((address_space(3))) void*)(lds_claim + 1), 4, 0, 16);
+                            }
+                        } else {
+                            int spins = 0;
+                            while ((unsigned)__builtin_amdgcn_readfirstlane(pv) + 1u < (unsigned)i) {
+                                if (++spins > 8192) {  // the partner is not coming (not resident?): stop pacing
+                                    if (opaque_lane() == 0) *(volatile unsigned long long*)(lds_claim + 2) = 0ull;
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(8);
+                                if (opaque_lane() == 0)
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)theirs,
+                                                                     (__attribute__((address_space(3))) void*)(lds_claim + 1), 4, 0, 16);
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                pv = *(volatile unsigned*)(lds_claim + 1);
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
+                        }
+                    }
+                }
+            }
+            if constexpr (DYN) {
+                // The run after the current one: claimed LEAD + 2 tiles before the current run's end by wave 7 (it does not
+                // issue LDS-DMA, its vmcnt is its own; it waits for the answer on the spot — an answer on its way into a
+                // register the compiler allocates is not safe — which holds the workgroup up for ~1.5 us, a handful of
+                // times per launch), parked in LDS, read by every wave one tile later (the rendezvous between make it
+                // visible) — a tile before the issue cursor, up to LEAD tiles ahead, leaves the run.
+                if (dyn && run_len >= CH) {  // (a shorter run is the corpus's last, clipped: nothing follows)
+                    const int left = run_len - tj;
+                    if (left == LEAD + 2 && wave == 7) {
+                        unsigned* ctr = gthr_pass() + (size_t)BQ * (BH_SLOTS256 + 1);
+                        unsigned got = (unsigned)claim_len;
+                        const unsigned off = 0u;
+                        if (opaque_lane() == 0) {
+                            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %0, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "+v"(got) : "v"(off), "s"(sgpr_ptr(ctr)) : "memory");
+                            *(volatile unsigned*)lds_claim = got;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else if (left == LEAD + 1) {
+                        const unsigned got = *(volatile unsigned*)lds_claim;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragment reads in flight land too: no register moves)
+                        // (the host starts the counter at the first tile of the claimed part of the corpus)
+                        const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane(got);
+                        if (t0 < (unsigned)n_tiles) {
+                            nxt_base = (int)t0;
+                            nxt_len = n_tiles - nxt_base < claim_len ? n_tiles - nxt_base : claim_len;
+                        }
+                        claim_len = claim_len >= 2 * CH ? claim_len >> 1 : CH;
+                    }
+                }
+            }
+            if (tj == run_len) {
+                if constexpr (PAIRED) {  // the partner must not wait for a workgroup that has left the shared tiles
+                    if (run_stride != 1 && wave == 7) {
+                        const unsigned long long ppv = *(volatile unsigned long long*)(lds_claim + 2);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const unsigned long long pp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ppv >> 32)) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ppv);
+                        if (pp != 0ull && opaque_lane() == 0)
+                            __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(pp), 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (nxt_len == 0) return true;
+                run_base = nxt_base;
+                run_stride = 1;
+                run_len = nxt_len;
+                nxt_len = 0;
+                tj = 0;
+                if (it_phase == 2) it_phase = 1;  // (the issue cursor is ahead of the tile just finished: it stands in the new run)
+            }
+            return false;
+        };
+        if (wave_on) {
         for (;;) {
             const int tile_id = run_base + tj * (boot ? boot_step : run_stride);
             // four independent accumulator chains (row block x query block): consecutive MFMAs never share one, so the
@@ -442,11 +556,7 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                 unsigned long long tl0 = 0, tl1 = 0, tl2 = 0, tl_dma = 0;
                 const bool tl_on = (ABL & 32) != 0 && b == 0 && i >= BH_TL_TILE0 && i < BH_TL_TILE0 + BH_TL_TILES;
                 const int nslot = cslot + 1 == R ? 0 : cslot + 1;
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const int ks = (part * LS + (f >> 2)) * 2 + ((f >> 1) & 1);  // k-step of 32 dims
-                    const int rb = f & 1;
-                    if (f == BF) {
+                auto rendezvous = [&]() {
                         // Rendezvous of stage s, taken at its fragment BF.  Own pieces of stage s+1 landed (R-3 younger
                         // stages stay in flight), then everybody's did, and everybody has left stage s-1, whose slot this
                         // stage's refill overwrites.  With BF in the middle of the stage a wave runs from one stage into
@@ -464,7 +574,12 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                             for (int j = 0; j < DPW; ++j) issue_line(j);
                             if (tl_on) tl_dma = __builtin_readcyclecounter() - tl2;
                         }
-                    }
+                };
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int ks = (part * LS + (f >> 2)) * 2 + ((f >> 1) & 1);  // k-step of 32 dims
+                    const int rb = f & 1;
+                    if (f == BF) rendezvous();
                     if constexpr (!(ABL & 2)) {
                         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD - 1));
                         asm volatile("" : "+v"(ag[f % NBUF]));
@@ -735,106 +850,26 @@ __global__ void __launch_bounds__(512, 2) bh_scan_topk256_kernel(BhScanArgs a) {
                     }
                 }
             }
-            // ---- next tile
-            ++tj;
-            if (boot) {
-                if (tj == nboot) {
-                    boot = false;
-                    tj = 0;
-                }
-                continue;
-            }
-            ++i;
-            if (i > n_tiles) break;  // (cannot happen: a workgroup never scans more tiles than there are; keeps a logic error from hanging the GPU)
-            if constexpr (PAIRED) {
-                // Checkpoint every BH_PAIR_CKPT (16) tiles of the round-robin run: wave 7 publishes the count and starts the load of the
-                // partner's word (LDS-DMA into the word behind the claim word: no register is in flight; the rendezvous of
-                // the next tile waits for it with the refill); one tile later it reads the word and, if the partner has not
-                // reached the checkpoint, polls until it has.  The other waves wait at the next rendezvous meanwhile.
-                // Nothing of this lives in registers across the tile loop: the workgroup's progress pointer is parked in LDS
-                // (null = not paced), the partner's word is 32 bytes away from it (bc ^ 8; the block is 64-byte aligned).
-                if (run_stride != 1 && wave == 7 && (i & (BH_PAIR_CKPT - 2)) == 0 && i > 1) {
-                    const unsigned long long ppv = *(volatile unsigned long long*)(lds_claim + 2);
-                    unsigned pv = *(volatile unsigned*)(lds_claim + 1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragment reads in flight land too: no register moves)
-                    const unsigned long long pp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ppv >> 32)) << 32) |
-                                                  (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ppv);
-                    if (pp != 0ull) {
-                        unsigned* mine = reinterpret_cast<unsigned*>(pp);
-                        const unsigned* theirs = reinterpret_cast<const unsigned*>(pp ^ 32ull);
-                        if ((i & 1) == 0) {
-                            if (opaque_lane() == 0) {
-                                __hip_atomic_fetch_max(mine, (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)theirs,
-                                                                 (__attribute__((address_space(3))) void*)(lds_claim + 1), 4, 0, 16);
-                            }
-                        } else {
-                            int spins = 0;
-                            while ((unsigned)__builtin_amdgcn_readfirstlane(pv) + 1u < (unsigned)i) {
-                                if (++spins > 8192) {  // the partner is not coming (not resident?): stop pacing
-                                    if (opaque_lane() == 0) *(volatile unsigned long long*)(lds_claim + 2) = 0ull;
-                                    break;
-                                }
-                                __builtin_amdgcn_s_sleep(8);
-                                if (opaque_lane() == 0)
-                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)theirs,
-                                                                     (__attribute__((address_space(3))) void*)(lds_claim + 1), 4, 0, 16);
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                pv = *(volatile unsigned*)(lds_claim + 1);
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            }
-                        }
+
+            if (next_tile()) break;
+        }
+        } else {
+            // A wave none of whose queries exists (BhScanArgs::nq_valid): its tile is the stage rendezvous, its lines of the refill
+            // and the bookkeeping — no fragment reads, no MFMAs, no filter.  (The choice is made HERE, once: a flag tested inside
+            // the tile loop would need a scalar register across it, and the scalar file is full.)
+            for (;;) {
+#pragma unroll
+                for (int part = 0; part < S; ++part) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * DPW) : "memory");
+                    if constexpr (!(ABL & 16)) asm volatile("s_barrier" ::: "memory");
+                    if (loader && !(ABL & 8)) {
+#pragma unroll
+                        for (int j = 0; j < DPW; ++j) issue_line(j);
                     }
+                    advance_cursor();
+                    cslot = cslot + 1 == R ? 0 : cslot + 1;
                 }
-            }
-            if constexpr (DYN) {
-                // The run after the current one: claimed LEAD + 2 tiles before the current run's end by wave 7 (it does not
-                // issue LDS-DMA, its vmcnt is its own; it waits for the answer on the spot — an answer on its way into a
-                // register the compiler allocates is not safe — which holds the workgroup up for ~1.5 us, a handful of
-                // times per launch), parked in LDS, read by every wave one tile later (the rendezvous between make it
-                // visible) — a tile before the issue cursor, up to LEAD tiles ahead, leaves the run.
-                if (dyn && run_len >= CH) {  // (a shorter run is the corpus's last, clipped: nothing follows)
-                    const int left = run_len - tj;
-                    if (left == LEAD + 2 && wave == 7) {
-                        unsigned* ctr = gthr_pass() + (size_t)BQ * (BH_SLOTS256 + 1);
-                        unsigned got = (unsigned)claim_len;
-                        const unsigned off = 0u;
-                        if (opaque_lane() == 0) {
-                            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %0, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "+v"(got) : "v"(off), "s"(sgpr_ptr(ctr)) : "memory");
-                            *(volatile unsigned*)lds_claim = got;
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    } else if (left == LEAD + 1) {
-                        const unsigned got = *(volatile unsigned*)lds_claim;
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the fragment reads in flight land too: no register moves)
-                        // (the host starts the counter at the first tile of the claimed part of the corpus)
-                        const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane(got);
-                        if (t0 < (unsigned)n_tiles) {
-                            nxt_base = (int)t0;
-                            nxt_len = n_tiles - nxt_base < claim_len ? n_tiles - nxt_base : claim_len;
-                        }
-                        claim_len = claim_len >= 2 * CH ? claim_len >> 1 : CH;
-                    }
-                }
-            }
-            if (tj == run_len) {
-                if constexpr (PAIRED) {  // the partner must not wait for a workgroup that has left the shared tiles
-                    if (run_stride != 1 && wave == 7) {
-                        const unsigned long long ppv = *(volatile unsigned long long*)(lds_claim + 2);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        const unsigned long long pp = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ppv >> 32)) << 32) |
-                                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)ppv);
-                        if (pp != 0ull && opaque_lane() == 0)
-                            __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(pp), 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                if (nxt_len == 0) break;
-                run_base = nxt_base;
-                run_stride = 1;
-                run_len = nxt_len;
-                nxt_len = 0;
-                tj = 0;
-                if (it_phase == 2) it_phase = 1;  // (the issue cursor is ahead of the tile just finished: it stands in the new run)
+                if (next_tile()) break;
             }
         }
         // drain: tail re-fetches and the fragment reads still in flight (their registers are dead to the compiler)

@@ -36,7 +36,8 @@ extern "C" {
  * pair256) and bh_encoder_config grew rotary_theta / ffn_gated at its END (NomicBert: rotary positions, gated SiLU feed-forward;
  * a shorter struct reads as plain BERT) + bh_op_rotary / bh_op_swiglu; a caller built against 140 keeps working memory-wise
  * (struct_size) but must be rebuilt to pass the version check; 142 = 0.1.4.2 (round 5): bh_encoder_counters grew ln_fused at its END
- * (whether the last forward pass ran with the LayerNorms fused into the GEMM epilogues: encoder option "ln_fused"). */
+ * (whether the last forward pass ran with the LayerNorms fused into the GEMM epilogues: encoder option "ln_fused") and bh_counters grew
+ * balanced_scan_ms / balanced_queries at its END (option balance_tail). */
 #define BH_VERSION 142
 
 typedef enum bh_status {
@@ -87,6 +88,12 @@ typedef struct bh_counters {
                                  corpus stream of the second served from the L2 of the first's XCD), else 0 */
     int32_t paired_launches;  /* number of such launches in the last search (each counts as 2 in n_passes) */
     int32_t reserved1;
+    /* ---- since BH_VERSION 142 ---- */
+    double balanced_scan_ms;  /* part of paired_scan_ms spent in the BALANCED launch: the queries left behind the last full pair of
+                                 passes (more than one tile, fewer than two) cut into two passes of about half each, run as one more
+                                 paired launch in which waves without any query sit the tiles out (option balance_tail); else 0 */
+    int32_t balanced_queries; /* queries that launch served (0 = no balanced launch in the last search) */
+    int32_t reserved2;
 } bh_counters;
 
 /* Library / device lifecycle ------------------------------------------------------- */

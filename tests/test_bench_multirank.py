@@ -126,6 +126,13 @@ def test_scan_roofline_accounts_for_paired_unpaired_and_tail_launches():
     # the figure that cannot be misread: the larger of (bytes the launch must move) / time / peak and flops / time / peak
     assert r["algorithmic_frac"] == r["frac"] and r["binding_resource"] == "mfma"
     assert abs(r["frac_binding"] - 2.0 * 2 * 256 * n * d / 13.4e-3 / 1e12 / 2500.0) < 1e-9 and r["frac_binding"] < r["frac"]
+    # the balanced remainder (index.hip option balance_tail): six paired launches, the sixth with 277 queries — reported beside the dominant
+    # launch and kept out of its average
+    cb = {"query_tile": 256, "n_passes": 12, "paired_launches": 6, "tail_query_tile": 0, "shader_mhz": 1500.0, "balanced_queries": 277}
+    rb = bench.scan_roofline({"scan_ms": steps * (5 * 13.4 + 8.0), "paired_scan_ms": steps * (5 * 13.4 + 8.0), "tail_scan_ms": 0.0,
+                              "balanced_scan_ms": steps * 8.0}, cb, steps, n, d, k, "missing.json")
+    assert rb["launches"] == 5 * steps and abs(rb["avg_launch_ms"] - 13.4) < 1e-9 and rb["tail_pass"] is None and "unpaired_launch" not in rb
+    assert rb["balanced_launch"]["queries"] == 277 and abs(rb["balanced_launch"]["avg_launch_ms"] - 8.0) < 1e-9
     # pairing off (or a library that does not report it): one pass per launch, the tail pass taken out of the average
     c1 = {"query_tile": 256, "n_passes": 12, "tail_query_tile": 128, "shader_mhz": 1500.0}
     r1 = bench.scan_roofline({"scan_ms": steps * (11 * 7.3 + 5.0), "tail_scan_ms": steps * 5.0}, c1, steps, n, d, k, "missing.json")

@@ -498,6 +498,47 @@ def test_paired_launches_match_oracle(amd, n, d, nq, k):
         ix.close()
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(300001, 768, 277, 50), (120001, 768, 512 + 277, 50), (70001, 768, 1024 + 300, 50), (70001, 768, 511, 100),
+                                      (70001, 768, 257, 200), (4999, 768, 512 + 400, 50), (90001, 1024, 256 + 200, 50), (90001, 1024, 129, 200),
+                                      (60001, 768, 600, 50), (60001, 768, 100, 50)])
+def test_balanced_remainder_and_idle_waves_match_oracle(amd, n, d, nq, k):
+    """Option balance_tail (index.hip, default on): the queries left behind the last full pair of passes — more than one tile, fewer than
+    two: 277 of the headline's 2 837 — run as ONE more paired launch of two passes of about half each (the first a whole number of waves'
+    queries; the second pass's tile starts where the first one's queries end, BhScanArgs::qtile2), in which the waves that hold no query
+    (BhScanArgs::nq_valid) only keep the stage rendezvous and their lines of the refill.  Bit-exact against the oracle with the option
+    on and off, for the headline remainder alone and behind one / two full pairs, lists of 128 / 256, d = 1024 (128-query tiles, 16
+    queries per wave), a corpus with fewer tiles than workgroups; the counters say which routing ran; and the query counts the option
+    does not apply to (an odd number of passes: 600; a single pass: 100 — where the idle waves of an ordinary pass still sit out)."""
+    rng = np.random.default_rng(n + nq + k + d)
+    x = rng.standard_normal((n, d)).astype(np.float16)
+    q = rng.standard_normal((nq, d)).astype(np.float16)
+    x[n // 3] = x[5]  # a tie across workgroups
+    ws, wi = c_oracle.canonical_search(q, x, k)
+    ix = amd.FlatIndex(n, d, metric="ip")
+    ix.upload(x)
+    ix.finalize()
+    tile = 256 if d == 768 else 128
+    n_pass = (nq + tile - 1) // tile
+    rem = nq - (n_pass - 2) * tile
+    applies = n_pass >= 2 and n_pass % 2 == 0 and tile < rem < 2 * tile
+    try:
+        for on in (1, 0, 1):
+            ix.set_option("balance_tail", on)
+            s, i = ix.search(q, k)
+            c = ix.counters()
+            compare.assert_bit_exact(s, i, ws, wi, f"balance_tail={on} n={n} d={d} nq={nq} k={k}")
+            assert c["n_passes"] == n_pass
+            if on and applies:
+                assert c["balanced_queries"] == rem and c["balanced_scan_ms"] > 0 and c["tail_query_tile"] == 0 and c["paired_launches"] == n_pass // 2
+            else:
+                assert c["balanced_queries"] == 0 and c["balanced_scan_ms"] == 0
+        # device-resident queries and the stage's pinned-host outputs take the same routing
+        sd, idd = ix.search(torch.from_numpy(q).cuda(), k)
+        compare.assert_bit_exact(sd.cpu().numpy(), idd.cpu().numpy(), ws, wi, "device queries")
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("k", [50, 56, 120])
 @pytest.mark.parametrize("d", [768, 1024])
 def test_certificate_catches_a_near_tie_cluster_at_rank_k(amd, k, d):
@@ -628,8 +669,10 @@ def test_large_k_is_searched_range_by_range(amd, n, d, nq, k, cluster):
 @pytest.mark.parametrize("nq", [1, 21, 128, 129, 256 + 21, 256 + 128, 256 + 129, 2 * 256 + 100])
 def test_tail_pass_on_the_128_query_kernel(amd, nq):
     """scan_topk256 (d = 768): a last pass of at most 128 queries runs on the 128-query kernel, merged as a group of its own
-    (option tail128, default on) — same bits as without it and as the oracle, around the routing boundaries."""
+    (option tail128, default on) — same bits as without it and as the oracle, around the routing boundaries.  (balance_tail off: it
+    takes remainders of more than one tile away from this routing; test_balanced_remainder_and_idle_waves_match_oracle covers it.)"""
     from bergen_amd import _lib
+    _lib.set_option("balance_tail", 0)
     rng = np.random.default_rng(nq)
     n, d, k = 20_000, 768, 50
     x = rng.standard_normal((n, d)).astype(np.float16)
@@ -654,6 +697,7 @@ def test_tail_pass_on_the_128_query_kernel(amd, nq):
             compare.assert_bit_exact(s, i, ws, wi, f"tail128={tail} nq={nq}")
     finally:
         _lib.set_option("tail128", 1)
+        _lib.set_option("balance_tail", 1)
         ix.close()
 
 
