@@ -1324,6 +1324,7 @@ def run(args, env):
         scan_ms += c["scan_ms"]
         tail_ms += c.get("tail_scan_ms", 0.0)
         pair_ms += c.get("paired_scan_ms", 0.0)
+        bal_ms += c.get("balanced_scan_ms", 0.0)
         merge_ms += c["merge_ms"]
         kernel_total_ms += c["total_ms"]
         uncertified += c.get("uncertified_queries", 0)
