@@ -1082,6 +1082,7 @@ def scan_roofline(acc, c, steps, n_rows, dim, k, traffic_json, dim_padded=None):
     bal_q = int(c.get("balanced_queries", 0) or 0)
     bal_ms = acc.get("balanced_scan_ms", 0.0) if bal_q else 0.0
     n_pair_full = n_pair - (1 if bal_q else 0)
+    pair_ms_all, n_pair_all = pair_ms, n_pair
     if bal_q and n_pair_full > 0:
         pair_ms -= bal_ms
         n_pair = n_pair_full
@@ -1120,6 +1121,9 @@ def scan_roofline(acc, c, steps, n_rows, dim, k, traffic_json, dim_padded=None):
                                   "traffic": pmc_traffic(traffic_json, name, n_rows, dp),
                                   "what": "an odd number of full passes leaves one that runs alone"}
     if bal_q:
+        # (a kernel trace — rocprofv3 --kernel-trace --stats — averages over EVERY launch of this kernel instantiation, the balanced one included)
+        out["avg_launch_ms_over_all_launches_of_this_kernel"] = pair_ms_all / max(1, n_pair_all * steps)
+        out["launches_of_this_kernel"] = n_pair_all * steps
         out["balanced_launch"] = {"kernel": name, "queries": bal_q, "avg_launch_ms": bal_ms / steps, "launches": steps,
                                   "what": "the queries left behind the last full pair of passes, cut into two passes of about half each: one paired launch, "
                                           "waves without a query skip the tiles' MFMAs (index.hip option balance_tail)"}

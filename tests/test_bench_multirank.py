@@ -133,6 +133,7 @@ def test_scan_roofline_accounts_for_paired_unpaired_and_tail_launches():
                               "balanced_scan_ms": steps * 8.0}, cb, steps, n, d, k, "missing.json")
     assert rb["launches"] == 5 * steps and abs(rb["avg_launch_ms"] - 13.4) < 1e-9 and rb["tail_pass"] is None and "unpaired_launch" not in rb
     assert rb["balanced_launch"]["queries"] == 277 and abs(rb["balanced_launch"]["avg_launch_ms"] - 8.0) < 1e-9
+    assert rb["launches_of_this_kernel"] == 6 * steps and abs(rb["avg_launch_ms_over_all_launches_of_this_kernel"] - (5 * 13.4 + 8.0) / 6) < 1e-9
     # pairing off (or a library that does not report it): one pass per launch, the tail pass taken out of the average
     c1 = {"query_tile": 256, "n_passes": 12, "tail_query_tile": 128, "shader_mhz": 1500.0}
     r1 = bench.scan_roofline({"scan_ms": steps * (11 * 7.3 + 5.0), "tail_scan_ms": steps * 5.0}, c1, steps, n, d, k, "missing.json")
