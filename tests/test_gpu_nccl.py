@@ -32,7 +32,7 @@ def nccl_world_1():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,d,nq,k,metric", [(40_001, 768, 300, 50, "ip"), (9_000, 1024, 70, 200, "cos"), (70_000, 768, 2837, 50, "ip")])
+@pytest.mark.parametrize("n,d,nq,k,metric", [(40_001, 768, 300, 50, "ip"), (9_000, 1024, 70, 200, "cos"), (20_000, 768, 2837, 50, "ip")])
 def test_sharded_search_through_rccl_world_size_one(nccl_world_1, n, d, nq, k, metric):
     from bergen_amd import FlatIndex
     from bergen_amd.sharded import ShardedSearcher
