@@ -193,6 +193,7 @@ hipError_t bh_gemm_probe_permlane(hipStream_t stream);
 int bh_gemm_swap_mode();
 void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of the first round of blocks
 void bh_gemm_set_gelu_nontemporal(int on);      // A/B knob: non-temporal stores of the bias + GELU output (default on)
+void bh_gemm_set_mfma16(int on);                // bias (+ GELU) projections on the 16x16x32 persistent kernel (gemm_f16_p16.h)
 void bh_gemm_set_full_line_stores(int on);      // persistent kernel: outputs through LDS as whole 128-byte lines (gemm_f16_persist.h PST bit 32)
 
 struct BhAttnArgs {

@@ -116,6 +116,33 @@ def test_gemm_full_line_stores_are_bit_identical():
         _lib.set_option("gemm_full_line_stores", 2)  # (the library default)
 
 
+def test_gemm_mfma16_kernel_against_oracle():
+    """Option gemm_mfma16 (gemm_f16_p16.h): the bias and bias + GELU projections on v_mfma_f32_16x16x32_f16 — another LDS image,
+    fragment pattern and epilogue route than gemm_f16_persist.h, the same contract.  Shapes with several tiles per workgroup, ragged
+    edges (the other kernels take those strips), K from one stage to 48; against the fp64 oracle and against the production kernel
+    (same tolerance: the two matrix instructions add their k terms in different groupings)."""
+    from bergen_amd import _lib, encoder
+    rng = np.random.default_rng(36)
+    try:
+        for (M, N, K) in [(256, 256, 64), (2048, 1024, 64), (4096 + 256, 3072, 768), (1024, 768, 3072), (2560 + 40, 1536 + 24, 192),
+                          (768, 256 * 100, 128)]:
+            a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
+            bc = rnd16(rng, N)
+            for kw, ref in [(dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
+                            (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
+                outs = []
+                for on in (0, 1, 2, 3, 4):  # off, then the four issue schedules
+                    _lib.set_option("gemm_mfma16", on)
+                    out, _ = encoder.gemm_f16(h16(a), h16(w), **kw)
+                    outs.append(out.clone())
+                for o in outs[1:]:
+                    assert_gemm_close(o, ref, f"mfma16 {M}x{N}x{K} {sorted(kw)}")
+                    assert torch.equal(o, outs[1])
+                assert_gemm_close(outs[1], outs[0].float().cpu().numpy().astype(np.float64), f"mfma16 vs production {M}x{N}x{K} {sorted(kw)}")
+    finally:
+        _lib.set_option("gemm_mfma16", 0)
+
+
 def test_gemm_alternating_loader_teams():
     """Variant 33 (gemm_f16_persist.h PST 16): deferred stores with the two four-wave teams of a workgroup alternating
     between refilling the LDS ring and storing — a wave skips the vmcnt wait of a stage it did not load in.  Several tiles per
