@@ -180,6 +180,7 @@ struct BhGemmArgs {
     const float* res_stats;
     const _Float16 *res_gamma, *res_beta;
     float* stats_out;
+    int tail_split;  // gemm_f16_p16.h: a last round of at most half the workgroups' worth of tiles is cut into 2 or 4 sub-tiles along M
 };
 // whether bh_launch_gemm_f16 would run an M x N problem on the persistent kernel's full-line-store path (the fused-LayerNorm epilogues exist there only)
 bool bh_gemm_ln_fusable(int M, int N, bool blocked_out);
@@ -194,6 +195,7 @@ int bh_gemm_swap_mode();
 void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of the first round of blocks
 void bh_gemm_set_gelu_nontemporal(int on);      // A/B knob: non-temporal stores of the bias + GELU output (default on)
 void bh_gemm_set_mfma16(int on);                // bias (+ GELU) projections on the 16x16x32 persistent kernel (gemm_f16_p16.h)
+void bh_gemm_set_tail_split(int on);            // gemm_f16_p16.h: sub-tiles for a short last round (default on)
 void bh_gemm_set_full_line_stores(int on);      // persistent kernel: outputs through LDS as whole 128-byte lines (gemm_f16_persist.h PST bit 32)
 
 struct BhAttnArgs {

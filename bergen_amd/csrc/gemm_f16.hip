@@ -24,7 +24,7 @@
 // keeps TWO independent 4-wave blocks per CU (256x128 tile, BK = 32, ring 3 = 72 KiB each): one block's
 // VALU/store epilogue overlaps the other block's MFMA main loop.
 #include "gemm_f16_persist.h"
-hipError_t bh_gemm_p16(const BhGemmArgs& a, int epi, bool nontemporal, int sched, hipStream_t s);  // gemm_f16_d.hip
+hipError_t bh_gemm_p16(const BhGemmArgs& a, int epi, bool nontemporal, int mode, hipStream_t s);  // gemm_f16_d.hip
 
 // Probe of v_permlane32_swap's direction (documented: vdst[32:63] <-> vsrc[0:31]).
 __global__ void bh_permlane_probe_kernel(unsigned* out) {
@@ -45,8 +45,11 @@ int g_full_line_stores = 2;  // bh_set_option "gemm_full_line_stores" (default 2
 }
 
 void bh_gemm_set_gelu_nontemporal(int on) { g_gelu_nontemporal = on != 0; }
-int g_mfma16 = 0;  // bh_set_option "gemm_mfma16": the bias (+ GELU) projections on gemm_f16_p16.h (v_mfma_f32_16x16x32_f16) instead of gemm_f16_persist.h
-void bh_gemm_set_mfma16(int on) { g_mfma16 = on; }  // 0 = off; 1 + SCHED (gemm_f16_p16.h)
+int g_mfma16 = 1;  // bh_set_option "gemm_mfma16" (default 1 since round 5): the bias (+ GELU) projections on gemm_f16_p16.h (v_mfma_f32_16x16x32_f16) instead of gemm_f16_persist.h
+void bh_gemm_set_mfma16(int on) { g_mfma16 = on; }  // 2 = + refill spread over both halves of a stage
+int g_tail_split = 0;  // bh_set_option "gemm_tail_split": gemm_f16_p16.h cuts a short last round of tiles into sub-tiles (same bits; default off: faster
+                       // for a GEMM alone, 1 % slower inside the encoder, whose two micro-batch streams already fill a launch's idle tail)
+void bh_gemm_set_tail_split(int on) { g_tail_split = on != 0; }
 void bh_gemm_set_full_line_stores(int level) { g_full_line_stores = level < 0 ? 0 : level > 2 ? 2 : level; }
 
 void bh_gemm_set_stagger(int phases, int pct) {
@@ -276,9 +279,12 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
             if ((e = bh_gemm_persist(t, epi, pst_eff, stream)) != hipSuccess) return e;
             if ((e = run_cfg(1, r, epi, stream)) != hipSuccess) return e;
         } else {
-            if (persist && g_mfma16 && (pst_eff == 33 || pst_eff == 35) && !t.c_block_rows && (epi == BH_EPI_BIAS_COL || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU)))
-                e = bh_gemm_p16(t, epi, pst_eff == 35, g_mfma16 - 1, stream);
-            else
+            // every full-line-store case of the plain epilogues runs on the 16x16x32 kernel (gemm_f16_p16.h) unless gemm_mfma16 is 0
+            if (persist && g_mfma16 && (pst_eff == 33 || pst_eff == 35) &&
+                (epi == 0 || epi == BH_EPI_BIAS_COL || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU) || (epi == BH_EPI_BIAS_ROW && t.c_block_rows))) {
+                t.tail_split = g_tail_split;
+                e = bh_gemm_p16(t, epi, pst_eff == 35, g_mfma16, stream);
+            } else
                 e = persist ? bh_gemm_persist(t, epi, pst_eff, stream) : run_cfg(variant, t, epi, stream);
             if (e != hipSuccess) return e;
         }

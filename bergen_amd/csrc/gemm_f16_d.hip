@@ -14,22 +14,29 @@ int n_cu() {
 }
 }  // namespace
 
-template <int SCHED>
-hipError_t p16_sched(const BhGemmArgs& a, int epi, bool nontemporal, hipStream_t s) {
-    if (epi == BH_EPI_BIAS_COL)
-        return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL, true, SCHED>(a, n_cu(), s) : bh_gemm_launch_p16<BH_EPI_BIAS_COL, false, SCHED>(a, n_cu(), s);
-    if (epi == (BH_EPI_BIAS_COL | BH_EPI_GELU))
-        return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, true, SCHED>(a, n_cu(), s)
-                           : bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, false, SCHED>(a, n_cu(), s);
-    return hipErrorNotSupported;
-}
-
-hipError_t bh_gemm_p16(const BhGemmArgs& a, int epi, bool nontemporal, int sched, hipStream_t s) {
-    switch (sched) {
-        case 0: return p16_sched<0>(a, epi, nontemporal, s);
-        case 1: return p16_sched<1>(a, epi, nontemporal, s);
-        case 2: return p16_sched<2>(a, epi, nontemporal, s);
-        case 3: return p16_sched<3>(a, epi, nontemporal, s);
+template <bool SPREAD>
+hipError_t p16_v(const BhGemmArgs& a, int epi, bool nontemporal, hipStream_t s) {
+    switch (epi) {
+        case 0: return bh_gemm_launch_p16<0, false, SPREAD>(a, n_cu(), s);
+        case BH_EPI_BIAS_COL: return bh_gemm_launch_p16<BH_EPI_BIAS_COL, false, SPREAD>(a, n_cu(), s);
+        case BH_EPI_BIAS_ROW: return bh_gemm_launch_p16<BH_EPI_BIAS_ROW, false, SPREAD>(a, n_cu(), s);
+        case BH_EPI_BIAS_COL | BH_EPI_GELU:
+            return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, true, SPREAD>(a, n_cu(), s)
+                               : bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, false, SPREAD>(a, n_cu(), s);
     }
     return hipErrorNotSupported;
+}
+// mode: 1 = production, 2 = refill spread over both halves of a stage (measured slower), 16 * ABL + 1 = bench-only ablations of the GELU kernel
+hipError_t bh_gemm_p16(const BhGemmArgs& a, int epi, bool nontemporal, int mode, hipStream_t s) {
+    if (mode >= 16) {
+        if (epi != (BH_EPI_BIAS_COL | BH_EPI_GELU)) return hipErrorNotSupported;
+        switch (mode >> 4) {
+#define BH_P16_ABL(X) \
+    case X: return bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, true, false, X>(a, n_cu(), s);
+            BH_P16_ABL(1) BH_P16_ABL(2) BH_P16_ABL(4) BH_P16_ABL(8) BH_P16_ABL(16) BH_P16_ABL(9) BH_P16_ABL(10) BH_P16_ABL(12) BH_P16_ABL(14) BH_P16_ABL(13) BH_P16_ABL(11)
+#undef BH_P16_ABL
+        }
+        return hipErrorNotSupported;
+    }
+    return mode == 2 ? p16_v<true>(a, epi, nontemporal, s) : p16_v<false>(a, epi, nontemporal, s);
 }

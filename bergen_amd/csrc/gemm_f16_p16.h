@@ -15,25 +15,29 @@
 //     before); feature fragments double-buffered over the k-steps, token fragments refilled rolling behind their 4 MFMAs.
 //   * epilogue: lane (q16, lg) of block (tb, fb) holds token 16 tb + q16, features 16 fb + 4 lg + 0..3: one 8-byte LDS write per block
 //     into the wave's 32-row x 128-byte staging image (16-byte chunks XORed with the row), read back and stored exactly as before.
-// Epilogues: bias per column, optionally GELU (the Q | K, attention-output, FFN-up and FFN-down projections: 92 % of the encoder's
-// GEMM time); everything else stays on gemm_f16_persist.h.
+//   * TAIL SPLIT (BhGemmArgs::tail_split): an XCD's 32 workgroups walk its tiles in rounds, and a last round with r <= 16 tiles left 16
+//     or more of them idle for a whole tile time (the bench batch's micro-batch: 780 tiles of the Q | K projection = 3.05 rounds, paid
+//     as 4).  Here such a remainder is cut along the TOKENS into 2 (r <= 16) or 4 (r <= 8) sub-tiles of 128 or 64 tokens x 256 features,
+//     one per workgroup, all eight waves on each (64 or 32 tokens x 64 features per wave); same pipeline, same stage count, a half or a
+//     quarter of the MFMAs per stage.  Every output element still sums the same k-steps in the same order: same bits.
+// Epilogues: none, bias per column (optionally + GELU), bias per row; row-major output or the attention kernel's blocked V^T layout — every
+// projection of a BERT layer.  The fused-LayerNorm, gated (SwiGLU), segmented-max and batched epilogues stay on gemm_f16_persist.h.
 #pragma once
 #include "gemm_f16_persist.h"
 
-// SCHED bit 1: token fragments double-buffered in registers, all reads of the next k-step issued in the first six MFMA groups of the current one;
-// bit 2: the stage refill issued two LDS-DMA instructions per group in the first four groups (instead of one in each of the eight)
-template <int EPI, bool NT, int SCHED>
+// ABL (bench only, results invalid): 1 no LDS-DMA after the pipeline start, 2 no MFMA, 4 no fragment reads, 8 no epilogue, 16 epilogue math without stores
+template <int EPI, bool NT, bool SPREAD, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert((EPI & ~(BH_EPI_BIAS_COL | BH_EPI_GELU)) == 0 && (EPI & BH_EPI_BIAS_COL) != 0, "bias per column, optional GELU");
-    constexpr int BK = 64, WM = 2, WN = 4, R = 2;
-    constexpr int NW = WM * WN;
+    static_assert(EPI == 0 || EPI == BH_EPI_BIAS_COL || EPI == (BH_EPI_BIAS_COL | BH_EPI_GELU) || EPI == BH_EPI_BIAS_ROW, "epilogues of this kernel");
+    constexpr int BK = 64, WN = 4, R = 2;
+    constexpr int NW = 8;
     constexpr int BM = 256, BN = 256;
     constexpr int PA = BM / 32, PB = BN / 32;
     constexpr int PIECE = 4096, SUBS = 4;
     constexpr int STAGE_BYTES = (PA + PB) * PIECE;
     constexpr int NL = (PA + PB) * SUBS / NW;  // 8 LDS-DMA instructions per wave per stage
-    constexpr int TB = 8, FB = 4;              // 16-token blocks / 16-feature blocks per wave
+    constexpr int TB = 8, FB = 4;              // 16-token blocks / 16-feature blocks per wave (a whole tile)
     constexpr int NLA = PA * SUBS / NW;        // instructions 0..3 fetch token rows, 4..7 feature rows
 
     const int tid = threadIdx.x;
@@ -42,26 +46,40 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int q16 = lane & 15, lg = lane >> 4;
 
-    // ---- this block's tiles (gemm_f16_persist.h: XCD x = block % 8 owns a contiguous range of the m-major tile order)
+    // ---- this block's work (gemm_f16_persist.h: XCD x = block % 8 owns a contiguous range of the m-major tile order; its G8 blocks walk
+    // it in rounds).  n_full whole tiles t_first + k G8, then — tail split — one sub-tile: part sub_part of 1 << sub_log of tile sub_tile.
     const int tiles_n = a.N / BN;
     const int n_tiles = (a.M / BM) * tiles_n;
-    int t_first, t_step, n_my;
+    int t_first, n_full, sub_tile = 0, sub_part = 0, sub_log = 0;
+    const int G8 = gridDim.x >> 3;
     {
-        const int G8 = gridDim.x >> 3, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
         const int q = n_tiles >> 3, r = n_tiles & 7;
         const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
         const int cnt = q + (x < r ? 1 : 0);
+        const int rounds = cnt / G8, rem = cnt - rounds * G8;
         t_first = start + j;
-        t_step = G8;
-        n_my = cnt > j ? (cnt - j + G8 - 1) / G8 : 0;
+        n_full = rounds + (j < rem ? 1 : 0);
+        if (a.tail_split && rem > 0 && 2 * rem <= G8) {
+            sub_log = 4 * rem <= G8 ? 2 : 1;
+            n_full = rounds;
+            if ((j >> sub_log) < rem) {
+                sub_tile = start + rounds * G8 + (j >> sub_log);
+                sub_part = j & ((1 << sub_log) - 1);
+            } else {
+                sub_log = 0;
+            }
+        }
     }
-    if (n_my == 0) return;
+    const int n_items = n_full + (sub_log ? 1 : 0);
+    if (n_items == 0) return;
 
     // ---- per-lane LDS-DMA source offsets: instruction i of a wave fetches 8 rows of piece 2 i + (wave >> 2)
     unsigned offA, offB;
     int dst0;
+    const int p0 = wave >> 2;
     {
-        const int sub = wave & 3, p0 = wave >> 2;
+        const int sub = wave & 3;
         const int row = 8 * sub + (lane >> 3);
         const int g = (row >> 1) & 7;
         const int chunk = (lane & 7) ^ g;
@@ -80,17 +98,25 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     const unsigned char* baseA = reinterpret_cast<const unsigned char*>(a.A);
     const unsigned char* baseB = reinterpret_cast<const unsigned char*>(a.B);
 
-    // ---- issue cursor (runs one stage ahead of the consumer, across tile boundaries)
+    // ---- issue cursor (runs one stage ahead of the consumer, across item boundaries)
     int it = 0, ikt = 0, islot = 0;
+    int ipa = PA;  // token pieces of the item at the cursor: 8, or 4 / 2 for a sub-tile
     const unsigned char *curA, *curB;
-    auto set_issue_tile = [&](int ord) {
-        const int t = t_first + ord * t_step;
-        const int tm0 = (t / tiles_n) * BM, tn0 = (t % tiles_n) * BN;
+    auto set_issue_item = [&](int ord) {
+        const bool is_sub = ord >= n_full;
+        const int t = is_sub ? sub_tile : t_first + ord * G8;
+        const int tm0 = (t / tiles_n) * BM + (is_sub ? sub_part * (BM >> sub_log) : 0), tn0 = (t % tiles_n) * BN;
+        ipa = is_sub ? PA >> sub_log : PA;
         curA = baseA + (size_t)tm0 * a.lda * 2;
         curB = baseB + (size_t)tn0 * a.ldb * 2;
     };
-    set_issue_tile(0);
+    set_issue_item(0);
+    bool abl_started = false;
     auto issue_piece = [&](int i) {
+        if (i < NLA && 2 * i + p0 >= ipa) return;  // (a sub-tile has fewer token rows)
+        if constexpr ((ABL & 1) != 0) {
+            if (abl_started) return;
+        }
         const unsigned char* ub = (i < NLA ? curA : curB) + (size_t)ikt * (BK * 2);
         unsigned off = i < NLA ? offA : offB;
         asm volatile("" : "+v"(off));  // ONE live offset register (gemm_f16_persist.h)
@@ -101,12 +127,12 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     auto issue_advance = [&]() {
         if (++islot == R) islot = 0;
         if (++ikt == KT) {
-            if (it + 1 < n_my) {
+            if (it + 1 < n_items) {
                 ++it;
                 ikt = 0;
-                set_issue_tile(it);
+                set_issue_item(it);
             } else {
-                ikt = KT - 1;  // no further tile: harmless re-fetch keeps vmcnt uniform
+                ikt = KT - 1;  // nothing further: a harmless re-fetch
             }
         }
     };
@@ -121,106 +147,125 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
         for (int fb = 0; fb < FB; ++fb) acc[tb][fb] = floatx4{0.f, 0.f, 0.f, 0.f};
-    constexpr bool DBX = (SCHED & 1) != 0, DMA2 = (SCHED & 2) != 0;
-    half8 xt[DBX ? 2 : 1][TB], wf[2][FB];
-    // token block tb of the wave: piece wm * 4 + (tb >> 1), 16-row block tb & 1; feature block fb: piece PA + wn * 2 + (fb >> 1), block fb & 1
+    // Fragments, double-buffered over the k-steps: all reads of the next k-step are issued behind the first five MFMA groups of the current
+    // one (measured against single-buffered token fragments refilled rolling: BERT-base forward 13.94 -> 13.80 ms).
+    half8 xt[2][TB], wf[2][FB];
+    // token block tb of a wave that owns TBS blocks: rows wm * 16 TBS + 16 tb of the (sub-)tile; feature block fb: piece PA + wn * 2 + (fb >> 1)
     auto read_wf = [&](int buf, const unsigned char* st, int ks) {
         const unsigned char* sw = st + (PA + wn * 2) * PIECE + rd_off[ks];
 #pragma unroll
         for (int fb = 0; fb < FB; ++fb) wf[buf][fb] = *reinterpret_cast<const half8*>(sw + (fb >> 1) * PIECE + (fb & 1) * 2048);
     };
-    auto read_xt = [&](int tb, const unsigned char* st, int ks) {
-        xt[DBX ? ks : 0][tb] = *reinterpret_cast<const half8*>(st + (wm * 4 + (tb >> 1)) * PIECE + (tb & 1) * 2048 + rd_off[ks]);
+    auto read_xt = [&](auto tbs_c, int tb, const unsigned char* st, int ks) {
+        constexpr int TBS = decltype(tbs_c)::value;
+        const int row0 = wm * 16 * TBS + 16 * tb;
+        xt[ks][tb] = *reinterpret_cast<const half8*>(st + (row0 >> 5) * PIECE + ((row0 >> 4) & 1) * 2048 + rd_off[ks]);
+    };
+    // reads of k-step ks behind MFMA group tb of the other k-step: the four feature fragments behind group 0, two token fragments behind each
+    // of the groups 1 .. 4 (what a short sub-tile schedule has no group for follows its last group)
+    auto reads_behind = [&](auto tbs_c, int tb, const unsigned char* st, int ks) {
+        constexpr int TBS = decltype(tbs_c)::value;
+        if constexpr ((ABL & 4) != 0) return;
+        if (tb == 0) read_wf(ks, st, ks);
+        if (tb >= 1) {
+            if (2 * tb - 2 < TBS) read_xt(tbs_c, 2 * tb - 2, st, ks);
+            if (2 * tb - 1 < TBS) read_xt(tbs_c, 2 * tb - 1, st, ks);
+        }
+        if (tb == TBS - 1) {
+#pragma unroll
+            for (int u = 2 * tb; u < TBS; ++u) read_xt(tbs_c, u, st, ks);
+        }
     };
 
     int cslot = 0;
-    auto stage = [&]() {
+    auto stage = [&](auto tbs_c) {
+        constexpr int TBS = decltype(tbs_c)::value;
         const unsigned char* st = smem + cslot * STAGE_BYTES;
         if (++cslot == R) cslot = 0;
-        // k-step 0 (fragments wf[0], xt[] are in registers: the wait hipcc puts at the loop head covers exactly them, so no read is
-        // issued before the first MFMAs); the reads of k-step 1 follow the MFMA group that frees their registers
+        // k-step 0 (its fragments are in registers: the wait hipcc puts at the loop head covers exactly them, so no read is issued before the
+        // first MFMAs)
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
+        for (int tb = 0; tb < TBS; ++tb) {
 #pragma unroll
             for (int fb = 0; fb < FB; ++fb)
-                acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][fb], xt[0][tb], acc[tb][fb], 0, 0, 0);
+                if constexpr ((ABL & 2) == 0) acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][fb], xt[0][tb], acc[tb][fb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DBX) {  // 12 reads over groups 0..5
-                if (tb == 0) read_wf(1, st, 1);
-                if (tb >= 1 && tb <= 4) { read_xt(2 * tb - 2, st, 1); read_xt(2 * tb - 1, st, 1); }
-            } else {
-                if (tb == 0) read_wf(1, st, 1);
-                read_xt(tb, st, 1);
+            if constexpr (SPREAD) {  // the second half of the refill that the previous stage's second half began: feature rows
+                constexpr int PER = (NL / 2 + TBS - 1) / TBS;
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    if (tb * PER + u < NL / 2) issue_piece(NL / 2 + tb * PER + u);
             }
+            reads_behind(tbs_c, tb, st, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (SPREAD) issue_advance();
         // k-step 1.  Every read of this stage must have returned before its slot is handed back:
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int fb = 0; fb < FB; ++fb) asm volatile("" : "+v"(wf[1][fb]));
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) asm volatile("" : "+v"(xt[DBX ? 1 : 0][tb]));
+        for (int tb = 0; tb < TBS; ++tb) asm volatile("" : "+v"(xt[1][tb]));
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // next stage landed (ring 2)
         const unsigned char* nst = smem + cslot * STAGE_BYTES;
-        if constexpr (!DBX) read_wf(0, nst, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb) {
+        for (int tb = 0; tb < TBS; ++tb) {
 #pragma unroll
             for (int fb = 0; fb < FB; ++fb)
-                acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][fb], xt[DBX ? 1 : 0][tb], acc[tb][fb], 0, 0, 0);
+                if constexpr ((ABL & 2) == 0) acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][fb], xt[1][tb], acc[tb][fb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // the refill goes into the slot everybody just left
-            if constexpr (DMA2) {
-                if (tb < 4) { issue_piece(2 * tb); issue_piece(2 * tb + 1); }
+            // the refill goes into the slot everybody just left: spread over the MFMA groups (one LDS-DMA instruction per group of a whole tile;
+            // measured against two per group in the first four: 13.80 vs 14.13 ms)
+            if constexpr (SPREAD) {  // token rows of the stage after the next, one LDS-DMA instruction behind every other group of a whole tile
+                constexpr int EVERY = TBS >= 8 ? 2 : 1, PER = TBS >= 4 ? 1 : NL / 2 / TBS;
+                if (tb % EVERY == 0) {
+#pragma unroll
+                    for (int u = 0; u < PER; ++u)
+                        if ((tb / EVERY) * PER + u < NL / 2) issue_piece((tb / EVERY) * PER + u);
+                }
             } else {
-                issue_piece(tb);  // NL == TB: one LDS-DMA instruction per group of four MFMAs
+#pragma unroll
+                for (int u = 0; u < NL / TBS; ++u) issue_piece(tb * (NL / TBS) + u);
             }
-            if constexpr (DBX) {
-                if (tb == 0) read_wf(0, nst, 0);
-                if (tb >= 1 && tb <= 4) { read_xt(2 * tb - 2, nst, 0); read_xt(2 * tb - 1, nst, 0); }
-            } else {
-                read_xt(tb, nst, 0);
-            }
+            reads_behind(tbs_c, tb, nst, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        issue_advance();
+        if constexpr (!SPREAD) issue_advance();
     };
-    static_assert(NL == TB, "issue schedule");
 
-    // ---- pipeline start
-    issue_stage();
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    issue_stage();
-    read_wf(0, smem, 0);
-#pragma unroll
-    for (int tb = 0; tb < TB; ++tb) read_xt(tb, smem, 0);
-
-    for (int ti = 0; ti < n_my; ++ti) {
-        const int t = t_first + ti * t_step;
-        const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-        for (int kt = 0; kt < KT; ++kt) stage();  // (the accumulators are zero: the epilogue leaves them so — a separate first stage with a
-                                                  // zero C operand made hipcc spill six accumulator quads per tile)
-
-        // ---- epilogue: bias (+ GELU), fp16, through the wave's staging image, out as whole 128-byte lines
-        unsigned char* stg = smem + R * STAGE_BYTES + wave * 4096;  // 32 token rows x 128 bytes
-        const int rrow = lane >> 3, rch = lane & 7;                  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
-        _Float16* gptr = a.C + (size_t)(m0 + wm * 128 + rrow) * a.ldc + n0 + wn * 64 + rch * 8;
+    // ---- epilogue of a (sub-)tile whose rows start at m0: bias (+ GELU), fp16, through the wave's staging image, out as whole 128-byte
+    // lines; leaves the accumulators zero (a first stage with a zero C operand instead made hipcc spill six accumulator quads per tile)
+    unsigned char* stg = smem + R * STAGE_BYTES + wave * 4096;  // 32 token rows x 128 bytes
+    auto epilogue = [&](auto tbs_c, int m0, int n0) {
+        constexpr int TBS = decltype(tbs_c)::value;
+        if constexpr ((ABL & 8) != 0) return;
+        const int rrow = lane >> 3, rch = lane & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
+        // output addressing: row-major, or — c_block_rows != 0 — blocked by 64 columns (the attention kernel's V^T layout: element (m, n) at
+        // C[(n / 64) * c_block_rows * 64 + m * 64 + n % 64]): the wave's 64 columns are one block, its rows 128-byte lines either way
+        const long long ldc_eff = a.c_block_rows ? 64 : a.ldc;
+        _Float16* gptr = a.C + (size_t)(m0 + wm * 16 * TBS + rrow) * ldc_eff + rch * 8 +
+                         (a.c_block_rows ? (size_t)((n0 >> 6) + wn) * (size_t)a.c_block_rows * 64 : (size_t)(n0 + wn * 64));
         half4 bias4[FB];
+        if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
 #pragma unroll
-        for (int fb = 0; fb < FB; ++fb) bias4[fb] = *reinterpret_cast<const half4*>(a.bias + n0 + wn * 64 + fb * 16 + 4 * lg);
+            for (int fb = 0; fb < FB; ++fb) bias4[fb] = *reinterpret_cast<const half4*>(a.bias + n0 + wn * 64 + fb * 16 + 4 * lg);
+        }
 #pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {  // 32-token parts of the wave's 128 tokens
+        for (int tp = 0; tp < (TBS + 1) / 2; ++tp) {  // 32-token parts of the wave's tokens
 #pragma unroll
-            for (int half_ = 0; half_ < 2; ++half_) {
+            for (int half_ = 0; half_ < (TBS > 1 ? 2 : 1); ++half_) {
                 const int tb = 2 * tp + half_;
                 const int tr = half_ * 16 + q16;  // token row inside the part
+                float brow = 0.f;
+                if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) brow = (float)a.bias[m0 + wm * 16 * TBS + tb * 16 + q16];
 #pragma unroll
                 for (int fb = 0; fb < FB; ++fb) {
                     half4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = acc[tb][fb][r] + (float)bias4[fb][r];
+                        float v = acc[tb][fb][r];
+                        if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)bias4[fb][r];
+                        if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) v += brow;
                         if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
                         o[r] = (_Float16)v;
                     }
@@ -229,26 +274,79 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
                     *reinterpret_cast<half4*>(stg + tr * 128 + ((chunk ^ (tr & 7)) << 4) + (lg & 1) * 8) = o;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own writes; no other wave touches stg)
+            asm volatile("" ::: "memory");  // (a wave's LDS instructions execute in order, and no other wave touches stg)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < (TBS > 1 ? 4 : 2); ++i) {
                 const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ rrow) << 4));
-                half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tp * 32 + 8 * i) * a.ldc);
+                half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tp * 32 + 8 * i) * ldc_eff);
+                if constexpr ((ABL & 16) != 0) {
+                    if (v[0] != (_Float16)12345.f) continue;  // (never true for the bench data: keeps the math alive)
+                }
                 if constexpr (NT)
                     __builtin_nontemporal_store(v, p);
                 else
                     *p = v;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads have landed before the next part overwrites stg)
+            asm volatile("" ::: "memory");
         }
+    };
+
+    // ---- pipeline start
+    issue_stage();
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (SPREAD) {
+#pragma unroll
+        for (int i = 0; i < NL / 2; ++i) issue_piece(i);
+    } else {
+        issue_stage();
+    }
+    abl_started = true;
+    using Whole = std::integral_constant<int, TB>;
+    auto first_fragments = [&](auto tbs_c) {  // k-step 0 of the stage at the consumer's slot (landed)
+        constexpr int TBS = decltype(tbs_c)::value;
+        const unsigned char* st = smem + cslot * STAGE_BYTES;
+        read_wf(0, st, 0);
+#pragma unroll
+        for (int tb = 0; tb < TBS; ++tb) read_xt(tbs_c, tb, st, 0);
+    };
+    if (n_full > 0) first_fragments(Whole{});
+
+    for (int ti = 0; ti < n_full; ++ti) {
+        const int t = t_first + ti * G8;
+        for (int kt = 0; kt < KT; ++kt) stage(Whole{});
+        epilogue(Whole{}, (t / tiles_n) * BM, (t % tiles_n) * BN);
+    }
+    if (sub_log) {
+        const int n0 = (sub_tile % tiles_n) * BN;
+        const int m0 = (sub_tile / tiles_n) * BM + sub_part * (BM >> sub_log);
+        // (the fragments pre-read behind the last whole tile's last stage followed the whole tile's row map)
+        if (sub_log == 1) {
+            using Sub = std::integral_constant<int, TB / 2>;
+            first_fragments(Sub{});
+            for (int kt = 0; kt < KT; ++kt) stage(Sub{});
+            epilogue(Sub{}, m0, n0);
+        } else {
+            using Sub = std::integral_constant<int, TB / 4>;
+            first_fragments(Sub{});
+            for (int kt = 0; kt < KT; ++kt) stage(Sub{});
+            epilogue(Sub{}, m0, n0);
+        }
+    }
+    if constexpr ((ABL & 8) != 0) {  // keep the accumulators alive
+        float sum = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) sum += acc[tb][fb][0] + acc[tb][fb][1] + acc[tb][fb][2] + acc[tb][fb][3];
+        if (sum == 12345.678f) a.C[tid] = (_Float16)sum;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI, bool NT, int SCHED>
+template <int EPI, bool NT, bool SPREAD, int ABL = 0>
 hipError_t bh_gemm_launch_p16(const BhGemmArgs& a, int n_cu, hipStream_t stream) {
     constexpr size_t smem = 2 * 16 * 4096 + 8 * 4096;
-    auto kern = bh_gemm_f16_p16kernel<EPI, NT, SCHED>;
+    auto kern = bh_gemm_f16_p16kernel<EPI, NT, SPREAD, ABL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -262,4 +360,4 @@ hipError_t bh_gemm_launch_p16(const BhGemmArgs& a, int n_cu, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t bh_gemm_p16(const BhGemmArgs& a, int epi, bool nontemporal, int sched, hipStream_t s);  // gemm_f16_d.hip
+hipError_t bh_gemm_p16(const BhGemmArgs& a, int epi, bool nontemporal, int mode, hipStream_t s);  // gemm_f16_d.hip

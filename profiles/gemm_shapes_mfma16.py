@@ -37,5 +37,5 @@ for name, m, n, k, gelu in shapes:
     res.append(row)
     print(json.dumps(row), flush=True)
     del a, w, outb
-_lib.set_option("gemm_mfma16", 0)
+_lib.set_option("gemm_mfma16", 1)  # (the library default)
 json.dump(res, open(out, "w"), indent=1)

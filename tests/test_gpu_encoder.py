@@ -100,6 +100,7 @@ def test_gemm_full_line_stores_are_bit_identical():
     from bergen_amd import _lib, encoder
     rng = np.random.default_rng(35)
     try:
+        _lib.set_option("gemm_mfma16", 0)  # (gemm_f16_persist.h's paths: gemm_f16_p16.h, the default for these epilogues, has the full-line route only)
         for (M, N, K) in [(2048, 1024, 64), (4096 + 256, 3072, 768), (1024, 768, 3072), (2560 + 40, 1536 + 24, 192)]:
             a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
             bc = rnd16(rng, N)
@@ -113,7 +114,8 @@ def test_gemm_full_line_stores_are_bit_identical():
                 assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), f"{M}x{N}x{K} {sorted(kw)}"
                 assert_gemm_close(outs[1], ref, f"full-line stores {M}x{N}x{K} {sorted(kw)}")
     finally:
-        _lib.set_option("gemm_full_line_stores", 2)  # (the library default)
+        _lib.set_option("gemm_full_line_stores", 2)  # (the library defaults)
+        _lib.set_option("gemm_mfma16", 1)
 
 
 def test_gemm_mfma16_kernel_against_oracle():
@@ -128,19 +130,53 @@ def test_gemm_mfma16_kernel_against_oracle():
                           (768, 256 * 100, 128)]:
             a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
             bc = rnd16(rng, N)
-            for kw, ref in [(dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
+            for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)), (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
                             (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
                 outs = []
-                for on in (0, 1, 2, 3, 4):  # off, then the four issue schedules
+                for on in (0, 1, 2):
                     _lib.set_option("gemm_mfma16", on)
-                    out, _ = encoder.gemm_f16(h16(a), h16(w), **kw)
+                    out, _ = encoder.gemm_f16(h16(a), h16(w), variant=7, **kw)
                     outs.append(out.clone())
-                for o in outs[1:]:
-                    assert_gemm_close(o, ref, f"mfma16 {M}x{N}x{K} {sorted(kw)}")
-                    assert torch.equal(o, outs[1])
+                assert torch.equal(outs[1], outs[2])
+                assert_gemm_close(outs[1], ref, f"mfma16 {M}x{N}x{K} {sorted(kw)}")
                 assert_gemm_close(outs[1], outs[0].float().cpu().numpy().astype(np.float64), f"mfma16 vs production {M}x{N}x{K} {sorted(kw)}")
     finally:
-        _lib.set_option("gemm_mfma16", 0)
+        _lib.set_option("gemm_mfma16", 1)  # (the library default)
+
+
+def test_gemm_tail_split_gives_the_same_bits():
+    """gemm_f16_p16.h's tail split: when the last round of an XCD's tiles would occupy at most half (a quarter) of its workgroups, those
+    tiles are cut into 2 (4) sub-tiles along the tokens.  Only who computes an output element changes, not the k-steps it sums or their
+    order: bit-identical to the run with the option off, for tile counts whose per-XCD remainders hit every case (no remainder, <= 8, <= 16,
+    > 16, fewer tiles than workgroups, a single tile), K from one stage to 48, both epilogues."""
+    from bergen_amd import _lib, encoder
+    rng = np.random.default_rng(37)
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    g8 = n_cu // 8
+    cases = []  # (row tiles, column tiles, K)
+    for tiles, K in [(1, 64), (8, 128), (8 * 3, 768), (8 * (g8 // 4), 192), (8 * (g8 // 4) + 8, 64), (8 * (g8 // 2), 768), (8 * (g8 // 2) + 8, 128),
+                     (n_cu, 64), (n_cu + 8, 768), (n_cu + 8 * (g8 // 4) - 3, 256), (n_cu + 8 * (g8 // 2) + 5, 3072), (2 * n_cu + 16, 192)]:
+        tn = 3 if tiles % 3 == 0 else 2 if tiles % 2 == 0 else 1
+        cases.append((tiles // tn, tn, K))
+    cases.append((130, 6, 768))  # the bench batch's micro-batch through the Q | K projection: 780 tiles
+    try:
+        for mode in (1, 2):  # refill in one half / spread over both halves of a stage
+            _lib.set_option("gemm_mfma16", mode)
+            for (tm, tn, K) in cases:
+                M, N = 256 * tm, 256 * tn
+                a, w = rnd16(rng, M, K, scale=0.5), rnd16(rng, N, K, scale=0.2)
+                bc = rnd16(rng, N)
+                for kw in (dict(bias=h16(bc)), dict(bias=h16(bc), gelu=True)):
+                    outs = []
+                    for on in (0, 1):
+                        _lib.set_option("gemm_tail_split", on)
+                        out, _ = encoder.gemm_f16(h16(a), h16(w), variant=7, **kw)
+                        outs.append(out.clone())
+                    assert torch.equal(outs[0], outs[1]), f"tail split changes bits: {tm} x {tn} tiles, K {K}, {sorted(kw)}"
+                assert_gemm_close(outs[1], bert_oracle.gemm_ref(a, w, bc, 1, gelu=True), f"tail split {tm} x {tn} tiles, K {K}")
+    finally:
+        _lib.set_option("gemm_mfma16", 1)  # (the library default)
+        _lib.set_option("gemm_tail_split", 1)
 
 
 def test_gemm_alternating_loader_teams():
