@@ -22,21 +22,67 @@
 
 namespace bh_gemm {
 
-// erf-GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x), as ONE sigmoid of an odd polynomial:
-//     Phi(x) ~= 1 / (1 + exp(-x (a + b x^2 + c x^4))),   x clamped to [-8, 8] inside the polynomial
-// (a, b, c) = (1.59501576, 7.40112985e-2, -7.03034549e-4): minimax fit of x Phi(x) over [-8, 8] (profiles/README.md, round 4:
-// max |error| 2.55e-5 in this fp32 arithmetic, over all x incl. +-7e4; the clamp keeps the quartic term from turning the
-// polynomial around beyond |x| ~ 11, and sigma(+-27.6) is 1 / 0 to fp32).  That is a twentieth of an fp16 half-ulp at |y| ~ 1 and
-// far below what rounding the pre-activation to fp16 — which the reference's fp16 forward does before its GELU — moves the
-// result by.  9 VALU instructions (2 transcendental) per output; the Abramowitz-Stegun erf it replaces (|err| 1.5e-7) took 15-16,
-// and the epilogue of the FFN-up GEMM is VALU-issue-bound (210 M outputs per launch).  The constants carry the -log2(e) of exp2.
+// erf-GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x), without a transcendental instruction (round 5):
+//     Phi(x) - 1/2 ~= xc R(t),  xc = x clamped to [-4.5, 4.5],  t = xc^2 (2 / 4.5^2) - 1 in [-1, 1],  R a degree-9 polynomial (Horner in t)
+//     gelu(x) ~= max(x, -4.5) (1/2 + xc R(t))
+// R = weighted minimax fit of (Phi(x) - 1/2) / x over [0, 4.5] under the constraint 4.5 R(1) = 1/2 (so that the bracket is 1 / 0 at the clamp,
+// up to rounding; profiles/fit_gelu.py, tests/test_gelu_formula.py): max |error| 1.6e-5 in this fp32 arithmetic over all x (|x| <= 12 dense grid + +-10^0..4.8), 1.7e-7 for
+// x < -6, relative 6e-8 for x > 6 — inside what the sigmoid form it replaces had (2.55e-5), a thirtieth of an fp16 half-ulp at |y| ~ 1 and far
+// below what rounding the pre-activation to fp16 (which the reference's fp16 forward does before its GELU) moves the result by.
+// Why: the FFN-up GEMM's epilogue is VALU-bound (210 M outputs per launch; both waves of a SIMD are in it at the same time) and the two
+// transcendentals of the sigmoid form (v_exp_f32, v_rcp_f32: quarter rate) were half of its ~66 cycles per output.  Every operation here has a
+// packed form (v_pk_mul_f32 / v_pk_fma_f32: two outputs per instruction) except the two clamps: gelu_erf2 is the same arithmetic on a pair, bit for
+// bit (IEEE fma / mul per lane), so kernels may use either and all agree.
+constexpr float GELU_C = 4.5f, GELU_TA = 2.0f / (4.5f * 4.5f);
+constexpr float GELU_R[10] = {1.569042617e-01f, -7.717613388e-02f, 5.471959913e-02f, -4.042935046e-02f, 2.830150923e-02f,
+                              -1.751939744e-02f, 1.080767254e-02f, -7.782468650e-03f, 4.237509094e-03f, -9.520901429e-04f};
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-    const float x2 = xc * xc;
-    float t = fmaf(1.0142644168809056e-3f, x2, -1.0677573084831238e-1f);
-    t = fmaf(t, x2, -2.301121234893799f);
-    const float e = __builtin_amdgcn_exp2f(t * xc);  // = exp(-x (a + b x^2 + c x^4)), <= 2^40
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
+    const float xc = __builtin_amdgcn_fmed3f(x, -GELU_C, GELU_C);
+    const float t = __builtin_fmaf(xc * xc, GELU_TA, -1.0f);
+    float r = GELU_R[9];
+#pragma unroll
+    for (int k = 8; k >= 0; --k) r = __builtin_fmaf(r, t, GELU_R[k]);
+    const float p = __builtin_fmaf(xc, r, 0.5f);
+    return fmaxf(x, -GELU_C) * p;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    f32x2 xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -GELU_C, GELU_C);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -GELU_C, GELU_C);
+    const f32x2 t = __builtin_elementwise_fma(xc * xc, f32x2{GELU_TA, GELU_TA}, f32x2{-1.0f, -1.0f});
+    f32x2 r = {GELU_R[9], GELU_R[9]};
+#pragma unroll
+    for (int k = 8; k >= 0; --k) r = __builtin_elementwise_fma(r, t, f32x2{GELU_R[k], GELU_R[k]});
+    const f32x2 p = __builtin_elementwise_fma(xc, r, f32x2{0.5f, 0.5f});
+    f32x2 xm;
+    xm[0] = fmaxf(x[0], -GELU_C);
+    xm[1] = fmaxf(x[1], -GELU_C);
+    return xm * p;
+}
+// two pairs in lockstep (a dependent packed instruction costs a wait state; the other pair's fills it)
+__device__ __forceinline__ void gelu_erf2x2(f32x2& a, f32x2& b) {
+    f32x2 ac, bc;
+    ac[0] = __builtin_amdgcn_fmed3f(a[0], -GELU_C, GELU_C);
+    ac[1] = __builtin_amdgcn_fmed3f(a[1], -GELU_C, GELU_C);
+    bc[0] = __builtin_amdgcn_fmed3f(b[0], -GELU_C, GELU_C);
+    bc[1] = __builtin_amdgcn_fmed3f(b[1], -GELU_C, GELU_C);
+    const f32x2 ta = __builtin_elementwise_fma(ac * ac, f32x2{GELU_TA, GELU_TA}, f32x2{-1.0f, -1.0f});
+    const f32x2 tb = __builtin_elementwise_fma(bc * bc, f32x2{GELU_TA, GELU_TA}, f32x2{-1.0f, -1.0f});
+    f32x2 ra = {GELU_R[9], GELU_R[9]}, rb = ra;
+#pragma unroll
+    for (int k = 8; k >= 0; --k) {
+        ra = __builtin_elementwise_fma(ra, ta, f32x2{GELU_R[k], GELU_R[k]});
+        rb = __builtin_elementwise_fma(rb, tb, f32x2{GELU_R[k], GELU_R[k]});
+    }
+    const f32x2 pa = __builtin_elementwise_fma(ac, ra, f32x2{0.5f, 0.5f});
+    const f32x2 pb = __builtin_elementwise_fma(bc, rb, f32x2{0.5f, 0.5f});
+    a[0] = fmaxf(a[0], -GELU_C);
+    a[1] = fmaxf(a[1], -GELU_C);
+    b[0] = fmaxf(b[0], -GELU_C);
+    b[1] = fmaxf(b[1], -GELU_C);
+    a *= pa;
+    b *= pb;
 }
 
 }  // namespace bh_gemm

@@ -245,6 +245,8 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
         const long long ldc_eff = a.c_block_rows ? 64 : a.ldc;
         _Float16* gptr = a.C + (size_t)(m0 + wm * 16 * TBS + rrow) * ldc_eff + rch * 8 +
                          (a.c_block_rows ? (size_t)((n0 >> 6) + wn) * (size_t)a.c_block_rows * 64 : (size_t)(n0 + wn * 64));
+        // (fetching the column biases ahead of the tile's last stage, out of the epilogue's open latency, was tried: 8 registers held through a
+        // stage push hipcc over the register files — 20 to 50 VGPR spills, SGPR spills)
         half4 bias4[FB];
         if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
 #pragma unroll
@@ -260,15 +262,18 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
                 if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) brow = (float)a.bias[m0 + wm * 16 * TBS + tb * 16 + q16];
 #pragma unroll
                 for (int fb = 0; fb < FB; ++fb) {
-                    half4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[tb][fb][r];
-                        if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) v += (float)bias4[fb][r];
-                        if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) v += brow;
-                        if constexpr ((EPI & BH_EPI_GELU) != 0) v = bh_gemm::gelu_erf(v);
-                        o[r] = (_Float16)v;
+                    // pairs: the bias add, the GELU polynomial and the final product are packed fp32 instructions
+                    bh_gemm::f32x2 v0 = {acc[tb][fb][0], acc[tb][fb][1]}, v1 = {acc[tb][fb][2], acc[tb][fb][3]};
+                    if constexpr ((EPI & BH_EPI_BIAS_COL) != 0) {
+                        v0 += bh_gemm::f32x2{(float)bias4[fb][0], (float)bias4[fb][1]};
+                        v1 += bh_gemm::f32x2{(float)bias4[fb][2], (float)bias4[fb][3]};
                     }
+                    if constexpr ((EPI & BH_EPI_BIAS_ROW) != 0) {
+                        v0 += bh_gemm::f32x2{brow, brow};
+                        v1 += bh_gemm::f32x2{brow, brow};
+                    }
+                    if constexpr ((EPI & BH_EPI_GELU) != 0) bh_gemm::gelu_erf2x2(v0, v1);
+                    const half4 o = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v1[0], (_Float16)v1[1]};
                     acc[tb][fb] = floatx4{0.f, 0.f, 0.f, 0.f};
                     const int chunk = fb * 2 + (lg >> 1);  // the 16-byte chunk of the row's 128 bytes that holds features 16 fb + 4 lg ..
                     *reinterpret_cast<half4*>(stg + tr * 128 + ((chunk ^ (tr & 7)) << 4) + (lg & 1) * 8) = o;
