@@ -183,6 +183,11 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         if (a.M % 256 || a.N % 256 || a.residual || a.gelu || !(a.bias && a.bias_mode == 1) || a.c_block_rows || g_swap_b != 0)
             return hipErrorInvalidValue;
         // (non-temporal burst, like the GELU output; level 2 of gemm_full_line_stores: 64-byte row pieces through LDS)
+        if (g_mfma16 && g_mfma16 < 16 && g_full_line_stores >= 2) {  // (the 16x16x32 kernel has the through-LDS route only)
+            BhGemmArgs t = a;
+            t.tail_split = g_tail_split;
+            return bh_gemm_p16(t, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, true, g_mfma16, stream);
+        }
         return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? 35 : 3, stream);
     }
     if (a.ln_stats || a.stats_out) {

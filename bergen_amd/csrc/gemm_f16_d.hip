@@ -20,6 +20,9 @@ hipError_t p16_v(const BhGemmArgs& a, int epi, bool nontemporal, hipStream_t s) 
         case 0: return bh_gemm_launch_p16<0, false, SPREAD>(a, n_cu(), s);
         case BH_EPI_BIAS_COL: return bh_gemm_launch_p16<BH_EPI_BIAS_COL, false, SPREAD>(a, n_cu(), s);
         case BH_EPI_BIAS_ROW: return bh_gemm_launch_p16<BH_EPI_BIAS_ROW, false, SPREAD>(a, n_cu(), s);
+        case BH_EPI_BIAS_COL | BH_EPI_SWIGLU:
+            return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, true, SPREAD>(a, n_cu(), s)
+                               : bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, false, SPREAD>(a, n_cu(), s);
         case BH_EPI_BIAS_COL | BH_EPI_GELU:
             return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, true, SPREAD>(a, n_cu(), s)
                                : bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_GELU, false, SPREAD>(a, n_cu(), s);

@@ -21,7 +21,8 @@
 //     one per workgroup, all eight waves on each (64 or 32 tokens x 64 features per wave); same pipeline, same stage count, a half or a
 //     quarter of the MFMAs per stage.  Every output element still sums the same k-steps in the same order: same bits.
 // Epilogues: none, bias per column (optionally + GELU), bias per row; row-major output or the attention kernel's blocked V^T layout — every
-// projection of a BERT layer.  The fused-LayerNorm, gated (SwiGLU), segmented-max and batched epilogues stay on gemm_f16_persist.h.
+// projection of a BERT layer — and the gated (SwiGLU) fold of NomicBert's feed-forward.  The fused-LayerNorm, segmented-max and batched
+// epilogues stay on gemm_f16_persist.h.
 #pragma once
 #include "gemm_f16_persist.h"
 
@@ -29,7 +30,9 @@
 template <int EPI, bool NT, bool SPREAD, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    static_assert(EPI == 0 || EPI == BH_EPI_BIAS_COL || EPI == (BH_EPI_BIAS_COL | BH_EPI_GELU) || EPI == BH_EPI_BIAS_ROW, "epilogues of this kernel");
+    static_assert(EPI == 0 || EPI == BH_EPI_BIAS_COL || EPI == (BH_EPI_BIAS_COL | BH_EPI_GELU) || EPI == BH_EPI_BIAS_ROW ||
+                      EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU),
+                  "epilogues of this kernel");
     constexpr int BK = 64, WN = 4, R = 2;
     constexpr int NW = 8;
     constexpr int BM = 256, BN = 256;
@@ -239,6 +242,50 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     auto epilogue = [&](auto tbs_c, int m0, int n0) {
         constexpr int TBS = decltype(tbs_c)::value;
         if constexpr ((ABL & 8) != 0) return;
+        if constexpr ((EPI & BH_EPI_SWIGLU) != 0) {
+            // Gated feed-forward (NomicBertMLP): the columns are (gate, up) pairs, C is [M][N / 2] = silu(gate) * up — the arithmetic of
+            // gemm_f16_persist.h's fold, expression for expression (same bits).  A lane's four columns are two pairs = two outputs = 4 bytes; the
+            // wave's 64 columns fold to 64-byte row pieces, staged as 32 rows x 64 bytes and stored 16 rows per instruction.
+            const int rrow = lane >> 2, rch = lane & 3;
+            _Float16* gptr = a.C + (size_t)(m0 + wm * 16 * TBS + rrow) * a.ldc + ((n0 + wn * 64) >> 1) + rch * 8;
+            half4 bias4[FB];
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) bias4[fb] = *reinterpret_cast<const half4*>(a.bias + n0 + wn * 64 + fb * 16 + 4 * lg);
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int tp = 0; tp < (TBS + 1) / 2; ++tp) {
+#pragma unroll
+                for (int half_ = 0; half_ < (TBS > 1 ? 2 : 1); ++half_) {
+                    const int tb = 2 * tp + half_;
+                    const int tr = half_ * 16 + q16;
+#pragma unroll
+                    for (int fb = 0; fb < FB; ++fb) {
+                        half2v o;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float g = acc[tb][fb][2 * e] + 0.f + (float)bias4[fb][2 * e];
+                            const float up = acc[tb][fb][2 * e + 1] + 0.f + (float)bias4[fb][2 * e + 1];
+                            o[e] = (_Float16)(g / (1.0f + __builtin_amdgcn_exp2f(-g * 1.4426950408889634f)) * up);
+                        }
+                        acc[tb][fb] = floatx4{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<half2v*>(stg + tr * 64 + ((fb ^ ((tr >> 1) & 3)) << 4) + lg * 4) = o;
+                    }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < (TBS > 1 ? 2 : 1); ++i) {
+                    const int row = 16 * i + rrow;
+                    const half8 v = *reinterpret_cast<const half8*>(stg + row * 64 + ((rch ^ ((row >> 1) & 3)) << 4));
+                    half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tp * 32 + 16 * i) * a.ldc);
+                    if constexpr (NT)
+                        __builtin_nontemporal_store(v, p);
+                    else
+                        *p = v;
+                }
+                asm volatile("" ::: "memory");
+            }
+            return;
+        }
         const int rrow = lane >> 3, rch = lane & 7;  // read-back: instruction i takes rows 8 i + rrow, 16-byte chunk rch
         // output addressing: row-major, or — c_block_rows != 0 — blocked by 64 columns (the attention kernel's V^T layout: element (m, n) at
         // C[(n / 64) * c_block_rows * 64 + m * 64 + n % 64]): the wave's 64 columns are one block, its rows 128-byte lines either way
