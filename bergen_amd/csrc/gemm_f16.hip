@@ -46,7 +46,7 @@ int g_full_line_stores = 2;  // bh_set_option "gemm_full_line_stores" (default 2
 
 void bh_gemm_set_gelu_nontemporal(int on) { g_gelu_nontemporal = on != 0; }
 int g_mfma16 = 1;  // bh_set_option "gemm_mfma16" (default 1 since round 5): the bias (+ GELU) projections on gemm_f16_p16.h (v_mfma_f32_16x16x32_f16) instead of gemm_f16_persist.h
-void bh_gemm_set_mfma16(int on) { g_mfma16 = on; }  // 2 = + refill spread over both halves of a stage
+void bh_gemm_set_mfma16(int on) { g_mfma16 = on; }  // (16 x ablation bits + 1: profiles/gemm_p16_ablate.py)
 int g_tail_split = 0;  // bh_set_option "gemm_tail_split": gemm_f16_p16.h cuts a short last round of tiles into sub-tiles (same bits; default off: faster
                        // for a GEMM alone, 1 % slower inside the encoder, whose two micro-batch streams already fill a launch's idle tail)
 void bh_gemm_set_tail_split(int on) { g_tail_split = on != 0; }

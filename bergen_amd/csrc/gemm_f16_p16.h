@@ -27,7 +27,7 @@
 #include "gemm_f16_persist.h"
 
 // ABL (bench only, results invalid): 1 no LDS-DMA after the pipeline start, 2 no MFMA, 4 no fragment reads, 8 no epilogue, 16 epilogue math without stores
-template <int EPI, bool NT, bool SPREAD, int ABL = 0>
+template <int EPI, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(EPI == 0 || EPI == BH_EPI_BIAS_COL || EPI == (BH_EPI_BIAS_COL | BH_EPI_GELU) || EPI == BH_EPI_BIAS_ROW ||
@@ -193,16 +193,9 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
             for (int fb = 0; fb < FB; ++fb)
                 if constexpr ((ABL & 2) == 0) acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][fb], xt[0][tb], acc[tb][fb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (SPREAD) {  // the second half of the refill that the previous stage's second half began: feature rows
-                constexpr int PER = (NL / 2 + TBS - 1) / TBS;
-#pragma unroll
-                for (int u = 0; u < PER; ++u)
-                    if (tb * PER + u < NL / 2) issue_piece(NL / 2 + tb * PER + u);
-            }
             reads_behind(tbs_c, tb, st, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (SPREAD) issue_advance();
         // k-step 1.  Every read of this stage must have returned before its slot is handed back:
 #pragma unroll
         for (int fb = 0; fb < FB; ++fb) asm volatile("" : "+v"(wf[1][fb]));
@@ -217,23 +210,15 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
             for (int fb = 0; fb < FB; ++fb)
                 if constexpr ((ABL & 2) == 0) acc[tb][fb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][fb], xt[1][tb], acc[tb][fb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // the refill goes into the slot everybody just left: spread over the MFMA groups (one LDS-DMA instruction per group of a whole tile;
-            // measured against two per group in the first four: 13.80 vs 14.13 ms)
-            if constexpr (SPREAD) {  // token rows of the stage after the next, one LDS-DMA instruction behind every other group of a whole tile
-                constexpr int EVERY = TBS >= 8 ? 2 : 1, PER = TBS >= 4 ? 1 : NL / 2 / TBS;
-                if (tb % EVERY == 0) {
+            // the refill goes into the slot everybody just left, one LDS-DMA instruction per MFMA group of a whole tile (also measured, BERT-base
+            // forward: two per group in the first four groups 13.80 -> 14.13 ms; the refill spread over both halves of a stage — token rows behind
+            // this k-step, feature rows behind the next stage's first — 13.79 -> 14.12 ms: profiles/README.md, round 5)
 #pragma unroll
-                    for (int u = 0; u < PER; ++u)
-                        if ((tb / EVERY) * PER + u < NL / 2) issue_piece((tb / EVERY) * PER + u);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NL / TBS; ++u) issue_piece(tb * (NL / TBS) + u);
-            }
+            for (int u = 0; u < NL / TBS; ++u) issue_piece(tb * (NL / TBS) + u);
             reads_behind(tbs_c, tb, nst, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (!SPREAD) issue_advance();
+        issue_advance();
     };
 
     // ---- epilogue of a (sub-)tile whose rows start at m0: bias (+ GELU), fp16, through the wave's staging image, out as whole 128-byte
@@ -346,12 +331,7 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     // ---- pipeline start
     issue_stage();
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if constexpr (SPREAD) {
-#pragma unroll
-        for (int i = 0; i < NL / 2; ++i) issue_piece(i);
-    } else {
-        issue_stage();
-    }
+    issue_stage();
     abl_started = true;
     using Whole = std::integral_constant<int, TB>;
     auto first_fragments = [&](auto tbs_c) {  // k-step 0 of the stage at the consumer's slot (landed)
@@ -395,10 +375,10 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI, bool NT, bool SPREAD, int ABL = 0>
+template <int EPI, bool NT, int ABL = 0>
 hipError_t bh_gemm_launch_p16(const BhGemmArgs& a, int n_cu, hipStream_t stream) {
     constexpr size_t smem = 2 * 16 * 4096 + 8 * 4096;
-    auto kern = bh_gemm_f16_p16kernel<EPI, NT, SPREAD, ABL>;
+    auto kern = bh_gemm_f16_p16kernel<EPI, NT, ABL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

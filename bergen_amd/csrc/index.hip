@@ -371,7 +371,7 @@ int bh_set_option(const char* name, int64_t value) {
         if (value < 0 || value > 2) return fail(BH_EINVAL, "gemm_full_line_stores must be 0, 1 or 2 (1 = row-major outputs, 2 = the default: + blocked V^T output and gated fold)");
         bh_gemm_set_full_line_stores((int)value);
     } else if (s == "gemm_mfma16") {
-        if (value < 0 || value > 511) return fail(BH_EINVAL, "gemm_mfma16 must be 0, 1, 2 or 16 x ablation bits + 1");
+        if (value < 0 || value > 511 || (value > 1 && (value & 15) != 1)) return fail(BH_EINVAL, "gemm_mfma16 must be 0, 1 or 16 x ablation bits + 1");
         bh_gemm_set_mfma16((int)value);
     } else if (s == "gemm_tail_split") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "gemm_tail_split must be 0 or 1");

@@ -133,11 +133,10 @@ def test_gemm_mfma16_kernel_against_oracle():
             for kw, ref in [(dict(), bert_oracle.gemm_ref(a, w)), (dict(bias=h16(bc)), bert_oracle.gemm_ref(a, w, bc, 1)),
                             (dict(bias=h16(bc), gelu=True), bert_oracle.gemm_ref(a, w, bc, 1, gelu=True))]:
                 outs = []
-                for on in (0, 1, 2):
+                for on in (0, 1):
                     _lib.set_option("gemm_mfma16", on)
                     out, _ = encoder.gemm_f16(h16(a), h16(w), variant=7, **kw)
                     outs.append(out.clone())
-                assert torch.equal(outs[1], outs[2])
                 assert_gemm_close(outs[1], ref, f"mfma16 {M}x{N}x{K} {sorted(kw)}")
                 assert_gemm_close(outs[1], outs[0].float().cpu().numpy().astype(np.float64), f"mfma16 vs production {M}x{N}x{K} {sorted(kw)}")
     finally:
@@ -160,7 +159,7 @@ def test_gemm_tail_split_gives_the_same_bits():
         cases.append((tiles // tn, tn, K))
     cases.append((130, 6, 768))  # the bench batch's micro-batch through the Q | K projection: 780 tiles
     try:
-        for mode in (1, 2):  # refill in one half / spread over both halves of a stage
+        for mode in (1,):
             _lib.set_option("gemm_mfma16", mode)
             for (tm, tn, K) in cases:
                 M, N = 256 * tm, 256 * tn
