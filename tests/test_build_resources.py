@@ -31,7 +31,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # path launches them: the GELU projection runs on gemm_f16_p16.h, whose bench-only ablation instantiations (last parameter != 0) may spill too)
 ALLOW_SCRATCH = re.compile(r"bh_gemm_f16_pkernelILi257ELi33E"
                            r"|bh_gemm_f16_pkernelILi9ELi(0|16)E"
-                           r"|bh_gemm_f16_p16kernelILi\d+ELb[01]ELb[01]ELi[1-9]"
+                           r"|bh_gemm_f16_p16kernelILi\d+ELb[01]ELi[1-9]"
                            r"|bh_scan_topk256_kernelILi24ELi64ELi12ELi3ELi4ELb[01]ELi0ELi1ELi1E"
                            r"|bh_gemm_f16_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELi[1-9]"
                            r"|bh_scan_topk256_kernelILi24ELi256E"
@@ -96,7 +96,7 @@ def test_production_kernels_do_not_spill():
     # occupancy assumptions of the launch geometry
     pk = {n: u for n, u in results["gemm_f16_c.hip"].items() if "pkernel" in n}
     assert pk and all(u["Occupancy"] >= 2 for u in pk.values())          # 8 waves per CU on 4 SIMDs
-    p16 = {n: u for n, u in results["gemm_f16_d.hip"].items() if re.search(r"p16kernelILi\d+ELb[01]ELb[01]ELi0E", n)}
-    assert len(p16) >= 5 and all(u["Occupancy"] >= 2 and u.get("ScratchSize", 0) == 0 for u in p16.values())  # the 16x16x32 kernels in production
+    p16 = {n: u for n, u in results["gemm_f16_d.hip"].items() if re.search(r"p16kernelILi\d+ELb[01]ELi0E", n)}
+    assert len(p16) >= 7 and all(u["Occupancy"] >= 2 and u.get("ScratchSize", 0) == 0 for u in p16.values())  # the 16x16x32 kernels in production
     att = results["attention.hip"]
     assert all(u["Occupancy"] >= 4 for u in att.values())                 # 16 waves per CU
