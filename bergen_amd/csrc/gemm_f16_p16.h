@@ -12,14 +12,16 @@
 //     4 ks + lg: conflict-free, profiles/lds_swizzle_search.py); applied, as there, to the per-lane SOURCE address of the LDS-DMA.
 //   * fragments: per k-step of 32 a wave reads 4 feature fragments (operand a: the weights, so that a lane ends with ONE token and 4
 //     consecutive features) and 8 token fragments (operand b), 32 MFMAs on 32 independent accumulator quads (128 registers, as
-//     before); feature fragments double-buffered over the k-steps, token fragments refilled rolling behind their 4 MFMAs.
+//     before); the fragments of both k-steps of a stage double-buffered in registers, all reads of the next k-step issued behind the first five
+//     MFMA groups of the current one.
 //   * epilogue: lane (q16, lg) of block (tb, fb) holds token 16 tb + q16, features 16 fb + 4 lg + 0..3: one 8-byte LDS write per block
 //     into the wave's 32-row x 128-byte staging image (16-byte chunks XORed with the row), read back and stored exactly as before.
 //   * TAIL SPLIT (BhGemmArgs::tail_split): an XCD's 32 workgroups walk its tiles in rounds, and a last round with r <= 16 tiles left 16
 //     or more of them idle for a whole tile time (the bench batch's micro-batch: 780 tiles of the Q | K projection = 3.05 rounds, paid
 //     as 4).  Here such a remainder is cut along the TOKENS into 2 (r <= 16) or 4 (r <= 8) sub-tiles of 128 or 64 tokens x 256 features,
 //     one per workgroup, all eight waves on each (64 or 32 tokens x 64 features per wave); same pipeline, same stage count, a half or a
-//     quarter of the MFMAs per stage.  Every output element still sums the same k-steps in the same order: same bits.
+//     quarter of the MFMAs per stage.  Every output element still sums the same k-steps in the same order: same bits.  OFF by default: +8 % on
+//     a projection launched alone, -1 % inside the encoder, whose second micro-batch stream already runs in a launch's idle tail.
 // Epilogues: none, bias per column (optionally + GELU), bias per row; row-major output or the attention kernel's blocked V^T layout — every
 // projection of a BERT layer — and the gated (SwiGLU) fold of NomicBert's feed-forward.  The fused-LayerNorm, segmented-max and batched
 // epilogues stay on gemm_f16_persist.h (the SPLADE head's segmented max was built here too and measured: with 4 tokens per lane instead of 8 it
