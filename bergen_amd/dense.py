@@ -31,9 +31,11 @@ def encoder_backend(model):
     return "hip" if isinstance(model, BertEncoder) else "hf"
 
 
-def _native_encoder(model, require_native=None):
+def _native_encoder(model, require_native=None, need_mlm_head=False):
     """Move an HF BertModel-architecture encoder onto the hand-written gfx950 forward pass.
     require_native (or BERGEN_AMD_REQUIRE_NATIVE=1 in the environment): raise instead of falling back to the HF module.
+    need_mlm_head (the Splade plug-in): a converted encoder without the masked-LM head tensors is of no use to the caller —
+    it stays on the HF module (whose `.logits` the plug-in then pools), loudly, like any other uncovered architecture.
 
     On a GPU box every BERT-architecture checkpoint (all dense retrievers of the reference's
     config/retriever/*.yaml except repllama) runs on bergen_amd.BertEncoder; BERGEN_AMD_ENCODER=hf keeps the
@@ -53,11 +55,18 @@ def _native_encoder(model, require_native=None):
         why = BertEncoder.unsupported_reason(model)
     if why is None:
         try:
-            return BertEncoder.from_hf(model, device=torch.cuda.current_device())
+            enc = BertEncoder.from_hf(model, device=torch.cuda.current_device())
+            if not need_mlm_head or enc.has_mlm_head:
+                return enc
+            enc.close()
+            why = f"no masked-LM head tensors recognised in {type(model).__name__}'s state dict (SPLADE pools the head's logits)"
         except (ValueError, TypeError, KeyError) as exc:
             # the configuration looked like one the kernels cover but the checkpoint's tensors do not fit it (names of a remote
             # modelling file, a missing tensor): that is a reason to stay on HF, not a crash of a run that worked before
             why = f"conversion of the checkpoint failed: {type(exc).__name__}: {exc}"
+    elif need_mlm_head and not _has_mlm_head_names(model):
+        # (no device needed to know: decided from the tensor names, so that a GPU-less box reports the same reason)
+        why = f"{why}; no masked-LM head tensors recognised in {type(model).__name__}'s state dict"
     name = getattr(getattr(model, "config", None), "_name_or_path", None) or type(model).__name__
     if require_native is None:
         require_native = os.environ.get("BERGEN_AMD_REQUIRE_NATIVE", "0") not in ("", "0", "false", "False")
@@ -72,6 +81,16 @@ def _native_encoder(model, require_native=None):
     except Exception:  # noqa: BLE001 — (an object that refuses attributes: the log line above is the record)
         pass
     return model
+
+
+def _has_mlm_head_names(model):
+    """True when `model`'s state dict carries a masked-LM head under one of the names canonical_state_dict maps
+    (BERT cls.predictions.*, DistilBERT vocab_*, RoBERTa lm_head.*)."""
+    try:
+        names = list(model.state_dict().keys())
+    except Exception:  # noqa: BLE001
+        return False
+    return any(n.startswith(("cls.predictions.transform.", "vocab_transform.", "lm_head.dense.")) for n in names)
 
 
 class Retriever(ABC):

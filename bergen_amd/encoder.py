@@ -286,8 +286,18 @@ def canonical_state_dict(cfg, state_dict):
                 if a in key:
                     key = key.replace(a, b)
                     break
-            if key.startswith(("vocab_transform.", "vocab_layer_norm.", "vocab_projector.", "pre_classifier.")):
-                continue  # DistilBERT task heads: not used by the reference's retrievers
+            # DistilBertForMaskedLM's head (modeling_distilbert.py: vocab_transform -> activation -> vocab_layer_norm ->
+            # vocab_projector) is BertForMaskedLM's cls.predictions by other names — the doc model of the reference's
+            # config/retriever/splade-efficient.yaml:3 reaches it through AutoModelForMaskedLM (models/retrievers/splade.py:17-19)
+            for a, b in (("vocab_transform.", "cls.predictions.transform.dense."),
+                         ("vocab_layer_norm.", "cls.predictions.transform.LayerNorm."),
+                         ("vocab_projector.", "cls.predictions.decoder.")):
+                if key.startswith(a):
+                    key = b + key[len(a):]
+                    break
+            if key.startswith(("pre_classifier.", "classifier.")):
+                # DistilBertForSequenceClassification pools with Linear + ReLU, not BertPooler's tanh: classify() must not exist
+                continue
         elif mt != "bert":
             # RobertaClassificationHead = dense + tanh + out_proj on the <s> token: BertPooler + classifier by another name
             if key.startswith("classifier.dense."):
@@ -295,7 +305,17 @@ def canonical_state_dict(cfg, state_dict):
             elif key.startswith("classifier.out_proj."):
                 key = "classifier." + key[len("classifier.out_proj."):]
             elif key.startswith("lm_head."):
-                continue
+                # RobertaLMHead (dense -> gelu -> layer_norm -> decoder, + bias) = BertForMaskedLM's cls.predictions renamed
+                for a, b in (("lm_head.dense.", "cls.predictions.transform.dense."),
+                             ("lm_head.layer_norm.", "cls.predictions.transform.LayerNorm."),
+                             ("lm_head.decoder.", "cls.predictions.decoder.")):
+                    if key.startswith(a):
+                        key = b + key[len(a):]
+                        break
+                if key == "lm_head.bias":
+                    key = "cls.predictions.bias"
+                if key.startswith("lm_head."):
+                    continue
         out[key] = t
     if mt == "distilbert" or "embeddings.token_type_embeddings.weight" not in out:
         out["embeddings.token_type_embeddings.weight"] = torch.zeros(int(cfg["type_vocab_size"]), d, dtype=torch.float16)

@@ -29,12 +29,12 @@ class Splade(Retriever):
             from transformers import AutoModelForMaskedLM, AutoTokenizer
         if model is None:
             model = AutoModelForMaskedLM.from_pretrained(self.model_name, low_cpu_mem_usage=True, torch_dtype=torch.float16)
-        self.model = _native_encoder(model)
+        self.model = _native_encoder(model, need_mlm_head=True)
         if query_encoder is not None:
-            self.query_encoder = _native_encoder(query_encoder)
+            self.query_encoder = _native_encoder(query_encoder, need_mlm_head=True)
         elif query_encoder_name:
             self.query_encoder = _native_encoder(AutoModelForMaskedLM.from_pretrained(
-                query_encoder_name, torch_dtype=torch.float16, low_cpu_mem_usage=True))
+                query_encoder_name, torch_dtype=torch.float16, low_cpu_mem_usage=True), need_mlm_head=True)
         else:
             self.query_encoder = self.model  # otherwise symmetric
         self.tokenizer = tokenizer if tokenizer is not None else AutoTokenizer.from_pretrained(self.model_name,
@@ -56,7 +56,9 @@ class Splade(Retriever):
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
         encoder = self.model if query_or_doc == "doc" else self.query_encoder
-        if getattr(encoder, "has_mlm_head", False):  # native: host BatchEncoding straight through the C ABI
+        from .encoder import BertEncoder
+        if isinstance(encoder, BertEncoder):  # native: host BatchEncoding straight through the C ABI
+            # (an injected BertEncoder without the head raises here by name — never `.logits` on its hidden-state tuple)
             return {"embedding": encoder.encode_splade(kwargs)}
         kwargs = {key: value.to(self.device) for key, value in kwargs.items()}
         logits = encoder(**kwargs).logits

@@ -73,5 +73,73 @@ def main():
           {t: float((out[f'ref_emb_{t}'] > 0).mean()) for t in ("untied", "tied")})
 
 
+# ---- DistilBertForMaskedLM / RobertaForMaskedLM: the other masked-LM heads AutoModelForMaskedLM can hand the reference's Splade ----
+# config/retriever/splade-efficient.yaml:3-4 names naver/efficient-splade-VI-BT-large-{doc,query}: DistilBertForMaskedLM checkpoints.
+# The fixture stores the HF state dict under HF's OWN names (vocab_transform / vocab_layer_norm / vocab_projector; lm_head.*), so the
+# tests also pin bergen_amd.encoder.canonical_state_dict's renaming onto BertForMaskedLM's cls.predictions.*.
+
+ALT = {
+    "distilbert": dict(vocab_size=1000, dim=128, n_heads=2, n_layers=2, hidden_dim=512, max_position_embeddings=64,
+                       activation="gelu", sinusoidal_pos_embds=False, dropout=0.0, attention_dropout=0.0, pad_token_id=0),
+    "roberta": dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512,
+                    max_position_embeddings=70, type_vocab_size=1, layer_norm_eps=1e-5, hidden_act="gelu", pad_token_id=1,
+                    bos_token_id=0, eos_token_id=2),
+}
+
+
+def alt_model(kind, seed):
+    import transformers as T
+    torch.manual_seed(seed)
+    if kind == "distilbert":
+        model = T.DistilBertForMaskedLM(T.DistilBertConfig(**ALT[kind], attn_implementation="eager"))
+    else:
+        model = T.RobertaForMaskedLM(T.RobertaConfig(**ALT[kind], attn_implementation="eager"))
+    model = model.eval()
+    with torch.no_grad():  # HF initialises biases to 0 and LayerNorm gains to 1: give every head tensor content, fp16-representable
+        g = torch.Generator().manual_seed(seed + 1)
+        for name, p in model.named_parameters():
+            if name.endswith(".bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            elif "norm" in name.lower() and name.endswith(".weight"):
+                p.copy_(1.0 + torch.randn(p.shape, generator=g) * 0.05)
+            elif name.endswith(".weight"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.08)
+            p.copy_(p.half().float())
+        head_bias = model.vocab_projector.bias if kind == "distilbert" else model.lm_head.bias
+        head_bias.copy_((head_bias - 2.2).half().float())  # sparse-ish output, like a trained SPLADE model
+    return model
+
+
+def main_alt():
+    assert ref_import.available(), "needs /root/reference"
+    ref = ref_import.load()
+    for kind, seed in (("distilbert", 41), ("roberta", 43)):
+        model = alt_model(kind, seed)
+        cfg = ALT[kind]
+        rng = np.random.default_rng(seed + 2)
+        B, T = 7, 37
+        lens = rng.integers(3, T + 1, size=B)
+        lens[0] = T
+        ids = rng.integers(3, cfg["vocab_size"], size=(B, T)).astype(np.int64)
+        mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+        ids[mask == 0] = cfg["pad_token_id"]
+        sp = object.__new__(ref.splade.Splade)  # skip __init__ (it downloads a checkpoint)
+        sp.model = model
+        sp.query_encoder = model
+        kwargs = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+        with torch.no_grad():
+            emb = sp("doc", kwargs)["embedding"]
+            logits = model(**kwargs).logits
+        out = {"w::" + k: v.detach().numpy().astype(np.float16) for k, v in model.state_dict().items()
+               if v.dtype.is_floating_point}
+        path = os.path.join(ROOT, "tests", "golden", f"splade_tiny_{kind}.npz")
+        np.savez_compressed(path, cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([repr(v) for v in cfg.values()]),
+                            model_type=np.array(kind), input_ids=ids, attention_mask=mask,
+                            ref_emb=emb.numpy().astype(np.float32), hf_logits=logits[:2].numpy().astype(np.float32), **out)
+        print("wrote", path, os.path.getsize(path), "bytes; density", float((emb > 0).float().mean()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--alt" not in sys.argv:  # (the BERT fixture is regenerated only on request of the default invocation: it is seeded)
+        main()
+    main_alt()

@@ -70,6 +70,13 @@ def _make(kind, tok, vocab, path):
                                                  layer_norm_eps=1e-5, **kw))
     elif kind == "bert_mlm":
         m = T.BertForMaskedLM(T.BertConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256, **kw))
+    elif kind == "distilbert_mlm":  # the doc model's class of config/retriever/splade-efficient.yaml:3
+        m = T.DistilBertForMaskedLM(T.DistilBertConfig(vocab_size=vocab, dim=128, n_heads=2, n_layers=2, hidden_dim=256,
+                                                       activation="gelu", max_position_embeddings=66, dropout=0.0,
+                                                       attention_dropout=0.0, pad_token_id=1))
+    elif kind == "xlmr_mlm":
+        m = T.XLMRobertaForMaskedLM(T.XLMRobertaConfig(hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                                                       type_vocab_size=1, layer_norm_eps=1e-5, **kw))
     elif kind == "bert_cls":
         m = T.BertForSequenceClassification(T.BertConfig(hidden_size=128, num_attention_heads=4, intermediate_size=256, num_labels=1, **kw))
     elif kind == "deberta_cls":
@@ -143,18 +150,21 @@ def test_left_padded_batches_get_hf_position_ids(kind, toy_tokenizer_files, tmp_
     _close(got.float().cpu().numpy(), want.numpy(), f"{kind}/left-padded")
 
 
-def test_splade_from_a_checkpoint_directory_runs_on_the_hip_path(toy_tokenizer_files, tmp_path):
+@pytest.mark.parametrize("kind", ["bert_mlm", "distilbert_mlm", "xlmr_mlm"])
+def test_splade_from_a_checkpoint_directory_runs_on_the_hip_path(kind, toy_tokenizer_files, tmp_path):
+    """AutoModelForMaskedLM resolves to whatever class the checkpoint names (reference splade.py:17-19): BertForMaskedLM for
+    naver/splade-v3, DistilBertForMaskedLM for splade-efficient.yaml's models — every one must land on the HIP path WITH its head."""
     import transformers as T
     import bergen_amd
     tok, vocab = toy_tokenizer_files
-    path = _make("bert_mlm", tok, vocab, tmp_path / "mlm")
+    path = _make(kind, tok, vocab, tmp_path / "mlm")
     sp = bergen_amd.Splade(model_name=path, max_len=32)
-    assert sp.backend == "hip"
+    assert sp.backend == "hip" and sp.model.has_mlm_head
     batch = sp.collate_fn([{"content": t} for t in TEXTS], "doc")
     got = sp("doc", batch)["embedding"].float().cpu().numpy()
     ref_model = T.AutoModelForMaskedLM.from_pretrained(path, torch_dtype=torch.float32).eval()
     with torch.no_grad():
-        logits = ref_model(**batch).logits
+        logits = ref_model(**{k: v for k, v in batch.items() if k != "token_type_ids" or kind == "bert_mlm"}).logits
     want, _ = torch.max(torch.log(1 + torch.relu(logits)) * batch["attention_mask"].unsqueeze(-1), dim=1)  # splade.py:42-43
     want = want.numpy()
     assert got.shape == want.shape == (len(TEXTS), vocab)

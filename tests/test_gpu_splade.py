@@ -12,7 +12,7 @@ import torch
 
 from oracle import bert_oracle
 
-from test_splade_oracle import load
+from test_splade_oracle import canonical_alt, load, load_alt
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,28 @@ def test_golden_fixture(tag):
     assert hid.shape == (ids.shape[0], ids.shape[1], cfg["hidden_size"])
     c = enc.counters()
     assert c["real_tokens"] == int(mask.sum())
+    enc.close()
+
+
+@pytest.mark.parametrize("kind", ["distilbert", "roberta"])
+def test_golden_fixture_other_mlm_heads(kind):
+    """DistilBertForMaskedLM (splade-efficient.yaml's checkpoints) and RobertaForMaskedLM: the HF state dict under HF's own names
+    into BertEncoder, against the reference Splade.__call__'s output (tests/golden/splade_tiny_<kind>.npz) and the oracle."""
+    from bergen_amd import BertEncoder
+    z, cfg, sd = load_alt(kind)
+    enc = BertEncoder(cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=0)
+    assert enc.has_mlm_head, "the masked-LM head tensors were dropped"
+    ids, mask = z["input_ids"], z["attention_mask"]
+    got = enc.encode_splade({"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)})
+    canon, csd = canonical_alt(cfg, sd)
+    if "cls.predictions.bias" in csd:
+        csd.setdefault("cls.predictions.decoder.bias", csd["cls.predictions.bias"])
+    off = int(canon.get("position_offset", 0))
+    if off:
+        csd["embeddings.position_embeddings.weight"] = csd["embeddings.position_embeddings.weight"][off:]
+    lmax, emb = _logit_max(csd, dict(canon, hidden_act="gelu"), ids, mask, np.zeros_like(ids))
+    _check(got, z["ref_emb"].astype(np.float64), lmax, f"golden {kind}")
+    _check(got, emb, lmax, f"oracle {kind}")
     enc.close()
 
 

@@ -546,7 +546,62 @@ def test_distilbert_and_roberta_state_dicts_get_bert_names():
                                 "classifier.out_proj.weight": z, "lm_head.dense.weight": z,
                                 "roberta.embeddings.token_type_embeddings.weight": z})
     assert set(rob) == {"embeddings.word_embeddings.weight", "pooler.dense.weight", "classifier.weight",
-                        "embeddings.token_type_embeddings.weight"}
+                        "embeddings.token_type_embeddings.weight", "cls.predictions.transform.dense.weight"}
+    # masked-LM heads (AutoModelForMaskedLM, reference splade.py:17-19): DistilBERT's vocab_* and RoBERTa's lm_head.* are
+    # BertForMaskedLM's cls.predictions.* by other names; DistilBERT's sequence-classification head is NOT BertPooler's
+    dmlm = canonical_state_dict(cfg, {"vocab_transform.weight": z, "vocab_transform.bias": z, "vocab_layer_norm.weight": z,
+                                      "vocab_layer_norm.bias": z, "vocab_projector.weight": z, "vocab_projector.bias": z,
+                                      "pre_classifier.weight": z, "classifier.weight": z})
+    assert set(dmlm) == {"cls.predictions.transform.dense.weight", "cls.predictions.transform.dense.bias",
+                         "cls.predictions.transform.LayerNorm.weight", "cls.predictions.transform.LayerNorm.bias",
+                         "cls.predictions.decoder.weight", "cls.predictions.decoder.bias", "embeddings.token_type_embeddings.weight"}
+    rmlm = canonical_state_dict(dict(model_type="roberta", hidden_size=d, num_attention_heads=1, head_dim=64, type_vocab_size=1),
+                                {"lm_head.dense.bias": z, "lm_head.layer_norm.weight": z, "lm_head.decoder.weight": z,
+                                 "lm_head.decoder.bias": z, "lm_head.bias": z})
+    assert set(rmlm) == {"cls.predictions.transform.dense.bias", "cls.predictions.transform.LayerNorm.weight",
+                         "cls.predictions.decoder.weight", "cls.predictions.decoder.bias", "cls.predictions.bias",
+                         "embeddings.token_type_embeddings.weight"}
+
+
+def test_splade_never_pools_a_headless_native_encoder(monkeypatch, caplog):
+    """Round-5 review: a masked-LM checkpoint whose head the converter does not recognise must stay on the HF module (backend
+    'hf', reason recorded) — never become a BertEncoder whose hidden-state tuple Splade.__call__ then asks for `.logits`."""
+    import logging
+    from types import SimpleNamespace
+    from bergen_amd import dense as dense_mod
+    from bergen_amd.encoder import BertEncoder
+    from bergen_amd.splade import Splade
+
+    class Headless(torch.nn.Module):  # an MLM class with unknown head names
+        def __init__(self):
+            super().__init__()
+            self.config = SimpleNamespace(model_type="bert", _name_or_path="toy/odd-mlm")
+            self.odd_head = torch.nn.Linear(4, 4)
+
+    closed = []
+    fake = BertEncoder.__new__(BertEncoder)
+    fake._h, fake.has_mlm_head = None, False
+    monkeypatch.setattr(fake, "close", lambda: closed.append(1), raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(BertEncoder, "unsupported_reason", staticmethod(lambda m: None))
+    monkeypatch.setattr(BertEncoder, "from_hf", classmethod(lambda cls, m, device=0: fake))
+    model = Headless()
+    dense_mod._warned.clear()
+    with caplog.at_level(logging.WARNING, logger="bergen_amd"):
+        kept = dense_mod._native_encoder(model, need_mlm_head=True)
+    assert kept is model and closed == [1], "the head-less conversion must be dropped, the HF module kept"
+    assert dense_mod.encoder_backend(kept) == "hf" and "masked-LM head" in kept._bergen_amd_fallback_reason
+    assert any("masked-LM head" in r.getMessage() for r in caplog.records)
+    with pytest.raises(RuntimeError, match="require_native"):
+        dense_mod._native_encoder(model, require_native=True, need_mlm_head=True)
+    assert dense_mod._native_encoder(model, need_mlm_head=False) is fake  # (the dense plug-in does not need the head)
+    # an INJECTED head-less BertEncoder is a caller error reported by name, not an AttributeError on a tuple
+    sp = Splade.__new__(Splade)
+    sp.model = sp.query_encoder = fake
+    sp.device = torch.device("cpu")
+    with pytest.raises(RuntimeError, match="cls.predictions"):
+        sp("doc", {"input_ids": torch.tensor([[3, 4]])})
 
 
 def test_k_is_validated_before_the_index_is_built(tmp_path):
