@@ -339,7 +339,13 @@ def encoder_leg(args, device_index, arch="bert"):
                     "finite_and_shaped": ok},
         "encoder_roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
-                             "algorithmic_flops_per_step": c["flops"]},
+                             "algorithmic_flops_per_step": c["flops"],
+                             # the matrix pipe's busy share inside the three GEMM instantiations of a BERT layer (SQ counters of the
+                             # encoder-only command, profiles/sq_counters.json): FFN-up (bias + GELU), the bias-per-column projections
+                             # (Q|K, attention output, FFN-down), the blocked V^T projection
+                             "mfma_busy_frac": {key: (lambda b: b["mfma_busy_frac"] if b else None)(
+                                 pmc_mfma_busy("bh_gemm_f16_p16kernel", lambda nm, e=epi: nm.replace(" ", "").startswith(f"bh_gemm_f16_p16kernel<{e},")))
+                                 for key, epi in (("ffn_up_gelu", 9), ("bias_col_projections", 1), ("vt_projection", 2))}},
     }
 
 
@@ -785,7 +791,8 @@ def encode_stage_leg(args, device_index):
         # (BERGEN_AMD_TOKENIZER_PIECES=1); "processes": the reference's DataLoader workers; "inline": none
         for loader, workers in (("threads", 4), ("threads_pieces", 4), ("threads", 16), ("processes", 4), ("inline", 0)):
             stage = bergen_amd.Retrieve(init_args=dense, batch_size=512, num_workers=workers, device=device_index,
-                                        loader="processes" if loader == "processes" else "threads")
+                                        loader="processes" if loader == "processes" else "threads", require_native=True)
+            res["backend"] = stage.backend  # ('hip': require_native would have refused anything else)
             path = os.path.join(root, f"idx_{loader}{workers}")
             if loader == "threads_pieces":
                 os.environ["BERGEN_AMD_TOKENIZER_PIECES"] = "1"
@@ -1122,6 +1129,17 @@ def scan_roofline(acc, c, steps, n_rows, dim, k, traffic_json, dim_padded=None):
     out["algorithmic_frac"] = out["frac"]
     out["frac_binding"] = max(out["hbm_frac_of_needed_bytes"], out["mfma_frac"])
     out["binding_resource"] = "mfma" if out["mfma_frac"] >= out["hbm_frac_of_needed_bytes"] else "hbm"
+    # `bound` names what physically binds the launch (round-5 review: the line said "hbm" beside binding_resource "mfma"); `achieved`,
+    # `peak`, `unit` and `frac` stay SURVEY §8d's byte accounting (bound_of_frac says so), the MFMA side is mfma_tflops / mfma_frac /
+    # mfma_busy_frac (the matrix pipe's busy share by the SQ counters, profiles/sq_counters.json)
+    out["bound"] = out["binding_resource"]
+    out["bound_of_frac"] = "hbm (SURVEY 8d bytes per pass x passes per launch)"
+    want = ("128" if n_pair else "0")
+    busy = pmc_mfma_busy("bh_scan_topk256_kernel", lambda nm: f"<{dp // 32}," in nm.replace(" ", "") and
+                         nm.replace(" ", "").split(",")[6] == want) if name == "bh_scan_topk256_kernel" else None
+    out["mfma_busy_frac"] = busy["mfma_busy_frac"] if busy else None
+    out["mfma"] = {"achieved": out["mfma_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": out["mfma_frac"],
+                   "busy_frac": out["mfma_busy_frac"], "busy": busy}
     if n_pair and n_single > 0:
         a1 = single_ms / (n_single * steps)
         out["unpaired_launch"] = {"kernel": name, "passes_per_launch": 1, "launches": n_single * steps, "avg_launch_ms": a1,
@@ -1162,6 +1180,41 @@ def pmc_traffic(path, kernel, n_rows, dim_padded, variant=None):
         return None
 
 
+def _lib_path():
+    from bergen_amd import _lib
+    return _lib.LIB_PATH
+
+
+def _bh_version():
+    from bergen_amd import _lib
+    return int(_lib.lib().bh_version())
+
+
+def pmc_mfma_busy(kernel_prefix, match=None, path=None):
+    """`mfma_busy_frac` of a kernel instantiation from the committed SQ-counter summary (profiles/sq_counters.json, made by
+    profiles/make_sq_counters.py from rocprofv3 --pmc passes on a GPU box): the share of a launch's shader-clock cycles in which a
+    SIMD's matrix pipe was busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8).  `match` picks the instantiation (a
+    predicate on the demangled name).  None when there is no entry or when the kernel's source has changed since the counters were
+    collected (each entry carries the sha256 of its source files): a stale measurement is not reported."""
+    import hashlib
+    try:
+        ents = json.load(open(path or os.path.join(ROOT, "profiles", "sq_counters.json"))).get("kernels", {})
+        for name, ent in ents.items():
+            if not name.startswith(kernel_prefix) or (match is not None and not match(name)):
+                continue
+            h = hashlib.sha256()
+            for f in ent.get("source_files", []):
+                h.update(open(os.path.join(ROOT, "bergen_amd", "csrc", f), "rb").read())
+            if ent.get("source_sha16") != h.hexdigest()[:16]:
+                return None
+            return {"mfma_busy_frac": ent.get("mfma_busy_frac"), "kernel": name, "wait_any_frac": ent.get("wait_any_frac"),
+                    "lds_conflict_frac": ent.get("lds_conflict_frac"), "from": "profiles/" + str(ent.get("from")),
+                    "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), rocprofv3 --pmc under the profiler's clock"}
+    except Exception:
+        return None
+    return None
+
+
 class HipEnv:
     """Where the bench runs: one MI355X per rank, RCCL between the ranks, the HIP library underneath.  bench.py itself only
     ever builds this one (there is no CPU mode); tests/bench_standin.py drives run() with an oracle-backed stand-in so that
@@ -1196,6 +1249,10 @@ class HipEnv:
     def make_index(self, n_rows, dim):
         import bergen_amd
         return bergen_amd.FlatIndex(n_rows, dim, metric="ip", device=self.local_rank)
+
+    def describe_backend(self):
+        return {"search": "hip", "library": os.path.relpath(_lib_path(), ROOT), "bh_version": _bh_version(),
+                "require_native": os.environ.get("BERGEN_AMD_REQUIRE_NATIVE") == "1"}
 
     def make_stage(self, rank, world):
         """The stage object BERGEN builds (modules/rag.py:177-181), here with the row-sharded search switched on: the
@@ -1265,6 +1322,9 @@ def launch_ranks_if_needed(args, script=None):
 
 def main():
     args = parse_args()
+    # a driver-run number must never come from a silent HF-torch fallback: every plug-in this script builds refuses one
+    # (bergen_amd.dense._native_encoder; the stage legs also pass Retrieve(require_native=True))
+    os.environ["BERGEN_AMD_REQUIRE_NATIVE"] = "1"
     launch_ranks_if_needed(args)
     run(args, HipEnv(int(os.environ.get("LOCAL_RANK", "0")), backend=args.dist_backend))
 
@@ -1420,6 +1480,10 @@ def run(args, env):
                             f"corpus row-sharded over {world} GPU(s), resident in HBM",
                 "query_tile": c["query_tile"], "passes_per_step": c["n_passes"], "workgroups": c["n_workgroups"],
                 "rows_per_gpu": hi - lo, "parallelism": f"row-shard x{world}" + (" + RCCL all-gather of partial top-k" if world > 1 else ""),
+                # what computed the numbers of this line: the HIP library (there is no other search path in bergen_amd), and — for the
+                # encoder / stage / rerank legs — the hand-written forward pass: bench.py runs with BERGEN_AMD_REQUIRE_NATIVE=1, under
+                # which every plug-in REFUSES to fall back to an HF torch module
+                "backend": env.describe_backend(),
             },
             "roofline": roof,
             "kernel_ms_per_step": {"scan": scan_ms / args.steps, "merge_rescore": merge_ms / args.steps,

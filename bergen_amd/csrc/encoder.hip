@@ -548,7 +548,9 @@ int bh_encoder_commit(bh_encoder* e) {
         }
         e->has_mlm = true;  // a missing decoder bias stays zero
     }
-    if (!e->cfg.ffn_gated && e->rel_span == 0) {
+    // (the folded weights of option ln_fused — a second copy of Wqk, Wv and W1 per layer — are built when the option is switched on,
+    // and freed when it goes back to 0: bh_encoder_set_option; a handle that was given the option before commit builds them here)
+    if (e->ln_fused && !e->cfg.ffn_gated && e->rel_span == 0) {
         int rc = build_ln_folds(e);
         if (rc) return rc;
     }
@@ -570,6 +572,16 @@ int bh_encoder_set_option(bh_encoder* e, const char* name, int64_t value) {
     }
     if (std::string(name) == "ln_fused") {
         if (value != 0 && value != 1) return bh_fail(BH_EINVAL, "ln_fused must be 0 or 1");
+        if (value == 1 && e->committed && !e->ln_arena && !e->cfg.ffn_gated && e->rel_span == 0) {
+            int rc = build_ln_folds(e);  // (allocates the arena, runs the fold kernels, synchronises the stream)
+            if (rc) return rc;
+        }
+        if (value == 0 && e->ln_arena) {
+            BH_HIP_TRY(hipSetDevice(e->device));
+            BH_HIP_TRY(hipDeviceSynchronize());  // (bh_encoder_forward is synchronous; belt and braces for its side streams)
+            (void)hipFree(e->ln_arena);
+            e->ln_arena = nullptr;
+        }
         e->ln_fused = (int)value;
         return BH_OK;
     }

@@ -288,7 +288,9 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
             if (persist && g_mfma16 && (pst_eff == 33 || pst_eff == 35) &&
                 (epi == 0 || epi == BH_EPI_BIAS_COL || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU) || (epi == BH_EPI_BIAS_ROW && t.c_block_rows))) {
                 t.tail_split = g_tail_split;
-                e = bh_gemm_p16(t, epi, pst_eff == 35, g_mfma16, stream);
+                // (gemm_mfma16 >= 16 are the bench-only ablation modes of the bias + GELU instantiation, profiles/gemm_p16_ablate.py:
+                // every other epilogue runs the production kernel — mode 1 — so that a forward pass never fails on them)
+                e = bh_gemm_p16(t, epi, pst_eff == 35, (g_mfma16 >= 16 && epi != (BH_EPI_BIAS_COL | BH_EPI_GELU)) ? 1 : g_mfma16, stream);
             } else
                 e = persist ? bh_gemm_persist(t, epi, pst_eff, stream) : run_cfg(variant, t, epi, stream);
             if (e != hipSuccess) return e;

@@ -738,10 +738,10 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
                         sa.nq_valid[0] = bal_nq[0];
                         sa.nq_valid[1] = bal_nq[1];
                         sa.qtile2 = ix->qbuf.p + (size_t)passes[(size_t)p + 1].first * dp;
-                    } else {
+                    } else if (opt.balance_tail != 0) {
                         sa.nq_valid[0] = bq;
                         sa.nq_valid[1] = std::min(bq, nq - passes[(size_t)p + 1].first);
-                    }
+                    }  // (balance_tail = 0: {0, 0} = every wave scans, the kernel behaviour before the balanced remainder)
                     sa.qsplit = 2;
                     sa.pair_window = opt.pair256 == 2 ? 0 : 1;
                     // the partner finds a line in L2 only if the first reader's request left it there: the stream of a paired
@@ -750,7 +750,7 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
                     HIP_TRY(hipMemsetAsync(sa.progress, 0, (size_t)grid * sizeof(unsigned), st));
                     HIP_TRY(bh_launch_scan256_paired(sa, dp, kp, grid, st));
                 } else {
-                    sa.nq_valid[0] = std::min(bq, nq - passes[(size_t)p].first);
+                    if (opt.balance_tail != 0) sa.nq_valid[0] = std::min(bq, nq - passes[(size_t)p].first);
                     HIP_TRY(launch_scan(sa));
                 }
                 // per pass  N*d*2 (corpus, read once) + Bq*d*2 + Bq*k*12, with the LOGICAL d

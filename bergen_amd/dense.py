@@ -83,6 +83,14 @@ def _native_encoder(model, require_native=None, need_mlm_head=False):
     return model
 
 
+def plugin_backends(plugin):
+    """Backends of BOTH encoders of a retriever plug-in (ours or a stock reference one): {'doc': 'hip'|'hf', 'query': 'hip'|'hf'}.
+    `.model` is the document encoder, `.query_encoder` the query side (the same object for symmetric models: dense.py:17-20)."""
+    doc = getattr(plugin, "model", None)
+    qry = getattr(plugin, "query_encoder", None)
+    return {"doc": encoder_backend(doc), "query": encoder_backend(qry if qry is not None else doc)}
+
+
 def _has_mlm_head_names(model):
     """True when `model`'s state dict carries a masked-LM head under one of the names canonical_state_dict maps
     (BERT cls.predictions.*, DistilBERT vocab_*, RoBERTa lm_head.*)."""
@@ -280,9 +288,17 @@ class Dense(Retriever):
         return encoder_backend(self.model)
 
     @property
+    def backends(self):
+        """{'doc': ..., 'query': ...}: an asymmetric plug-in (query_encoder_name) may have ONE side on the HF torch implementation."""
+        return plugin_backends(self)
+
+    @property
     def fallback_reason(self):
-        """Why the document encoder is NOT on the HIP forward pass (None when it is)."""
-        return None if self.backend == "hip" else getattr(self.model, "_bergen_amd_fallback_reason", "injected torch module")
+        """Why an encoder of this plug-in is NOT on the HIP forward pass (None when both are)."""
+        for enc in (self.model, getattr(self, "query_encoder", None)):
+            if enc is not None and encoder_backend(enc) != "hip":
+                return getattr(enc, "_bergen_amd_fallback_reason", "injected torch module")
+        return None
 
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):

@@ -98,6 +98,7 @@ def _nomic_hub_config(get):
     if get("moe_every_n_layers", 0) or get("num_experts", 0) and int(get("num_experts")) > 1:
         raise ValueError("nomic_bert mixture-of-experts feed-forward")
     max_pos = int(need("n_positions", "max_position_embeddings"))
+    # (rotary_emb_base: the hub NomicBertConfig class default is 10000; nomic-embed-text-v1.5's config.json SETS 1000)
     if get("rotary_scaling_factor", None):
         # dynamic NTK scaling changes the rotary base only for sequences LONGER than max_trained_positions; up to there the plain
         # table holds, so the encoder simply does not accept longer sequences (bh_encoder_forward: "sequence too long")
@@ -106,7 +107,7 @@ def _nomic_hub_config(get):
                 num_hidden_layers=int(need("n_layer", "num_hidden_layers")), intermediate_size=int(need("n_inner", "intermediate_size")),
                 hidden_act="silu", type_vocab_size=int(get("type_vocab_size", 2) or 0) or 1,
                 layer_norm_eps=float(need("layer_norm_epsilon", "layer_norm_eps")), position_offset=0,
-                rotary_theta=float(get("rotary_emb_base", 1000.0) or 1000.0), ffn_gated=1, max_position_embeddings_override=max_pos)
+                rotary_theta=float(get("rotary_emb_base", None) or 10000.0), ffn_gated=1, max_position_embeddings_override=max_pos)
 
 
 def _nomic_hub_names(sd):

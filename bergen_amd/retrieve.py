@@ -123,9 +123,15 @@ class Retrieve:
         # require_native: a run on an architecture the HIP forward pass does not cover (gte-*-v1.5, jina-v2, repllama ...) keeps its
         # HF torch encoder with one warning by default; with this switch the stage refuses to start instead (the plug-ins take the
         # same switch themselves — Dense(require_native=True), BERGEN_AMD_REQUIRE_NATIVE=1 — and then fail at load time)
-        if require_native and getattr(self.model, "backend", "hip") != "hip":
-            raise RuntimeError(f"bergen_amd.Retrieve(require_native=True): the encoder of {getattr(self.model, 'model_name', self.model)!r} "
-                               f"runs on the HF torch implementation ({getattr(self.model, 'fallback_reason', None) or 'see the warning above'})")
+        # BOTH encoders are checked (an asymmetric Dense / Splade whose query encoder fell back must not pass), from the encoder
+        # objects themselves: a plug-in that does not say what it runs on (a stock reference one) is judged by its `.model`
+        if require_native:
+            from .dense import plugin_backends
+            sides = plugin_backends(self.model)
+            if any(v != "hip" for v in sides.values()):
+                raise RuntimeError(f"bergen_amd.Retrieve(require_native=True): the encoder of {getattr(self.model, 'model_name', self.model)!r} "
+                                   f"runs on the HF torch implementation {sides} "
+                                   f"({getattr(self.model, 'fallback_reason', None) or 'see the warning above'})")
         # host-side thread pools (torch intra-op, OpenMP, the tokenizer's rayon pool) follow the container's CPU quota, not the host's
         # CPU count (utils.cpu_budget: a GPU pod that shows 256 CPUs under a quota of 16 gets frozen by the CFS throttle otherwise);
         # explicit OMP_NUM_THREADS / RAYON_NUM_THREADS settings of the user win
@@ -663,8 +669,8 @@ class Retrieve:
     @property
     def backend(self):
         """'hip' when the plug-in's encoder runs on the hand-written kernels, 'hf' when it stayed on torch."""
-        from .dense import encoder_backend
-        return getattr(self.model, "backend", None) or encoder_backend(getattr(self.model, "model", None))
+        from .dense import plugin_backends
+        return "hip" if all(v == "hip" for v in plugin_backends(self.model).values()) else "hf"
 
     def get_clean_model_name(self):
         return self.model.model_name.replace('/', '_')

@@ -53,6 +53,19 @@ class Splade(Retriever):
         from .dense import encoder_backend
         return encoder_backend(self.model)
 
+    @property
+    def backends(self):
+        from .dense import plugin_backends
+        return plugin_backends(self)
+
+    @property
+    def fallback_reason(self):
+        from .dense import encoder_backend
+        for enc in (self.model, self.query_encoder):
+            if encoder_backend(enc) != "hip":
+                return getattr(enc, "_bergen_amd_fallback_reason", "injected torch module")
+        return None
+
     @torch.no_grad()
     def __call__(self, query_or_doc, kwargs):
         encoder = self.model if query_or_doc == "doc" else self.query_encoder

@@ -79,6 +79,9 @@ class OracleEnv:
     def make_index(self, n_rows, dim):
         return OracleIndex(n_rows, dim)
 
+    def describe_backend(self):
+        return {"search": "oracle stand-in (tests/bench_standin.py: control-flow test, not a measurement)"}
+
     make_stage = bench.HipEnv.make_stage  # the bench's own stage construction (Retrieve with search_rank / search_world)
 
     def sync(self):

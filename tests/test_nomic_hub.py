@@ -168,3 +168,38 @@ def test_retrieve_require_native_refuses_an_hf_backend():
     with pytest.raises(RuntimeError, match="require_native=True.*gte-base.*model_type 'new'"):
         bergen_amd.Retrieve(init_args=Plug(), require_native=True)
     bergen_amd.Retrieve(init_args=Plug()).close()  # default: the stage starts, the warning was the plug-in's
+
+
+def test_retrieve_require_native_checks_the_query_encoder_too():
+    """Round-5 advisor finding: an asymmetric plug-in whose QUERY encoder fell back to HF passed the check (only `.backend`, the
+    document side, was read), and a plug-in without a `backend` attribute counted as native."""
+    import bergen_amd
+    from bergen_amd.encoder import BertEncoder
+
+    native = BertEncoder.__new__(BertEncoder)
+    native._h = None
+
+    class Asym:
+        model_name = "toy/asymmetric"
+        backend = "hip"                      # what the old check read
+        model = native
+        query_encoder = torch.nn.Identity()  # the side that stayed on torch
+
+    class Silent:  # no `backend` attribute at all, a torch module inside
+        model_name = "toy/silent"
+        model = torch.nn.Identity()
+
+    for plug in (Asym(), Silent()):
+        with pytest.raises(RuntimeError, match="require_native=True"):
+            bergen_amd.Retrieve(init_args=plug, require_native=True)
+        r = bergen_amd.Retrieve(init_args=plug)
+        assert r.backend == "hf"
+        r.close()
+
+    class Sym:
+        model_name = "toy/native"
+        model = native
+
+    r = bergen_amd.Retrieve(init_args=Sym(), require_native=True)
+    assert r.backend == "hip"
+    r.close()
