@@ -731,6 +731,29 @@ def retrieve_stage_full_leg(args, stage, index, queries, want_scores, want_rows,
         shutil.rmtree(root, ignore_errors=True)
 
 
+def toy_wordpiece(vocab_size=30522, seed=12):
+    """A WordPiece tokenizer over a toy vocabulary of letter-only pseudo-words (no tokenizer file exists offline): one token per
+    word, BERT's normaliser / pre-tokeniser / [CLS] A [SEP] B [SEP] template.  Returns (tokenizer, words)."""
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    rng = np.random.default_rng(seed)
+    syl = ["ka", "mi", "to", "ra", "ne", "lo", "si", "du", "pe", "ga", "vo", "ti", "ma", "re", "ku", "ban", "ter", "lin", "sor", "pad",
+           "an", "el", "ion", "st", "qu"]
+    pool = set()
+    while len(pool) < vocab_size - 5:  # letter-only pseudo-words of 1-4 syllables (word-like lengths for the tokeniser)
+        pool.add("".join(syl[j] for j in rng.integers(0, len(syl), size=int(rng.integers(1, 5)))))
+    words = sorted(pool)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
+    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer(lowercase=True)
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
+                                                     special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
+                                  mask_token="[MASK]", model_input_names=["input_ids", "token_type_ids", "attention_mask"])
+    return tok, words
+
+
 def encode_stage_leg(args, device_index):
     """`Retrieve.encode_and_save` (reference modules/retrieve.py:110-144) as a stage: text passages -> tokeniser in DataLoader
     worker processes (collate_fn, padding='longest') -> HIP forward pass -> D2H of every batch -> chunk files in the reference's
@@ -743,29 +766,14 @@ def encode_stage_leg(args, device_index):
     import tempfile
 
     import datasets
-    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
-    from transformers import PreTrainedTokenizerFast
 
     import bergen_amd
     from bergen_amd import BertEncoder, synth
     n_pass = args.encode_stage_passages
     cfg = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
                max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
-    rng = np.random.default_rng(12)
-    syl = ["ka", "mi", "to", "ra", "ne", "lo", "si", "du", "pe", "ga", "vo", "ti", "ma", "re", "ku", "ban", "ter", "lin", "sor", "pad",
-           "an", "el", "ion", "st", "qu"]
-    pool = set()
-    while len(pool) < cfg["vocab_size"] - 5:  # letter-only pseudo-words of 1-4 syllables (word-like lengths for the tokeniser)
-        pool.add("".join(syl[j] for j in rng.integers(0, len(syl), size=int(rng.integers(1, 5)))))
-    words = sorted(pool)
-    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
-    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
-    t.normalizer = normalizers.BertNormalizer(lowercase=True)
-    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
-    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1",
-                                                     special_tokens=[("[CLS]", 2), ("[SEP]", 3)])
-    tok = PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]",
-                                  mask_token="[MASK]", model_input_names=["input_ids", "token_type_ids", "attention_mask"])
+    tok, words = toy_wordpiece(cfg["vocab_size"], seed=12)
+    rng = np.random.default_rng(13)
     lens = np.clip(np.rint(rng.normal(104, 24, size=n_pass)), 12, 250).astype(np.int64)
     picks = rng.integers(0, len(words), size=int(lens.sum()))
     texts, o = [], 0
@@ -875,8 +883,58 @@ def rerank_leg(args, device_index):
                                   "note": ("32 pairs = 5.4 k tokens: 22 x 4 tiles of 256 x 256 per N = 1024 projection on 256 CUs - a launch- and "
                                            "latency-bound shape, the fraction says how far from the matrix peak such a batch sits") if n_pairs == 32 else
                                           "256 pairs (config/reranker/bge.yaml batch_size): GEMMs that fill the chip"}}
+        if n_pairs == 32:
+            try:
+                out[name]["through_rerank_eval"] = rerank_eval_leg(enc, cfg, n_pairs)
+            except Exception as e:  # noqa: BLE001 — a leg must not take the line down
+                out[name]["through_rerank_eval"] = {"error": f"{type(e).__name__}: {e}"}
         enc.close()
     return out
+
+
+_RERANK_TOK = []
+
+
+def rerank_eval_leg(enc, cfg, yaml_batch):
+    """The rerank STAGE (reference modules/rerank.py:24-48) at the yaml's batch size: `Rerank(init_args=CrossEncoder, batch_size=32).eval`
+    over 64 queries x 50 retrieved passages = 3 200 (query, passage) text pairs (~180 tokens each: a 12-word question + a KILT-like
+    passage, toy WordPiece vocabulary), tokeniser included.  The stage coalesces the yaml batches into launches of >= 256 pairs,
+    tokenises ahead on threads and copies the scores back once (bergen_amd/rerank.py); the same stage with one launch per yaml batch
+    (launch_pairs = 1: the reference's loop shape) is timed beside it and must return the SAME bits."""
+    import bergen_amd
+    if not _RERANK_TOK:
+        _RERANK_TOK.append(toy_wordpiece(cfg["vocab_size"], seed=12))
+    tok, words = _RERANK_TOK[0]
+    rng = np.random.default_rng(23)
+    n_q, per_q = 64, 50
+    data = []
+    for qi in range(n_q):
+        q = " ".join(words[j] for j in rng.integers(0, len(words), size=12))
+        for di in range(per_q):
+            n = int(np.clip(np.rint(rng.normal(165, 40)), 20, 240))
+            data.append({"query": q, "doc": " ".join(words[j] for j in rng.integers(0, len(words), size=n)), "q_id": f"q{qi}", "d_id": f"d{qi}_{di}"})
+    ce = bergen_amd.CrossEncoder("bench/cross-encoder-random", max_len=256, model=enc, tokenizer=tok)
+    res = {"pairs": len(data), "yaml_batch_size": yaml_batch, "backend": ce.backend}
+    outs = {}
+    for label, launch_pairs in (("coalesced_256", 256), ("one_launch_per_yaml_batch", 1)):
+        stage = bergen_amd.Rerank(init_args=ce, batch_size=yaml_batch, launch_pairs=launch_pairs, num_workers=4)
+        stage.eval(data[:per_q * 8])  # warm-up (workspace growth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs[label] = stage.eval(data)
+        dt = time.perf_counter() - t0
+        st = stage.last_eval_stats
+        tf = st["algorithmic_flops"] / dt / 1e12
+        res[label] = {"pairs_per_s": len(data) / dt, "seconds": dt, "launches": st["launches"], "kernel_ms": st["kernel_ms"],
+                      "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                                   "frac_kernels_only": st["algorithmic_flops"] / (st["kernel_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                   "algorithmic_flops": st["algorithmic_flops"]}}
+    a, b = outs["coalesced_256"], outs["one_launch_per_yaml_batch"]
+    res["identical_to_per_batch_loop"] = bool(a["q_id"] == b["q_id"] and a["doc_id"] == b["doc_id"] and
+                                              all(torch.equal(x, y) for x, y in zip(a["score"], b["score"])))
+    res["pairs_per_s"] = res["coalesced_256"]["pairs_per_s"]
+    res["frac"] = res["coalesced_256"]["roofline"]["frac"]
+    return res
 
 
 def certificate_leg(args, local_rank, device):

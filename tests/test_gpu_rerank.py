@@ -107,7 +107,23 @@ def test_rerank_stage_end_to_end_on_the_native_cross_encoder():
     enc = _native(cfg, sd)
     tok = Tok()
     ce = bergen_amd.CrossEncoder("toy/cross-encoder", max_len=48, model=enc, tokenizer=tok)
-    out = bergen_amd.Rerank(init_args=ce, batch_size=16).eval(data)
+    assert ce.native
+    stage = bergen_amd.Rerank(init_args=ce, batch_size=16)
+    out = stage.eval(data)
+    assert stage.last_eval_stats["launches"] == 1 and stage.last_eval_stats["pairs"] == 35
+    # the pipeline's launch size does not change a bit of the result: one launch per yaml batch of 4 (9 launches) vs one of 35 pairs
+    small = bergen_amd.Rerank(init_args=ce, batch_size=4, launch_pairs=1, num_workers=2)
+    out_small = small.eval(data)
+    assert small.last_eval_stats["launches"] == 9
+    assert out_small["q_id"] == out["q_id"] and out_small["doc_id"] == out["doc_id"]
+    for a, b in zip(out_small["score"], out["score"]):
+        assert np.array_equal(a.numpy().view(np.uint32), b.numpy().view(np.uint32))
+    # and it equals the reference-shaped loop (collate_fn padded to max_len, one __call__ and one copy per batch)
+    loop = torch.cat([ce(ce.collate_fn(data[b0:b0 + 16]) and {k: v for k, v in ce.collate_fn(data[b0:b0 + 16]).items() if k not in ("q_id", "d_id")})["score"].cpu()
+                      for b0 in range(0, len(data), 16)]).reshape(-1)
+    _, _, s_loop = stage.sort_by_score_indexes(loop, [e["q_id"] for e in data], [e["d_id"] for e in data])
+    for a, b in zip(s_loop, out["score"]):
+        assert np.array_equal(a.numpy().view(np.uint32), b.numpy().view(np.uint32))
     assert out["q_id"] == [f"q{i}" for i in range(5)]
     b = tok([e["query"] for e in data], [e["doc"] for e in data], max_length=48)
     ref = bert_oracle.cross_encode(sd, cfg, b["input_ids"].numpy(), b["attention_mask"].numpy(),

@@ -82,3 +82,54 @@ def test_cross_encoder_collate_matches_reference_contract():
     out = ce.collate_fn([{"query": "a", "doc": "b", "q_id": "q", "d_id": "d"}])
     assert seen["padding"] == "max_length" and seen["truncation"] == "only_second" and seen["max_length"] == 32
     assert seen["a"] == ["a"] and seen["b"] == ["b"] and out["q_id"] == ["q"] and out["d_id"] == ["d"]
+
+
+@pytest.mark.parametrize("batch_size,launch_pairs,want_launches", [(4, 256, 1), (4, 8, 3), (4, 1, 5), (4, 6, 3), (32, 256, 1)])
+def test_native_pipeline_coalesces_yaml_batches_and_keeps_the_reference_order(batch_size, launch_pairs, want_launches):
+    """Rerank.eval on the native path (modules/rerank.py:24-48 as a pipeline): whole yaml batches coalesced into launches of
+    >= launch_pairs pairs, tokenised ahead on threads, ONE copy of the scores back — pairs stay in dataset order, so the grouping
+    and the per-query stable sort are the reference loop's whatever the launch size."""
+    import bergen_amd
+
+    launches = []
+
+    class FakeEncoder:
+        num_labels = 1
+
+        def classify(self, batch):
+            launches.append(int(batch["x"].shape[0]))
+            return batch["x"].float() * 2.0
+
+        def counters(self):
+            return {"flops": 10.0, "forward_ms": 1.0}
+
+    class FakeCE(bergen_amd.Reranker):
+        native = True
+
+        def __init__(self):
+            super().__init__("org/fake-native")
+            self.model = FakeEncoder()
+
+        def collate_fn(self, examples, query_or_doc=None):
+            raise AssertionError("the native pipeline tokenises with collate_packed")
+
+        def collate_packed(self, examples):
+            return {"x": torch.tensor([[float(len(e["doc"]))] for e in examples]),
+                    "q_id": [e["q_id"] for e in examples], "d_id": [e["d_id"] for e in examples]}
+
+        def __call__(self, kwargs):
+            raise AssertionError("the native pipeline calls classify on the encoder")
+
+    lens = [3, 9, 5, 1, 7, 2, 8, 8, 4, 6, 11, 10, 13, 12, 0, 15, 14]  # 17 pairs: a ragged last launch; a tie (8, 8)
+    data = [{"query": "q", "doc": "x" * n, "q_id": f"q{i % 3}", "d_id": f"d{i}"} for i, n in enumerate(lens)]
+    r = bergen_amd.Rerank(init_args=FakeCE(), batch_size=batch_size, launch_pairs=launch_pairs, num_workers=3)
+    out = r.eval(data)
+    assert len(launches) == want_launches and sum(launches) == len(lens)
+    assert all(n % batch_size == 0 for n in launches[:-1]), "a launch is a whole number of yaml batches"
+    ref = bergen_amd.Rerank.sort_by_score_indexes(r, torch.tensor([2.0 * n for n in lens]), [d["q_id"] for d in data], [d["d_id"] for d in data])
+    assert out["q_id"] == ref[0] and out["doc_id"] == ref[1]
+    assert [s.tolist() for s in out["score"]] == [s.tolist() for s in ref[2]]
+    assert out["doc_id"][0] == ["d15", "d12", "d6", "d9", "d0", "d3"]  # q0 by descending length: 15, 13, 8, 6, 3, 1
+    assert out["doc_id"][1].index("d7") < out["doc_id"][1].index("d4")   # q1: d7 (8) above d4 (7)
+    st = r.last_eval_stats
+    assert st["pairs"] == 17 and st["launches"] == want_launches and st["algorithmic_flops"] == 10.0 * want_launches
