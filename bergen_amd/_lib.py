@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BERGEN_HIP_LIB", os.path.join(_HERE, "lib", "libbergen_hip.so"))
 
-BH_VERSION = 142  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
+BH_VERSION = 143  # the header version the struct layouts below mirror (tests/test_abi.py compares it with include/bergen_hip.h)
 
 BH_OK = 0
 BH_EINVAL = -1
@@ -84,6 +84,7 @@ class bh_encoder_config(_Sized):
         ("position_offset", ctypes.c_int32),
         ("rotary_theta", ctypes.c_float),
         ("ffn_gated", ctypes.c_int32),
+        ("rotary_scale", ctypes.c_float),   # since BH_VERSION 143
     ]
 
 
@@ -139,6 +140,7 @@ SYMBOLS = {
     "bh_op_layernorm": (ctypes.c_int, [_vp, _vp, _i64, _i32, ctypes.c_float, _vp, _vp]),
     "bh_op_rotary": (ctypes.c_int, [_vp, _i64, _i32, _vp, ctypes.c_float, _i32]),
     "bh_op_swiglu": (ctypes.c_int, [_vp, _vp, _i64, _i32]),
+    "bh_op_gated_act": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32]),
     "bh_gemm_permlane_mode": (ctypes.c_int, []),
     "bh_sparse_create": (ctypes.c_int, [ctypes.POINTER(_vp), _i64, _i32]),
     "bh_sparse_upload_csr": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i32]),

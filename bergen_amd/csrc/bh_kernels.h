@@ -154,7 +154,8 @@ struct BhGemmArgs {
     int M, N, K;  // K % 64 == 0; lda, ldb, ldc, ldr % 8 == 0
     int bias_mode;
     int gelu;    // erf-GELU on the result
-    int swiglu;  // persistent kernel, whole 256 x 256 tiles, bias per column: columns are (gate, up) pairs, C is [M][N / 2] = silu(gate) * up
+    int swiglu;  // persistent kernel, whole 256 x 256 tiles, bias per column: columns are (gate, up) pairs, C is [M][N / 2] = silu(gate) * up;
+                 // 2 = the same fold with an erf-GELU gate (16x16x32 kernel only: ask bh_gemm_geglu_fusable() first)
     int swap_b;  // filled by the launcher: direction of v_permlane32_swap on this device
     // segmented-max epilogue (persistent kernel, SPLADE head): C is not stored; relu(C + bias) is max-reduced over the
     // COLUMNS (packed tokens) of each sequence into seg_out[sequence][m] (uint32 view of non-negative floats, zeroed
@@ -294,6 +295,7 @@ struct BhSwigluArgs {
     _Float16* out;       // [n_rows][f]
     long long n_rows;
     int f;               // multiple of 8
+    int act = 0;         // the gate's activation: 0 = SiLU (NomicBert), 1 = erf-GELU (the "new" architecture of gte-*-en-v1.5)
 };
 hipError_t bh_launch_swiglu(const BhSwigluArgs& a, hipStream_t stream);
 
@@ -411,3 +413,7 @@ hipError_t bh_launch_cls_head(const BhClsHeadArgs& a, hipStream_t stream);
 
 hipError_t bh_launch_scatter_f16(unsigned short* dst, const unsigned long long* pos, const unsigned short* val, int n,
                                  hipStream_t stream);
+
+// whether bh_launch_gemm_f16 can fold a GELU-gated feed-forward in its epilogue under the current process options (BhGemmArgs::swiglu = 2
+// exists on the 16x16x32 kernel's through-LDS store route only); false = the caller runs the plain GEMM + bh_launch_swiglu (act = 1)
+bool bh_gemm_geglu_fusable();

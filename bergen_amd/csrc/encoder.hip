@@ -372,9 +372,10 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
     if (c.position_offset < 0 || c.position_offset >= c.max_position) return bh_fail(BH_EINVAL, "position_offset %d", c.position_offset);
     if (c.intermediate % 64 != 0) return bh_fail(BH_EUNSUPPORTED, "intermediate=%d must be a multiple of 64", c.intermediate);
     if (c.ffn_gated != 0 && c.ffn_gated != 1) return bh_fail(BH_EINVAL, "ffn_gated %d (0 or 1)", c.ffn_gated);
-    if (c.activation != (c.ffn_gated ? 1 : 0))
-        return bh_fail(BH_EUNSUPPORTED, "activation %d with ffn_gated %d unsupported (0 = erf-GELU with a plain feed-forward, 1 = SiLU with a gated one)",
+    if (!(c.activation == 0 || (c.activation == 1 && c.ffn_gated == 1)))
+        return bh_fail(BH_EUNSUPPORTED, "activation %d with ffn_gated %d unsupported (0 = erf-GELU, plain or gated feed-forward; 1 = SiLU with a gated one)",
                        c.activation, c.ffn_gated);
+    if (!(c.rotary_scale >= 0.f) || c.rotary_scale > 1.f) return bh_fail(BH_EINVAL, "rotary_scale %g (0 = off, else in (0, 1])", (double)c.rotary_scale);
     if (!(c.rotary_theta >= 0.f) || (c.rotary_theta > 0.f && c.rotary_theta < 1.f)) return bh_fail(BH_EINVAL, "rotary_theta %g (0 = off, else >= 1)", (double)c.rotary_theta);
     if (c.rotary_theta > 0.f && hd != 64) return bh_fail(BH_EUNSUPPORTED, "rotary positions need 64-dim heads (head_dim %d)", hd);
     int dev = 0;
@@ -394,7 +395,7 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
         std::vector<float> tab((size_t)c.max_position * 64);
         for (int p = 0; p < c.max_position; ++p)
             for (int j = 0; j < 32; ++j) {
-                const double ang = (double)p * pow((double)c.rotary_theta, -2.0 * j / 64.0);
+                const double ang = (double)p * pow((double)c.rotary_theta, -2.0 * j / 64.0) * (c.rotary_scale > 0.f ? (double)c.rotary_scale : 1.0);
                 tab[(size_t)p * 64 + j] = (float)cos(ang);
                 tab[(size_t)p * 64 + 32 + j] = (float)sin(ang);
             }
@@ -805,7 +806,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
     // the [rows][2 dff] intermediate never exists; else the plain GEMM into GU + the fold kernel (option "ffn_fused" 0 forces it).
     auto ffn_fused = [&](long long rows) {
         return e->ffn_fused && rows % 256 == 0 && (2 * dff) % 256 == 0 && e->gemm_variant == 0 &&
-               (rows / 256) * (2 * dff / 256) * 2 > (long long)e->n_cu;
+               (rows / 256) * (2 * dff / 256) * 2 > (long long)e->n_cu && (c.activation == 1 || bh_gemm_geglu_fusable());  // (GELU gate: 16x16x32 kernel only)
     };
     if (c.ffn_gated) {
         bool need_gu = false;
@@ -1155,7 +1156,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
                 g.M = rows;
                 g.N = 2 * dff;
                 g.K = d;
-                g.swiglu = 1;
+                g.swiglu = c.activation == 0 ? 2 : 1;  // gate activation: erf-GELU (gte) or SiLU (NomicBert)
                 BH_HIP_TRY(bh_launch_gemm_f16(g, 0, ls));
             } else {
                 _Float16* GUp = e->GU.p + r0 * 2 * dff;
@@ -1165,6 +1166,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
                 sa.out = Hp;
                 sa.n_rows = rows;
                 sa.f = dff;
+                sa.act = c.activation == 0 ? 1 : 0;
                 BH_HIP_TRY(bh_launch_swiglu(sa, ls));
             }
         } else if ((rc = gemm(e, Xp, d, L.w1, d, Hp, dff, rows, dff, d, L.b1, 1, nullptr, 0, 1, 0, ls))) return rc;
@@ -1314,7 +1316,7 @@ int bh_op_gemm_f16(const void* A, int64_t lda, const void* B, int64_t ldb, void*
     g.N = N;
     g.K = K;
     g.gelu = gelu == 1 ? 1 : 0;
-    g.swiglu = gelu == 2 ? 1 : 0;  // (the gated fold of the persistent kernel: see the header)
+    g.swiglu = gelu == 2 ? 1 : gelu == 3 ? 2 : 0;  // (the gated fold of the persistent kernel, SiLU / erf-GELU gate: see the header)
     if (repeats < 1) repeats = 1;
     hipEvent_t e0, e1;
     BH_HIP_TRY(hipEventCreate(&e0));
@@ -1405,6 +1407,21 @@ int bh_op_swiglu(const void* gu, void* out, int64_t n_rows, int32_t f) {
     sa.out = static_cast<_Float16*>(out);
     sa.n_rows = n_rows;
     sa.f = f;
+    BH_HIP_TRY(bh_launch_swiglu(sa, nullptr));
+    BH_HIP_TRY(hipStreamSynchronize(nullptr));
+    return BH_OK;
+}
+
+int bh_op_gated_act(const void* gu, void* out, int64_t n_rows, int32_t f, int32_t act) {
+    if (!gu || !out) return bh_fail(BH_EINVAL, "null buffer");
+    if (n_rows < 0 || f <= 0 || (f & 7)) return bh_fail(BH_EUNSUPPORTED, "f=%d (a positive multiple of 8)", f);
+    if (act != 0 && act != 1) return bh_fail(BH_EINVAL, "act %d (0 = SiLU, 1 = erf-GELU)", act);
+    BhSwigluArgs sa{};
+    sa.gu = static_cast<const _Float16*>(gu);
+    sa.out = static_cast<_Float16*>(out);
+    sa.n_rows = n_rows;
+    sa.f = f;
+    sa.act = act;
     BH_HIP_TRY(bh_launch_swiglu(sa, nullptr));
     BH_HIP_TRY(hipStreamSynchronize(nullptr));
     return BH_OK;

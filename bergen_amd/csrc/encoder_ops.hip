@@ -16,6 +16,7 @@
 //                        (gate, up) columns of ONE GEMM, fp32 math — the fallback of the GEMM's own fused fold (BH_EPI_SWIGLU)
 #include "bh_device.h"
 #include "bh_kernels.h"
+#include "gemm_f16_kernel.h"  // bh_gemm::gelu_erf (the GEMM epilogues' GELU: the gated fold below must give the same bits)
 
 namespace {
 
@@ -381,11 +382,19 @@ __global__ void __launch_bounds__(256) bh_swiglu_kernel(BhSwigluArgs a) {
     const half8 lo = *reinterpret_cast<const half8*>(g);
     const half8 hi = *reinterpret_cast<const half8*>(g + 8);
     half8 o;
+    if (a.act == 1) {  // erf-GELU gate (gte-*-en-v1.5): the GEMM epilogue's polynomial, expression for expression (same bits)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float g0 = (float)lo[2 * e], g1 = (float)hi[2 * e];
-        o[e] = (_Float16)(g0 / (1.0f + __builtin_amdgcn_exp2f(-g0 * 1.4426950408889634f)) * (float)lo[2 * e + 1]);
-        o[4 + e] = (_Float16)(g1 / (1.0f + __builtin_amdgcn_exp2f(-g1 * 1.4426950408889634f)) * (float)hi[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) {
+            o[e] = (_Float16)(bh_gemm::gelu_erf((float)lo[2 * e]) * (float)lo[2 * e + 1]);
+            o[4 + e] = (_Float16)(bh_gemm::gelu_erf((float)hi[2 * e]) * (float)hi[2 * e + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g0 = (float)lo[2 * e], g1 = (float)hi[2 * e];
+            o[e] = (_Float16)(g0 / (1.0f + __builtin_amdgcn_exp2f(-g0 * 1.4426950408889634f)) * (float)lo[2 * e + 1]);
+            o[4 + e] = (_Float16)(g1 / (1.0f + __builtin_amdgcn_exp2f(-g1 * 1.4426950408889634f)) * (float)hi[2 * e + 1]);
+        }
     }
     *reinterpret_cast<half8*>(a.out + (size_t)row * (size_t)a.f + (size_t)c * 8) = o;
 }

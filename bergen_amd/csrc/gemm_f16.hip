@@ -146,6 +146,8 @@ static int gemm_cu_count() {
 // for everything; 7 = persistent 256x256 kernel (gemm_f16_persist.h; burst stores); 8 = 7 with stores deferred into
 // the next tile's main loop, 9 = 7 with non-temporal stores (both valid results; ablations); 11..28 = bench-only
 // ablations (results invalid); 33 = 7 with deferred stores and alternating loader teams; 10 = 7 with the last partial round of tiles re-cut into 128x128 tiles (experiment, measured neutral).
+bool bh_gemm_geglu_fusable() { return g_mfma16 != 0 && g_mfma16 < 16 && g_full_line_stores >= 2; }
+
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t stream) {
     BhGemmArgs a = a_in;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -186,8 +188,9 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
         if (g_mfma16 && g_mfma16 < 16 && g_full_line_stores >= 2) {  // (the 16x16x32 kernel has the through-LDS route only)
             BhGemmArgs t = a;
             t.tail_split = g_tail_split;
-            return bh_gemm_p16(t, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, true, g_mfma16, stream);
+            return bh_gemm_p16(t, BH_EPI_BIAS_COL | BH_EPI_SWIGLU | (a.swiglu == 2 ? BH_EPI_GELU : 0), true, g_mfma16, stream);
         }
+        if (a.swiglu == 2) return hipErrorNotSupported;  // (the GELU gate exists on the 16x16x32 kernel only: bh_gemm_geglu_fusable())
         return bh_gemm_persist(a, BH_EPI_BIAS_COL | BH_EPI_SWIGLU, g_full_line_stores >= 2 ? 35 : 3, stream);
     }
     if (a.ln_stats || a.stats_out) {

@@ -34,7 +34,7 @@ template <int EPI, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(EPI == 0 || EPI == BH_EPI_BIAS_COL || EPI == (BH_EPI_BIAS_COL | BH_EPI_GELU) || EPI == BH_EPI_BIAS_ROW ||
-                      EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU),
+                      EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU) || EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU | BH_EPI_GELU),
                   "epilogues of this kernel");
     constexpr int BK = 64, WN = 4, R = 2;
     constexpr int NW = 8;
@@ -253,7 +253,10 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
                         for (int e = 0; e < 2; ++e) {
                             const float g = acc[tb][fb][2 * e] + 0.f + (float)bias4[fb][2 * e];
                             const float up = acc[tb][fb][2 * e + 1] + 0.f + (float)bias4[fb][2 * e + 1];
-                            o[e] = (_Float16)(g / (1.0f + __builtin_amdgcn_exp2f(-g * 1.4426950408889634f)) * up);
+                            if constexpr ((EPI & BH_EPI_GELU) != 0)  // GELU gate (gte-*-en-v1.5): bh_swiglu_kernel's act = 1, same bits
+                                o[e] = (_Float16)(bh_gemm::gelu_erf(g) * up);
+                            else
+                                o[e] = (_Float16)(g / (1.0f + __builtin_amdgcn_exp2f(-g * 1.4426950408889634f)) * up);
                         }
                         acc[tb][fb] = floatx4{0.f, 0.f, 0.f, 0.f};
                         *reinterpret_cast<half2v*>(stg + tr * 64 + ((fb ^ ((tr >> 1) & 3)) << 4) + lg * 4) = o;

@@ -653,7 +653,9 @@ static int search_device_lists(bh_index* ix, const void* q_dev, int32_t q_dtype,
     // partner workgroups of the two passes on one XCD walking the same tiles, so that a corpus line leaves HBM once per 512
     // queries.  A pass of a paired launch has grid / 2 lists per query, stored behind each other: such passes are merged in
     // groups of their own; an odd main pass is left over and runs unpaired.
-    const bool pair256 = grouped && use256 && opt.pair256 != 0 && opt.ablate == 0 && grid == 256 && n_main >= 2 &&
+    // (bench-only: the ablation ladder of the paired headline instantiation, ablate 1 / 5 / 7 / 9 at d = 768 and lists of 64)
+    const bool pair_ablate_ok = opt.ablate == 0 || ((opt.ablate == 1 || opt.ablate == 5 || opt.ablate == 7 || opt.ablate == 9) && dp == 768 && kp == 64);
+    const bool pair256 = grouped && use256 && opt.pair256 != 0 && pair_ablate_ok && grid == 256 && n_main >= 2 &&
                          bh_scan256_pair_supports(dp, kp) && (dp != 1024 || opt.ring_variant == 0 || opt.ring_variant == 5);
     const int n_paired = pair256 ? (n_main & ~1) : 0;
     struct Group {

@@ -3,10 +3,14 @@
 // (one list per GPU / per rank after the RCCL all-gather) and replaces the reference's host
 // merge, modules/retrieve.py:169-177 (torch.cat + torch.topk + torch.gather on CPU).
 //
-// One workgroup per query.  M = n_lists*k entries (<= 4096) are staged in LDS and ranked by
-// counting: rank(i) = #{j : entry j precedes entry i}; entries with rank < k are scattered to
-// their output slot.  O(M^2) compares per query, but M is a few hundred to ~1600 here
-// (8 shards x k<=200) and the whole step is latency-bound next to the scan.
+// One workgroup per query.  M = n_lists*k entries (<= 4096) are staged in LDS and RANKED: rank(i) = #{j : entry j precedes
+// entry i}; entries with rank < k are scattered to their output slot.
+//   * The lists a search produces are SORTED in the canonical order (valid entries first, padding — id < 0 — at the tail): the
+//     entries of list l that precede entry (l, j) are then exactly its first j, and those of another list l' a PREFIX of it, found
+//     by binary search: (n_lists - 1) * log2(k) steps per entry.  (Round 6: the one-GPU proxy of the whole 8-GPU search showed the
+//     all-pairs count below taking 2.45 ms for 8 lists of 200 on rank 0's critical path — 28 % of the step it follows.)
+//   * The entry point accepts ANY lists (the reference's host merge, torch.cat + torch.topk, does): every workgroup first checks
+//     that its query's lists are sorted, and counts all pairs — O(M^2), M a few hundred to ~1600 — when one is not.
 #include "bh_device.h"
 #include "bh_kernels.h"
 
@@ -31,16 +35,50 @@ __global__ void __launch_bounds__(256) bh_merge_lists_kernel(const float* __rest
         out_ids[(size_t)q * k + i] = -1ll;
     }
     __syncthreads();
+    // entry a precedes entry b (canonical order: score descending, id ascending, then position; padding never precedes)
+    auto precedes = [&](int a, float sc, long long id, int b) {
+        const long long ida = s_id[a];
+        const float sca = s_sc[a];
+        return (ida >= 0) && ((sca > sc) || (sca == sc && (ida < id || (ida == id && a < b))));
+    };
+    // sorted?  (every entry against its successor in the same list: a valid entry must precede the next valid one, padding must
+    // not be followed by a valid entry)
+    __shared__ int s_unsorted;
+    if (threadIdx.x == 0) s_unsorted = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const int j = i % k;
+        if (j + 1 < k) {
+            const long long id1 = s_id[i + 1];
+            if (id1 >= 0 && !precedes(i, s_sc[i + 1], id1, i + 1)) bad = true;
+        }
+    }
+    if (bad) s_unsorted = 1;
+    __syncthreads();
+    const bool sorted = s_unsorted == 0;
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
         const long long id = s_id[i];
         if (id < 0) continue;
         const float sc = s_sc[i];
         int rank = 0;
-        for (int j = 0; j < M; ++j) {
-            const long long idj = s_id[j];
-            const float scj = s_sc[j];
-            const bool before = (idj >= 0) && ((scj > sc) || (scj == sc && (idj < id || (idj == id && j < i))));
-            rank += before ? 1 : 0;
+        if (sorted) {
+            const int l = i / k;
+            rank = i - l * k;  // its own list's entries before it
+            for (int lo = 0; lo < n_lists; ++lo) {
+                if (lo == l) continue;
+                int a = 0, b = k;  // the prefix of list lo that precedes entry i: first position whose entry does not
+                while (a < b) {
+                    const int mid = (a + b) >> 1;
+                    if (precedes(lo * k + mid, sc, id, i))
+                        a = mid + 1;
+                    else
+                        b = mid;
+                }
+                rank += a;
+            }
+        } else {
+            for (int j = 0; j < M; ++j) rank += precedes(j, sc, id, i) ? 1 : 0;
         }
         if (rank < k) {
             out_scores[(size_t)q * k + rank] = sc;

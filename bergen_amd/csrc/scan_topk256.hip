@@ -962,9 +962,12 @@ static hipError_t launch256_one(const BhScanArgs& a, int grid, hipStream_t strea
     constexpr size_t smem = ring + 16 <= 160 * 1024 ? ring + 16 : ring;  // + the chunk claim word (dynamic tile distribution)
     constexpr bool kProduction = (ABL == 0 || ABL == 128) && (LM == 1 || LM == 0) && SCHED == 1 && NBUF == PD;
     // the bench-only instantiations exist with the non-temporal stream policy only (compile time)
-    const bool nt = a.nontemporal != 0 || !kProduction;
+    // (... except the ablations of the PAIRED launch, which exist with the cached policy only: partner workgroups share the
+    // stream through L2, which a non-temporal first reader would defeat — the production paired launch runs cached too)
+    constexpr bool kPairedAblation = (ABL & 128) != 0 && ABL != 128;
+    const bool nt = !kPairedAblation && (a.nontemporal != 0 || !kProduction);
     static bool attr_done[2] = {false, false};
-    void (*kern)(BhScanArgs) = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, true, ABL, LM, SCHED, NBUF, NB>;
+    void (*kern)(BhScanArgs) = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, !kPairedAblation, ABL, LM, SCHED, NBUF, NB>;
     if constexpr (kProduction) {
         if (!nt) kern = bh_scan_topk256_kernel<NK32, KP, LS, R, PD, false, ABL, LM, SCHED, NBUF, NB>;
     }
@@ -1021,7 +1024,18 @@ static hipError_t launch256_paired_kp(const BhScanArgs& a, int kp, int grid, hip
     return hipErrorInvalidValue;
 }
 hipError_t bh_launch_scan256_paired(const BhScanArgs& a, int dim_padded, int kp, int grid, hipStream_t stream) {
-    if (!bh_scan256_pair_supports(dim_padded, kp) || a.qsplit != 2 || grid != 256 || !a.progress || a.ablate != 0) return hipErrorInvalidValue;
+    if (!bh_scan256_pair_supports(dim_padded, kp) || a.qsplit != 2 || grid != 256 || !a.progress) return hipErrorInvalidValue;
+    if (a.ablate != 0) {
+        // bench-only (profiles/ablate_paired.py; results invalid): the in-kernel ablation ladder of the PAIRED headline instantiation
+        if (dim_padded != 768 || kp != 64) return hipErrorInvalidValue;
+        switch (a.ablate) {
+            case 1: return launch256_one<24, 64, 12, 3, 4, 128 | 1, 0, 1, 4, 2>(a, grid, stream);  // no filter / candidate path
+            case 5: return launch256_one<24, 64, 12, 3, 4, 128 | 5, 0, 1, 4, 2>(a, grid, stream);  // + no MFMA: stream + fragment reads
+            case 7: return launch256_one<24, 64, 12, 3, 4, 128 | 7, 0, 1, 4, 2>(a, grid, stream);  // + no fragment reads: stream + rendezvous (+ pacing)
+            case 9: return launch256_one<24, 64, 12, 3, 4, 128 | 9, 0, 1, 4, 2>(a, grid, stream);  // no filter, no refill: MFMA + fragment reads + rendezvous
+        }
+        return hipErrorInvalidValue;
+    }
     if (dim_padded == 1024) return launch256_paired_kp<32, 8, 4, 4, 1, 1>(a, kp, grid, stream);
     return launch256_paired_kp<24, 12, 3, 4, 2, 0>(a, kp, grid, stream);
 }

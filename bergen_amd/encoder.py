@@ -47,7 +47,7 @@ def pool_mode_or_none(pooler):
         return None
 
 
-SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert", "deberta-v2", "nomic_bert")
+SUPPORTED_MODEL_TYPES = ("bert", "distilbert", "roberta", "xlm-roberta", "camembert", "deberta-v2", "nomic_bert", "new")
 
 # NomicBert names (transformers modeling_nomic_bert.py: layers.<l>.self_attn / mlp / post_*_layernorm) -> BERT names; the gate and
 # up projections of the gated feed-forward become ONE tensor (canonical_state_dict)
@@ -209,6 +209,39 @@ def canonical_config(config):
                      num_hidden_layers=get("num_hidden_layers"), intermediate_size=get("intermediate_size"),
                      hidden_act="silu", type_vocab_size=get("type_vocab_size", 2), layer_norm_eps=get("layer_norm_eps", 1e-12),
                      position_offset=0, rotary_theta=theta, ffn_gated=1)
+    elif mt == "new":
+        # Alibaba-NLP/gte-base-en-v1.5, gte-large-en-v1.5 (config/retriever/gte-*-en-v1.5.yaml): the REMOTE architecture "new"
+        # (hub repository Alibaba-NLP/new-impl) — BERT's post-LN block with rotary positions (NTK-scaled), a packed biased q | k | v
+        # projection and a GELU-gated feed-forward.  No copy of that modelling file exists offline: the mapping follows its published
+        # description (oracle/new_oracle.py: parity unpinned) and every conversion is PROBED against the caller's own HF module
+        # (`self_check`, BertEncoder.from_hf) — a mismatch keeps the run on that module, loudly.
+        why = None
+        if str(get("position_embedding_type", "rope")) != "rope":
+            why = f"position_embedding_type {get('position_embedding_type')!r} (rope only)"
+        elif str(get("layer_norm_type", "layer_norm")) != "layer_norm":
+            why = f"layer_norm_type {get('layer_norm_type')!r}"
+        elif get("logn_attention_scale", False):
+            why = "logn_attention_scale is set"
+        elif str(get("hidden_act", "gelu")) != "gelu":
+            why = f"hidden_act {get('hidden_act')!r} (erf-GELU gate only)"
+        scaling = get("rope_scaling", None)
+        sget = (scaling.get if isinstance(scaling, dict) else (lambda k, dflt=None: getattr(scaling, k, dflt))) if scaling else None
+        theta, scale = float(get("rope_theta", 10000.0) or 10000.0), 1.0
+        hd_new = int(get("hidden_size")) // max(1, int(get("num_attention_heads")))
+        if sget is not None and why is None:
+            if str(sget("type", "")) != "ntk" or sget("mixed_b", None) is not None:
+                why = f"rope_scaling {scaling!r} (type 'ntk' without mixed_b only)"
+            else:
+                # NTKScalingRotaryEmbedding builds its cos / sin cache once for max_position_embeddings * factor positions, i.e.
+                # always in the scaled regime: base' = base * factor, inv_freq / factor^(2 / dim)
+                factor = float(sget("factor", 1.0))
+                theta, scale = theta * factor, factor ** (-2.0 / hd_new)
+        if why:
+            raise ValueError(f"'new' (gte) configuration outside the HIP forward pass: {why}")
+        c = dict(hidden_size=get("hidden_size"), num_attention_heads=get("num_attention_heads"), num_hidden_layers=get("num_hidden_layers"),
+                 intermediate_size=get("intermediate_size"), hidden_act="gelu", type_vocab_size=int(get("type_vocab_size", 0) or 0) or 1,
+                 layer_norm_eps=get("layer_norm_eps", 1e-12), position_offset=0, rotary_theta=theta, rotary_scale=scale, ffn_gated=1,
+                 self_check=True)
     elif mt == "distilbert":
         c = dict(hidden_size=get("dim"), num_attention_heads=get("n_heads"), num_hidden_layers=get("n_layers"),
                  intermediate_size=get("hidden_dim"), hidden_act=get("activation", "gelu"), type_vocab_size=1,
@@ -227,13 +260,13 @@ def canonical_config(config):
             raise ValueError(f"position_embedding_type {pet!r}")
     c.update(vocab_size=get("vocab_size"), max_position_embeddings=c.pop("max_position_embeddings_override", None) or get("max_position_embeddings"),
              model_type=mt)
-    if c["hidden_act"] != ("silu" if c.get("ffn_gated") else "gelu"):
-        raise ValueError(f"hidden_act {c['hidden_act']!r} (erf-GELU only)")
+    if not (c["hidden_act"] == "gelu" or (c["hidden_act"] == "silu" and c.get("ffn_gated"))):
+        raise ValueError(f"hidden_act {c['hidden_act']!r} (erf-GELU, or SiLU as the gate of a gated feed-forward)")
     d, nh = int(c["hidden_size"]), int(c["num_attention_heads"])
     hd = d // max(1, nh)
     if d != nh * hd or hd % 8 != 0 or not 8 <= hd <= 64:
         raise ValueError(f"head dim {d / max(1, nh):g} (multiples of 8 up to 64)")
-    if mt in ("deberta-v2", "nomic_bert") and hd != 64:
+    if mt in ("deberta-v2", "nomic_bert", "new") and hd != 64:
         raise ValueError(f"{mt} with head dim {hd} (64 only)")
     if d % 64 != 0 or d > 2048 or nh * 64 > 2048:
         raise ValueError(f"hidden_size {d} with {nh} heads (multiple of 64, heads * 64 <= 2048)")
@@ -280,6 +313,24 @@ def canonical_state_dict(cfg, state_dict):
                     break
             if key.startswith(("cls.", "classifier.", "pooler.")):
                 continue  # task heads of NomicBertFor*: the retriever reads the last hidden state (dense.py:40-44)
+        elif mt == "new":
+            if key.startswith("new."):
+                key = key[len("new."):]
+            if key.endswith("inv_freq") or key.startswith(("pooler.", "lm_head.", "classifier.")):
+                continue  # (rotary frequencies are rebuilt in the library; the retriever reads the last hidden state, dense.py:40-44)
+            for a, b in ((".attention.o_proj.", ".attention.output.dense."), (".attn_ln.", ".attention.output.LayerNorm."),
+                         (".mlp.down_proj.", ".output.dense."), (".mlp_ln.", ".output.LayerNorm."),
+                         (".attention.q_proj.", ".attention.self.query."), (".attention.k_proj.", ".attention.self.key."),
+                         (".attention.v_proj.", ".attention.self.value.")):
+                if a in key:
+                    key = key.replace(a, b)
+                    break
+            if ".attention.qkv_proj." in key:  # pack_qkv: rows (or bias entries) [q | k | v]
+                if t.shape[0] % 3:
+                    raise ValueError(f"{key}: {tuple(t.shape)} is not q | k | v stacked along dim 0")
+                for part, piece in zip(("query", "key", "value"), torch.chunk(t, 3, dim=0)):
+                    out[key.replace(".attention.qkv_proj.", f".attention.self.{part}.")] = piece
+                continue
         elif mt == "distilbert":
             if key.startswith("transformer.layer."):
                 key = "encoder.layer." + key[len("transformer.layer."):]
@@ -339,6 +390,26 @@ def canonical_state_dict(cfg, state_dict):
             for name, n in (("attention.self.query", d), ("attention.self.key", d), ("attention.self.value", d),
                             ("attention.output.dense", d), ("intermediate.dense", 2 * f), ("output.dense", d)):
                 out.setdefault(pre + name + ".bias", torch.zeros(n, dtype=torch.float16))
+    if mt == "new":
+        # rotary positions: a zero position table; up_gate_proj's rows are [up | gate] (NewGatedMLP splits the output in that order):
+        # interleaved (gate j, up j) like NomicBert's; it has no bias
+        nl, f = int(cfg["num_hidden_layers"]), int(cfg["intermediate_size"])
+        out["embeddings.position_embeddings.weight"] = torch.zeros(int(cfg["max_position_embeddings"]), d, dtype=torch.float16)
+        for l in range(nl):
+            pre = f"encoder.layer.{l}."
+            ug = out.pop(pre + "mlp.up_gate_proj.weight", None)
+            if ug is None or ug.shape[0] != 2 * f:
+                raise ValueError(f"'new' state dict lacks encoder.layer.{l}.mlp.up_gate_proj.weight of {2 * f} rows")
+            up, gate = ug[:f].detach().float(), ug[f:].detach().float()
+            out[pre + "intermediate.dense.weight"] = torch.stack([gate, up], dim=1).reshape(2 * f, d)
+            ugb = out.pop(pre + "mlp.up_gate_proj.bias", None)
+            if ugb is not None:
+                out[pre + "intermediate.dense.bias"] = torch.stack([ugb[f:].detach().float(), ugb[:f].detach().float()], dim=1).reshape(2 * f)
+            else:
+                out[pre + "intermediate.dense.bias"] = torch.zeros(2 * f, dtype=torch.float16)
+            for name, n in (("attention.self.query", d), ("attention.self.key", d), ("attention.self.value", d),
+                            ("attention.output.dense", d), ("output.dense", d)):
+                out.setdefault(pre + name + ".bias", torch.zeros(n, dtype=torch.float16))
     if mt == "deberta-v2":  # word embeddings only (position_biased_input = False): a zero position table
         out["embeddings.position_embeddings.weight"] = torch.zeros(int(cfg["max_position_embeddings"]), d, dtype=torch.float16)
         if "encoder.rel_embeddings.weight" in out:  # the attention uses the first 2 * position_buckets rows
@@ -387,9 +458,11 @@ class BertEncoder:
             n_layers=int(get("num_hidden_layers")), hidden=self.hidden_size, n_heads=int(get("num_attention_heads")),
             intermediate=int(get("intermediate_size")), vocab_size=int(get("vocab_size")),
             max_position=int(get("max_position_embeddings")), type_vocab_size=int(get("type_vocab_size")),
-            activation=1 if get("ffn_gated") else 0, ln_eps=float(get("layer_norm_eps", 1e-12)), head_dim=int(get("head_dim")),
-            position_offset=int(get("position_offset", 0)), rotary_theta=float(get("rotary_theta", 0.0) or 0.0),
-            ffn_gated=int(get("ffn_gated", 0) or 0))
+            activation=1 if (get("ffn_gated") and get("hidden_act") == "silu") else 0, ln_eps=float(get("layer_norm_eps", 1e-12)),
+            head_dim=int(get("head_dim")), position_offset=int(get("position_offset", 0)),
+            rotary_theta=float(get("rotary_theta", 0.0) or 0.0), ffn_gated=int(get("ffn_gated", 0) or 0),
+            rotary_scale=float(get("rotary_scale", 0.0) or 0.0))
+        self.needs_self_check = bool(get("self_check", False))
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))
         self._h = h
@@ -453,8 +526,52 @@ class BertEncoder:
 
     @classmethod
     def from_hf(cls, model, device=0):
-        """Build from an instantiated HF BertModel (weights are copied into HBM once)."""
-        return cls(model.config, model.state_dict(), device=device)
+        """Build from an instantiated HF BertModel (weights are copied into HBM once).  An architecture whose mapping could not be
+        pinned offline (`needs_self_check`: the remote "new" class of gte-*-en-v1.5) is PROBED against `model` itself before it is
+        handed out: ValueError when the two disagree (the caller keeps the HF module)."""
+        enc = cls(model.config, model.state_dict(), device=device)
+        if enc.needs_self_check:
+            try:
+                enc.self_check(model)
+            except Exception:
+                enc.close()
+                raise
+        return enc
+
+    @torch.no_grad()
+    def self_check(self, model, batch=4, seq_len=24, seed=1234):
+        """A probe batch through the HF module `model` (wherever it lives, in its own dtype) and through this encoder: the last hidden
+        states of the attended tokens must agree — cosine >= 0.995 per sequence and max |diff| <= 5e-2 x max |reference| (two fp16
+        forward passes of the same weights).  Raises ValueError with the figures otherwise.  Used where the name / arithmetic mapping
+        of an architecture follows a description instead of a pinned source (oracle/new_oracle.py)."""
+        g = torch.Generator().manual_seed(seed)
+        T = int(min(seq_len, int(getattr(self.config, "max_position_embeddings", seq_len) if not isinstance(self.config, dict)
+                                 else self.config.get("max_position_embeddings", seq_len))))
+        ids = torch.randint(5, max(6, self.vocab_size - 1), (batch, T), generator=g)
+        lens = torch.tensor([T] + [max(2, T - 5 * (i + 1)) for i in range(batch - 1)])
+        mask = (torch.arange(T)[None, :] < lens[:, None]).long()
+        ids = ids * mask
+        try:
+            p = next(model.parameters())
+            dev, was_training = p.device, model.training
+        except StopIteration:
+            dev, was_training = torch.device("cpu"), False
+        model.eval()
+        want = model(input_ids=ids.to(dev), attention_mask=mask.to(dev))[0].float().cpu()
+        if was_training:
+            model.train()
+        got = self(input_ids=ids, attention_mask=mask)[0].float().cpu()
+        worst_cos, worst_abs = 1.0, 0.0
+        for b in range(batch):
+            w, h = want[b, :int(lens[b])].reshape(-1), got[b, :int(lens[b])].reshape(-1)
+            cos = float(torch.dot(w, h) / (w.norm() * h.norm() + 1e-30))
+            worst_cos = min(worst_cos, cos)
+            worst_abs = max(worst_abs, float((w - h).abs().max() / (w.abs().max() + 1e-30)))
+        self.self_check_result = {"min_cosine": worst_cos, "max_rel_abs_diff": worst_abs}
+        if not (worst_cos >= 0.995 and worst_abs <= 5e-2):
+            raise ValueError(f"self-check against the HF module failed: min cosine {worst_cos:.5f}, max |diff| / max |ref| {worst_abs:.4f} "
+                             f"(the HIP mapping of this architecture does not reproduce the module's forward pass)")
+        return self.self_check_result
 
     @staticmethod
     def unsupported_reason(model):
@@ -568,8 +685,8 @@ def gemm_f16(a, w, bias=None, bias_mode=1, residual=None, gelu=False, variant=0,
     assert a.is_cuda and w.is_cuda and a.dtype == torch.float16 and w.dtype == torch.float16
     M, K = a.shape
     N = w.shape[0]
-    fold = gelu == "swiglu"
-    gelu = 2 if fold else int(bool(gelu))
+    fold = gelu in ("swiglu", "geglu")  # gated fold, SiLU or erf-GELU gate
+    gelu = (2 if gelu == "swiglu" else 3) if fold else int(bool(gelu))
     if out is None:
         out = torch.empty((M, N // 2 if fold else N), dtype=torch.float16, device=a.device)
     ms = ctypes.c_float(0)
@@ -617,6 +734,15 @@ def swiglu(gu):
     out = torch.empty((gu.shape[0], gu.shape[1] // 2), dtype=torch.float16, device=gu.device)
     torch.cuda.synchronize(gu.device)
     _lib.check(_lib.lib().bh_op_swiglu(_p(gu), _p(out), gu.shape[0], gu.shape[1] // 2))
+    return out
+
+
+def gated_act(gu, act="silu"):
+    """act(gate) * up over gu [rows, 2 f] fp16 ((gate, up) column pairs) -> [rows, f] fp16; act "silu" (= swiglu) or "gelu" (erf)."""
+    assert gu.is_cuda and gu.dtype == torch.float16 and gu.is_contiguous() and gu.shape[1] % 16 == 0
+    out = torch.empty((gu.shape[0], gu.shape[1] // 2), dtype=torch.float16, device=gu.device)
+    torch.cuda.synchronize(gu.device)
+    _lib.check(_lib.lib().bh_op_gated_act(_p(gu), _p(out), gu.shape[0], gu.shape[1] // 2, {"silu": 0, "gelu": 1}[act]))
     return out
 
 

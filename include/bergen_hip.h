@@ -37,8 +37,10 @@ extern "C" {
  * a shorter struct reads as plain BERT) + bh_op_rotary / bh_op_swiglu; a caller built against 140 keeps working memory-wise
  * (struct_size) but must be rebuilt to pass the version check; 142 = 0.1.4.2 (round 5): bh_encoder_counters grew ln_fused at its END
  * (whether the last forward pass ran with the LayerNorms fused into the GEMM epilogues: encoder option "ln_fused") and bh_counters grew
- * balanced_scan_ms / balanced_queries at its END (option balance_tail). */
-#define BH_VERSION 142
+ * balanced_scan_ms / balanced_queries at its END (option balance_tail); 143 = 0.1.4.3 (round 6): bh_encoder_config grew rotary_scale at its
+ * END and accepts activation 0 with ffn_gated 1 (the GELU-gated feed-forward + NTK-scaled rotary positions of Alibaba-NLP/gte-*-en-v1.5,
+ * config/retriever/gte-base-en-v1.5.yaml) + bh_op_gated_act (bh_op_swiglu with the gate's activation as an argument). */
+#define BH_VERSION 143
 
 typedef enum bh_status {
     BH_OK = 0,
@@ -206,7 +208,7 @@ typedef struct bh_encoder_config {
     int32_t vocab_size;
     int32_t max_position;    /* max_position_embeddings */
     int32_t type_vocab_size;
-    int32_t activation;      /* 0 = erf-GELU ("gelu"); 1 = SiLU, with ffn_gated = 1 only */
+    int32_t activation;      /* 0 = erf-GELU ("gelu"); 1 = SiLU, with ffn_gated = 1 only.  With ffn_gated = 1 it is the GATE's activation */
     float ln_eps;            /* layer_norm_eps */
     int32_t head_dim;        /* 0 or 64: hidden / n_heads = 64.  8..56 (e5-small, bge-small, MiniLM: 32): the attention kernel
                                 works on 64-wide heads, the CALLER stores query / key / value weights and biases zero-padded to
@@ -225,7 +227,14 @@ typedef struct bh_encoder_config {
                                 H = silu(X Wg^T) * (X Wu^T) (NomicBertMLP, modeling_nomic_bert.py:266-279): the tensor
                                 "intermediate.dense.weight" holds gate and up rows INTERLEAVED — row 2 j = gate row j, row
                                 2 j + 1 = up row j, [2 * intermediate][hidden] —, "intermediate.dense.bias" likewise (2 *
-                                intermediate entries): one GEMM yields (gate, up) column pairs, which the GEMM's epilogue folds */
+                                intermediate entries): one GEMM yields (gate, up) column pairs, which the GEMM's epilogue folds.
+                                activation 0 with ffn_gated 1 (since 143): H = gelu(X Wg^T + bg) * (X Wu^T + bu), the GEGLU feed-forward of
+                                the "new" architecture (Alibaba-NLP/new-impl NewGatedMLP: up_gate_proj's first half is up, its second half
+                                the gate; the CALLER interleaves them as above) */
+    /* ---- since BH_VERSION 143 (a shorter struct reads as 0 = 1.0 here) ---- */
+    float rotary_scale;      /* 0 or 1: plain rotary angles t * theta^(-2j / 64).  Else every angle is multiplied by it: NTK-scaled RoPE
+                                (new-impl NTKScalingRotaryEmbedding: base' = base * factor goes into rotary_theta, the inverse frequencies
+                                are divided by factor^(2 / 64) — rotary_scale = factor^(-2 / 64)) */
 } bh_encoder_config;
 
 typedef struct bh_encoder bh_encoder;
@@ -324,6 +333,8 @@ int bh_op_attention(const void* qk, int64_t ldqk, const void* vt, int64_t ldvt, 
  * gu [n_rows][2 f] fp16 (device; (gate, up) column pairs).  Kernel-level entry points for the parity tests, like the three around them. */
 int bh_op_rotary(void* qk, int64_t n_rows, int32_t n_heads, const int32_t* pos, float theta, int32_t max_pos);
 int bh_op_swiglu(const void* gu, void* out, int64_t n_rows, int32_t f);
+/* the same fold with the gate's activation as an argument: act 0 = SiLU (bh_op_swiglu), 1 = erf-GELU (since BH_VERSION 143) */
+int bh_op_gated_act(const void* gu, void* out, int64_t n_rows, int32_t f, int32_t act);
 int bh_op_layernorm(const void* in, void* out, int64_t n_rows, int32_t d, float eps, const void* gamma,
                     const void* beta);
 /* 0 / 1 = direction of v_permlane32_swap found on the device (diagnostic), -1 on failure. */

@@ -1,0 +1,133 @@
+"""A torch implementation of the "new" encoder architecture (Alibaba-NLP/new-impl: gte-base-en-v1.5 / gte-large-en-v1.5), written
+from the published description of that REMOTE modelling file, which is not available offline (see oracle/new_oracle.py: parity
+unpinned).  Test infrastructure: it plays the part of the HF module a user's `AutoModel.from_pretrained(..., trust_remote_code=True)`
+returns — same config fields, same tensor names, same call convention (`model(input_ids=..., attention_mask=...)[0]`) — for the
+conversion and self-check tests, and is the second, independently written restatement the numpy oracle is compared with."""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+
+def new_config(**kw):
+    cfg = dict(model_type="new", vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+               hidden_act="gelu", max_position_embeddings=128, type_vocab_size=0, layer_norm_type="layer_norm", layer_norm_eps=1e-12,
+               position_embedding_type="rope", rope_theta=500000.0, rope_scaling={"type": "ntk", "factor": 2.0}, pack_qkv=True,
+               unpad_inputs=False, use_memory_efficient_attention=False, logn_attention_scale=False, logn_attention_clip1=False,
+               _name_or_path="toy/gte-tiny")
+    cfg.update(kw)
+    return SimpleNamespace(**cfg)
+
+
+class _Rotary(nn.Module):
+    def __init__(self, dim, max_pos, base, factor):
+        super().__init__()
+        if factor is not None:  # NTKScalingRotaryEmbedding, mixed_b None: the cache is built for max_pos * factor positions
+            base = base * factor
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        if factor is not None:
+            inv_freq = inv_freq / factor ** (2 / dim)
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+
+    def forward(self, seq_len):
+        t = torch.arange(seq_len, dtype=torch.float32)
+        freqs = torch.outer(t, self.inv_freq.float().cpu())
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos(), emb.sin()
+
+
+def _rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size)
+        if c.type_vocab_size > 0:
+            self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        sc = c.rope_scaling
+        self.rotary_emb = _Rotary(c.hidden_size // c.num_attention_heads, c.max_position_embeddings, c.rope_theta,
+                                  None if sc is None else sc["factor"])
+
+
+class _Attention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.qkv_proj = nn.Linear(c.hidden_size, 3 * c.hidden_size, bias=True)
+        self.o_proj = nn.Linear(c.hidden_size, c.hidden_size, bias=True)
+
+
+class _MLP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.up_gate_proj = nn.Linear(c.hidden_size, 2 * c.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(c.intermediate_size, c.hidden_size, bias=True)
+
+
+class _Layer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = _Attention(c)
+        self.mlp = _MLP(c)
+        self.attn_ln = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.mlp_ln = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(c) for _ in range(c.num_hidden_layers)])
+
+
+class TorchNewModel(nn.Module):
+    def __init__(self, config, seed=0, break_it=None):
+        super().__init__()
+        self.config = config
+        self.break_it = break_it  # tests: "swap_gate" computes act(up) * gate — a module the HIP mapping must NOT reproduce
+        torch.manual_seed(seed)
+        self.embeddings = _Embeddings(config)
+        self.encoder = _Encoder(config)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(seed + 1)
+            for name, p in self.named_parameters():
+                if "LayerNorm.weight" in name or name.endswith("_ln.weight"):
+                    p.copy_(1.0 + 0.05 * torch.randn(p.shape, generator=g))
+                elif "word_embeddings" in name or "token_type" in name:
+                    p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                p.copy_(p.half().float())
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, **unused):
+        c = self.config
+        B, T = input_ids.shape
+        dt = self.embeddings.word_embeddings.weight.dtype
+        x = self.embeddings.word_embeddings(input_ids)
+        if c.type_vocab_size > 0:
+            x = x + self.embeddings.token_type_embeddings(torch.zeros_like(input_ids) if token_type_ids is None else token_type_ids)
+        x = self.embeddings.LayerNorm(x)
+        cos, sin = self.embeddings.rotary_emb(T)
+        cos, sin = cos.to(x.device, dt)[None, None], sin.to(x.device, dt)[None, None]
+        nh = c.num_attention_heads
+        dh = c.hidden_size // nh
+        bias = torch.zeros(B, 1, 1, T, dtype=dt, device=x.device)
+        if attention_mask is not None:
+            bias = bias.masked_fill(attention_mask[:, None, None, :] == 0, torch.finfo(dt).min)
+        for layer in self.encoder.layer:
+            q, k, v = layer.attention.qkv_proj(x).split(c.hidden_size, dim=-1)
+            q, k, v = (t.view(B, T, nh, dh).transpose(1, 2) for t in (q, k, v))
+            q = q * cos + _rotate_half(q) * sin
+            k = k * cos + _rotate_half(k) * sin
+            s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh) + bias
+            p = torch.softmax(s, dim=-1)
+            ctx = torch.matmul(p, v).transpose(1, 2).reshape(B, T, c.hidden_size)
+            x = layer.attn_ln(x + layer.attention.o_proj(ctx))
+            up, gate = layer.mlp.up_gate_proj(x).split(c.intermediate_size, dim=-1)
+            h = (torch.nn.functional.gelu(up) * gate) if self.break_it == "swap_gate" else (torch.nn.functional.gelu(gate) * up)
+            x = layer.mlp_ln(x + layer.mlp.down_proj(h))
+        return (x,)

@@ -825,3 +825,30 @@ def test_sharded_searcher_buffers_on_the_device(amd, monkeypatch):
     assert len(s0._buf) == 1
     for ix, _ in shards:
         ix.close()
+
+
+def test_merge_lists_ranking_paths_against_the_oracle(amd):
+    """bh_merge_topk_device ranks by binary search when every list of a query is sorted in the canonical order (what searches
+    produce) and by an all-pairs count otherwise (the entry point accepts any lists, like the reference's torch.cat + torch.topk,
+    modules/retrieve.py:169-177): both against oracle/flat_ip_oracle.c's merge on lists with exact score ties inside and across
+    lists, duplicate ids, short lists (padding at the tail) and — second half — shuffled entries."""
+    import torch
+    rng = np.random.default_rng(77)
+    for n_lists, nq, k in ((8, 300, 200), (8, 257, 50), (3, 64, 7), (20, 33, 200), (1, 5, 50)):
+        pool = rng.standard_normal((nq, 64)).astype(np.float32)  # few distinct scores: many ties
+        s = pool[np.arange(nq)[None, :, None], rng.integers(0, 64, size=(n_lists, nq, k))]
+        i = rng.integers(0, 5000, size=(n_lists, nq, k)).astype(np.int64)  # a small id range: duplicates across and inside lists
+        n_valid = rng.integers(0, k + 1, size=(n_lists, nq))
+        n_valid[0, 0] = k
+        # canonical order inside every list: score descending, id ascending; padding (-inf, -1) behind the valid entries
+        order = np.lexsort((i, -s), axis=-1)
+        s, i = np.take_along_axis(s, order, -1), np.take_along_axis(i, order, -1)
+        pad = np.arange(k)[None, None, :] >= n_valid[:, :, None]
+        s[pad], i[pad] = -np.inf, -1
+        for shuffled in (False, True):
+            if shuffled:  # the same entries in arbitrary order (padding anywhere): the all-pairs path
+                perm = np.argsort(rng.random(s.shape), axis=-1)
+                s, i = np.take_along_axis(s, perm, -1), np.take_along_axis(i, perm, -1)
+            ws, wi = c_oracle.merge_topk(np.ascontiguousarray(s), np.ascontiguousarray(i))
+            ms, mi = amd.merge_topk(torch.from_numpy(s).cuda(), torch.from_numpy(i).cuda())
+            compare.assert_bit_exact(ms.cpu().numpy(), mi.cpu().numpy(), ws, wi, f"{n_lists} lists x {nq} x {k}, shuffled={shuffled}")
