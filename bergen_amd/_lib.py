@@ -85,6 +85,7 @@ class bh_encoder_config(_Sized):
         ("rotary_theta", ctypes.c_float),
         ("ffn_gated", ctypes.c_int32),
         ("rotary_scale", ctypes.c_float),   # since BH_VERSION 143
+        ("alibi", ctypes.c_int32),
     ]
 
 

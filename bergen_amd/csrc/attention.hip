@@ -44,7 +44,9 @@ __device__ __forceinline__ float half_lanes_sum(float v) {
 // WIDE: the context rows leave as 16-byte stores (two neighbouring 4-column groups joined by one half-lane exchange: a store
 // instruction then covers 32 bytes of each of its 32 rows instead of 16 — the same lesson as the GEMM's output path: the
 // memory system pays per row piece, not per byte); needs the documented direction of v_permlane32_swap (probed by the GEMM).
-template <int NWV, bool WIDE>
+// ALIBI: + the symmetric ALiBi bias -slope[head] |query - key| on every score (JinaBert: jina-embeddings-v2), applied with the
+// padding mask in units of the raw dot product (the 1/8 scale is folded into the exponent: the bias is multiplied by 8).
+template <int NWV, bool WIDE, bool ALIBI = false>
 __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NWV;
@@ -181,9 +183,12 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
         // mask keys beyond the sequence, block max
         const int key0 = kb * 32 + 4 * h;
         float bmax = -__builtin_inff();
+        float slope8 = 0.f;
+        if constexpr (ALIBI) slope8 = 8.0f * a.alibi[head];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int key = key0 + (v & 3) + 8 * (v >> 2);
+            if constexpr (ALIBI) sc[v] = fmaf(-slope8, fabsf((float)(q0 + ql - key)), sc[v]);
             sc[v] = key < len ? sc[v] : -__builtin_inff();
             bmax = fmaxf(bmax, sc[v]);
         }
@@ -268,7 +273,7 @@ __global__ void __launch_bounds__(64 * NWV, 4) bh_attention_kernel(BhAttnArgs a)
 }
 
 namespace {
-template <int NWV, bool WIDE>
+template <int NWV, bool WIDE, bool ALIBI>
 hipError_t launch_attn_w(const BhAttnArgs& a_in, int n_seq, int n_heads, int max_len, hipStream_t stream) {
     if (n_seq <= 0) return hipSuccess;
     const int nkb = (max_len + 31) / 32;
@@ -278,20 +283,20 @@ hipError_t launch_attn_w(const BhAttnArgs& a_in, int n_seq, int n_heads, int max
     const size_t smem = (size_t)nkb * 8192;
     static size_t attr_smem = 0;
     if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel<NWV, WIDE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bh_attention_kernel<NWV, WIDE, ALIBI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         attr_smem = smem;
     }
-    hipLaunchKernelGGL((bh_attention_kernel<NWV, WIDE>), dim3(n_heads, n_seq), dim3(64 * NWV), smem, stream, a);
+    hipLaunchKernelGGL((bh_attention_kernel<NWV, WIDE, ALIBI>), dim3(n_heads, n_seq), dim3(64 * NWV), smem, stream, a);
     return hipGetLastError();
 }
 template <int NWV>
 hipError_t launch_attn(const BhAttnArgs& a, int n_seq, int n_heads, int max_len, hipStream_t stream) {
     // 16-byte context stores where v_permlane32_swap has its documented direction (the GEMM's probe), 8-byte stores otherwise
-    if (n_seq > 0 && bh_gemm_probe_permlane(stream) == hipSuccess && bh_gemm_swap_mode() == 0)
-        return launch_attn_w<NWV, true>(a, n_seq, n_heads, max_len, stream);
-    return launch_attn_w<NWV, false>(a, n_seq, n_heads, max_len, stream);
+    const bool wide = n_seq > 0 && bh_gemm_probe_permlane(stream) == hipSuccess && bh_gemm_swap_mode() == 0;
+    if (a.alibi) return wide ? launch_attn_w<NWV, true, true>(a, n_seq, n_heads, max_len, stream) : launch_attn_w<NWV, false, true>(a, n_seq, n_heads, max_len, stream);
+    return wide ? launch_attn_w<NWV, true, false>(a, n_seq, n_heads, max_len, stream) : launch_attn_w<NWV, false, false>(a, n_seq, n_heads, max_len, stream);
 }
 }  // namespace
 

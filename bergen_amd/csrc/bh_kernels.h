@@ -213,6 +213,7 @@ struct BhAttnArgs {
     int d_model;
     int v_lds_off;       // filled by the launcher: byte offset of the V^T image in LDS
     const int* seq_idx;  // filled by the launcher: optional indirection blockIdx.y -> sequence (length buckets)
+    const float* alibi = nullptr;  // [n_heads] ALiBi slope per head (attention.hip only; null = none): score -= slope |i - j|
     // disentangled (DeBERTa-v2/v3) attention, attention_rel.hip only: score[i][j] = (Q_i.K_j + c2p[i][t(i-j)] + p2c[j][t(i-j)]) * scale
     const _Float16* c2p = nullptr;  // [n_heads][tokens][rel_ld]: Q_i . Kr[p]  (Kr = key_proj(rel_embeddings))
     const _Float16* p2c = nullptr;  // [n_heads][tokens][rel_ld]: K_j . Qr[p]  (Qr = query_proj(rel_embeddings))

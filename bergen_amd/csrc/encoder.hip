@@ -88,6 +88,7 @@ struct bh_encoder {
     int ffn_fused = 1;           // option "ffn_fused": the persistent GEMM folds the pairs in its epilogue where it applies (0: always GU + fold kernel)
     int n_cu = 256;
     BhDevBuf<float> rot;         // rotary positions (cfg.rotary_theta > 0): [max_position][64] = 32 cosines | 32 sines per position
+    BhDevBuf<float> alibi;       // ALiBi slope per head (cfg.alibi)
     BhDevBuf<float> POOLED;  // classification head: the pooler's output [batch][d]
     BhDevBuf<unsigned> SEG;  // SPLADE head: per (sequence, term) running max of relu(logit)
     // optional masked-LM head (BertOnlyMLMHead: transform dense + GELU + LayerNorm, decoder); SPLADE pooling (pool 3)
@@ -375,6 +376,8 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
     if (!(c.activation == 0 || (c.activation == 1 && c.ffn_gated == 1)))
         return bh_fail(BH_EUNSUPPORTED, "activation %d with ffn_gated %d unsupported (0 = erf-GELU, plain or gated feed-forward; 1 = SiLU with a gated one)",
                        c.activation, c.ffn_gated);
+    if (c.alibi != 0 && c.alibi != 1) return bh_fail(BH_EINVAL, "alibi %d (0 or 1)", c.alibi);
+    if (c.alibi && (hd != 64 || c.rotary_theta > 0.f)) return bh_fail(BH_EUNSUPPORTED, "ALiBi needs 64-dim heads and no rotary positions");
     if (!(c.rotary_scale >= 0.f) || c.rotary_scale > 1.f) return bh_fail(BH_EINVAL, "rotary_scale %g (0 = off, else in (0, 1])", (double)c.rotary_scale);
     if (!(c.rotary_theta >= 0.f) || (c.rotary_theta > 0.f && c.rotary_theta < 1.f)) return bh_fail(BH_EINVAL, "rotary_theta %g (0 = off, else >= 1)", (double)c.rotary_theta);
     if (c.rotary_theta > 0.f && hd != 64) return bh_fail(BH_EUNSUPPORTED, "rotary positions need 64-dim heads (head_dim %d)", hd);
@@ -402,6 +405,22 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
         rc = e->rot.ensure(tab.size());
         if (rc == BH_OK && hipMemcpy(e->rot.p, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             rc = bh_fail(BH_EHIP, "rotary table upload failed");
+    }
+    if (rc == BH_OK && c.alibi) {
+        // the standard ALiBi head slopes (JinaBert's _get_alibi_head_slopes): a geometric sequence starting at 2^(-8 / n) for n a power
+        // of two; otherwise the slopes of the next lower power of two, then every other one of twice that many
+        std::vector<float> sl;
+        auto pow2_slopes = [](int n, std::vector<float>& out, int take, int step) {
+            const double start = pow(2.0, -pow(2.0, -(log2((double)n) - 3.0)));
+            for (int i = 0, got = 0; i < n && got < take; i += step, ++got) out.push_back((float)(start * pow(start, (double)i)));
+        };
+        int closest = 1;
+        while (closest * 2 <= c.n_heads) closest *= 2;
+        pow2_slopes(closest, sl, closest, 1);
+        if (closest != c.n_heads) pow2_slopes(2 * closest, sl, c.n_heads - closest, 2);
+        rc = e->alibi.ensure(sl.size());
+        if (rc == BH_OK && hipMemcpy(e->alibi.p, sl.data(), sl.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = bh_fail(BH_EHIP, "ALiBi slope upload failed");
     }
     if (rc == BH_OK) {
         hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -978,6 +997,7 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
         aa.seq_off = e->seq_off.p;
         aa.seq_len = d_len;
         aa.d_model = da;
+        aa.alibi = c.alibi ? e->alibi.p : nullptr;
         (void)CTXp;
         if (rel) {
             // Qr | Kr = rel . Wqk^T + bqk (share_att_key: the layer's own query / key projections), then per head

@@ -256,7 +256,17 @@ def canonical_config(config):
                  # RoBERTa numbers positions from padding_idx + 1 (modeling_roberta.create_position_ids_from_input_ids)
                  position_offset=0 if mt == "bert" else int(get("pad_token_id", 1)) + 1)
         pet = get("position_embedding_type", "absolute")
-        if pet not in (None, "absolute"):
+        if pet == "alibi" and mt == "bert":
+            # jinaai/jina-embeddings-v2-* (config/retriever/jina-embeddings-v2-base-en.yaml): the REMOTE class JinaBertModel (hub
+            # repository jinaai/jina-bert-implementation, model_type "bert") — BERT's post-LN block with symmetric ALiBi attention
+            # biases instead of a position table and (feed_forward_type "geglu") a GELU-gated feed-forward without input bias.  Like
+            # the "new" class above it cannot be pinned offline: mapped from its published description, probed against the caller's
+            # module at conversion (self_check).
+            fft = str(get("feed_forward_type", "original"))
+            if fft not in ("original", "geglu"):
+                raise ValueError(f"feed_forward_type {fft!r} (original / geglu)")
+            c.update(alibi=1, self_check=True, ffn_gated=1 if fft == "geglu" else 0, jina=True)
+        elif pet not in (None, "absolute"):
             raise ValueError(f"position_embedding_type {pet!r}")
     c.update(vocab_size=get("vocab_size"), max_position_embeddings=c.pop("max_position_embeddings_override", None) or get("max_position_embeddings"),
              model_type=mt)
@@ -350,6 +360,11 @@ def canonical_state_dict(cfg, state_dict):
             if key.startswith(("pre_classifier.", "classifier.")):
                 # DistilBertForSequenceClassification pools with Linear + ReLU, not BertPooler's tanh: classify() must not exist
                 continue
+        elif mt == "bert" and cfg.get("jina"):
+            for a, b in ((".mlp.wo.", ".output.dense."), (".mlp.layernorm.", ".output.LayerNorm.")):
+                if a in key:
+                    key = key.replace(a, b)
+                    break
         elif mt != "bert":
             # RobertaClassificationHead = dense + tanh + out_proj on the <s> token: BertPooler + classifier by another name
             if key.startswith("classifier.dense."):
@@ -390,6 +405,18 @@ def canonical_state_dict(cfg, state_dict):
             for name, n in (("attention.self.query", d), ("attention.self.key", d), ("attention.self.value", d),
                             ("attention.output.dense", d), ("intermediate.dense", 2 * f), ("output.dense", d)):
                 out.setdefault(pre + name + ".bias", torch.zeros(n, dtype=torch.float16))
+    if cfg.get("jina"):
+        # ALiBi: a zero position table; gated_layers' rows are [gated | non-gated] (JinaBertGLUMLP: act(h[:, :f]) * h[:, f:]): interleaved
+        # (gate j, up j); it has no bias
+        nl, f = int(cfg["num_hidden_layers"]), int(cfg["intermediate_size"])
+        out["embeddings.position_embeddings.weight"] = torch.zeros(int(cfg["max_position_embeddings"]), d, dtype=torch.float16)
+        for l in range(nl if cfg.get("ffn_gated") else 0):
+            pre = f"encoder.layer.{l}."
+            gl = out.pop(pre + "mlp.gated_layers.weight", None)
+            if gl is None or gl.shape[0] != 2 * f:
+                raise ValueError(f"jina state dict lacks encoder.layer.{l}.mlp.gated_layers.weight of {2 * f} rows")
+            out[pre + "intermediate.dense.weight"] = torch.stack([gl[:f].detach().float(), gl[f:].detach().float()], dim=1).reshape(2 * f, d)
+            out[pre + "intermediate.dense.bias"] = torch.zeros(2 * f, dtype=torch.float16)
     if mt == "new":
         # rotary positions: a zero position table; up_gate_proj's rows are [up | gate] (NewGatedMLP splits the output in that order):
         # interleaved (gate j, up j) like NomicBert's; it has no bias
@@ -461,7 +488,7 @@ class BertEncoder:
             activation=1 if (get("ffn_gated") and get("hidden_act") == "silu") else 0, ln_eps=float(get("layer_norm_eps", 1e-12)),
             head_dim=int(get("head_dim")), position_offset=int(get("position_offset", 0)),
             rotary_theta=float(get("rotary_theta", 0.0) or 0.0), ffn_gated=int(get("ffn_gated", 0) or 0),
-            rotary_scale=float(get("rotary_scale", 0.0) or 0.0))
+            rotary_scale=float(get("rotary_scale", 0.0) or 0.0), alibi=int(get("alibi", 0) or 0))
         self.needs_self_check = bool(get("self_check", False))
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().bh_encoder_create(ctypes.byref(h), ctypes.byref(cfg)))

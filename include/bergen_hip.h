@@ -39,7 +39,7 @@ extern "C" {
  * (whether the last forward pass ran with the LayerNorms fused into the GEMM epilogues: encoder option "ln_fused") and bh_counters grew
  * balanced_scan_ms / balanced_queries at its END (option balance_tail); 143 = 0.1.4.3 (round 6): bh_encoder_config grew rotary_scale at its
  * END and accepts activation 0 with ffn_gated 1 (the GELU-gated feed-forward + NTK-scaled rotary positions of Alibaba-NLP/gte-*-en-v1.5,
- * config/retriever/gte-base-en-v1.5.yaml) + bh_op_gated_act (bh_op_swiglu with the gate's activation as an argument). */
+ * config/retriever/gte-base-en-v1.5.yaml), alibi (jina-embeddings-v2) + bh_op_gated_act (bh_op_swiglu with the gate's activation as an argument). */
 #define BH_VERSION 143
 
 typedef enum bh_status {
@@ -235,6 +235,10 @@ typedef struct bh_encoder_config {
     float rotary_scale;      /* 0 or 1: plain rotary angles t * theta^(-2j / 64).  Else every angle is multiplied by it: NTK-scaled RoPE
                                 (new-impl NTKScalingRotaryEmbedding: base' = base * factor goes into rotary_theta, the inverse frequencies
                                 are divided by factor^(2 / 64) — rotary_scale = factor^(-2 / 64)) */
+    int32_t alibi;           /* 1: ALiBi attention biases (jinaai/jina-embeddings-v2-*: remote JinaBert, position_embedding_type "alibi"):
+                                score[i][j] = q_i . k_j / sqrt(head_dim) - slope_h |i - j|, the SYMMETRIC encoder form, slope_h the standard
+                                ALiBi head slopes (2^(-8 (h + 1) / n) for n a power of two, interleaved from 2 n otherwise); the caller
+                                uploads a zero position table.  0: none */
 } bh_encoder_config;
 
 typedef struct bh_encoder bh_encoder;

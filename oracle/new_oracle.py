@@ -129,3 +129,76 @@ def random_new(cfg, seed=0, scale=0.05):
         sd[p + "mlp_ln.weight"] = g(d)
         sd[p + "mlp_ln.bias"] = r(d)
     return sd
+
+
+# ---- JinaBert (jinaai/jina-embeddings-v2-*: config/retriever/jina-embeddings-v2-base-en.yaml, Dense + MeanPooler + CosineSim) ----------
+# The same situation as "new": the architecture is the checkpoint's REMOTE modelling file (hub repository
+# jinaai/jina-bert-implementation, modeling_bert.py: JinaBertModel, model_type "bert"), absent offline -> PARITY UNPINNED; restated from its
+# published description, guarded in the product by the conversion self-check:
+#     JinaBertEmbeddings       word + token_type embeddings -> LayerNorm; no position table when position_embedding_type == "alibi"
+#     JinaBertSelfAttention    BERT's biased query / key / value projections; scores = q k^T / sqrt(dim) + mask + alibi,
+#                              alibi[h][i][j] = -slope_h |i - j| (the symmetric encoder form), slope_h = _get_alibi_head_slopes(n_heads)
+#     JinaBertSelfOutput       dense + LayerNorm(hidden + input)
+#     JinaBertGLUMLP           (feed_forward_type "geglu") gated_layers (Linear hidden -> 2 intermediate, NO bias) split [gated | non-gated];
+#                              wo(gelu(gated) * non_gated) (bias); layernorm(out + residual)
+
+def alibi_slopes(n_heads):
+    """The standard ALiBi head slopes (Press et al.; JinaBert's _get_alibi_head_slopes)."""
+    def pow2(n):
+        start = 2.0 ** (-(2.0 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+    if math.log2(n_heads).is_integer():
+        return np.asarray(pow2(n_heads))
+    closest = 2 ** math.floor(math.log2(n_heads))
+    return np.asarray(pow2(closest) + list(alibi_slopes(2 * closest))[0::2][: n_heads - closest])
+
+
+def jina_forward(sd, cfg, input_ids, attention_mask=None, token_type_ids=None, dtype=np.float64):
+    """Last hidden state [B, T, d] of a JinaBertModel (alibi, geglu) with state dict `sd` (numpy, the remote file's names: BERT's for the
+    embeddings and the attention, encoder.layer.<l>.mlp.gated_layers / wo / layernorm for the feed-forward)."""
+    W = lambda k: np.asarray(sd[k], dtype)
+    ids = np.asarray(input_ids)
+    B, T = ids.shape
+    mask = np.ones((B, T), np.int64) if attention_mask is None else np.asarray(attention_mask)
+    types = np.zeros((B, T), np.int64) if token_type_ids is None else np.asarray(token_type_ids)
+    eps = cfg.get("layer_norm_eps", 1e-12)
+    nh, f = cfg["num_attention_heads"], cfg["intermediate_size"]
+    x = W("embeddings.word_embeddings.weight")[ids] + W("embeddings.token_type_embeddings.weight")[types]
+    x = _ln(x, W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias"), eps)
+    d = x.shape[-1]
+    dh = d // nh
+    pos = np.arange(T)
+    bias = -alibi_slopes(nh)[:, None, None] * np.abs(pos[:, None] - pos[None, :])[None]  # [nh, T, T]
+    neg = np.where(mask[:, None, None, :] != 0, 0.0, -np.inf)
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{l}."
+        lin = lambda t, n: t @ W(p + n + ".weight").T + W(p + n + ".bias")
+        q, k, v = (lin(x, "attention.self." + n).reshape(B, T, nh, dh).transpose(0, 2, 1, 3) for n in ("query", "key", "value"))
+        s = q @ k.transpose(0, 1, 3, 2) / math.sqrt(dh) + bias[None] + neg
+        s = s - s.max(-1, keepdims=True)
+        pr = np.exp(s)
+        pr = pr / pr.sum(-1, keepdims=True)
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(B, T, d)
+        x = _ln(lin(ctx, "attention.output.dense") + x, W(p + "attention.output.LayerNorm.weight"), W(p + "attention.output.LayerNorm.bias"), eps)
+        gl = x @ W(p + "mlp.gated_layers.weight").T
+        h = _gelu(gl[..., :f]) * gl[..., f:]
+        x = _ln(lin(h, "mlp.wo") + x, W(p + "mlp.layernorm.weight"), W(p + "mlp.layernorm.bias"), eps)
+    return x
+
+
+def random_jina(cfg, seed=0, scale=0.05):
+    rng = np.random.default_rng(seed)
+    d, f, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    r = lambda *s, sc=scale: (rng.standard_normal(s) * sc).astype(np.float16).astype(np.float32)
+    g = lambda n: (1.0 + rng.standard_normal(n) * 0.05).astype(np.float16).astype(np.float32)
+    sd = {"embeddings.word_embeddings.weight": r(V, d, sc=0.5), "embeddings.token_type_embeddings.weight": r(cfg.get("type_vocab_size", 2), d, sc=0.5),
+          "embeddings.LayerNorm.weight": g(d), "embeddings.LayerNorm.bias": r(d)}
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{l}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = r(d, d), r(d)
+        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"] = g(d), r(d)
+        sd[p + "mlp.gated_layers.weight"] = r(2 * f, d)
+        sd[p + "mlp.wo.weight"], sd[p + "mlp.wo.bias"] = r(d, f), r(d)
+        sd[p + "mlp.layernorm.weight"], sd[p + "mlp.layernorm.bias"] = g(d), r(d)
+    return sd

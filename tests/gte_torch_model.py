@@ -131,3 +131,88 @@ class TorchNewModel(nn.Module):
             h = (torch.nn.functional.gelu(up) * gate) if self.break_it == "swap_gate" else (torch.nn.functional.gelu(gate) * up)
             x = layer.mlp_ln(x + layer.mlp.down_proj(h))
         return (x,)
+
+
+# ---- JinaBert (jina-embeddings-v2): BERT attention + symmetric ALiBi bias, GELU-gated feed-forward; same role as TorchNewModel ----------
+
+def jina_config(**kw):
+    cfg = dict(model_type="bert", vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+               hidden_act="gelu", max_position_embeddings=128, type_vocab_size=2, layer_norm_eps=1e-12, position_embedding_type="alibi",
+               feed_forward_type="geglu", emb_pooler="mean", _name_or_path="toy/jina-tiny")
+    cfg.update(kw)
+    return SimpleNamespace(**cfg)
+
+
+def _alibi_head_slopes(n_heads):
+    def get_slopes_power_of_2(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        ratio = start
+        return [start * ratio ** i for i in range(n)]
+    if math.log2(n_heads).is_integer():
+        return get_slopes_power_of_2(n_heads)
+    closest_power_of_2 = 2 ** math.floor(math.log2(n_heads))
+    return get_slopes_power_of_2(closest_power_of_2) + _alibi_head_slopes(2 * closest_power_of_2)[0::2][: n_heads - closest_power_of_2]
+
+
+class TorchJinaBert(nn.Module):
+    def __init__(self, config, seed=0):
+        super().__init__()
+        c = self.config = config
+        torch.manual_seed(seed)
+        self.embeddings = nn.Module()
+        self.embeddings.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.embeddings.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.embeddings.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.encoder = nn.Module()
+        layers = []
+        for _ in range(c.num_hidden_layers):
+            L = nn.Module()
+            L.attention = nn.Module()
+            L.attention.self = nn.Module()
+            L.attention.self.query = nn.Linear(c.hidden_size, c.hidden_size)
+            L.attention.self.key = nn.Linear(c.hidden_size, c.hidden_size)
+            L.attention.self.value = nn.Linear(c.hidden_size, c.hidden_size)
+            L.attention.output = nn.Module()
+            L.attention.output.dense = nn.Linear(c.hidden_size, c.hidden_size)
+            L.attention.output.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+            L.mlp = nn.Module()
+            L.mlp.gated_layers = nn.Linear(c.hidden_size, 2 * c.intermediate_size, bias=False)
+            L.mlp.wo = nn.Linear(c.intermediate_size, c.hidden_size)
+            L.mlp.layernorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+            layers.append(L)
+        self.encoder.layer = nn.ModuleList(layers)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(seed + 1)
+            for name, p in self.named_parameters():
+                if "LayerNorm.weight" in name or name.endswith("layernorm.weight"):
+                    p.copy_(1.0 + 0.05 * torch.randn(p.shape, generator=g))
+                elif "embeddings" in name and "LayerNorm" not in name:
+                    p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.05 * torch.randn(p.shape, generator=g))
+                p.copy_(p.half().float())
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, **unused):
+        c = self.config
+        B, T = input_ids.shape
+        dt = self.embeddings.word_embeddings.weight.dtype
+        tt = torch.zeros_like(input_ids) if token_type_ids is None else token_type_ids
+        x = self.embeddings.LayerNorm(self.embeddings.word_embeddings(input_ids) + self.embeddings.token_type_embeddings(tt))
+        nh = c.num_attention_heads
+        dh = c.hidden_size // nh
+        pos = torch.arange(T, device=x.device)
+        rel = (pos[None, :] - pos[:, None]).abs().to(dt)
+        alibi = -torch.tensor(_alibi_head_slopes(nh), dtype=dt, device=x.device)[:, None, None] * rel[None]
+        bias = alibi[None].expand(B, -1, -1, -1).clone()
+        if attention_mask is not None:
+            bias = bias + torch.zeros(B, 1, 1, T, dtype=dt, device=x.device).masked_fill(attention_mask[:, None, None, :] == 0, torch.finfo(dt).min)
+        for L in self.encoder.layer:
+            q, k, v = (m(x).view(B, T, nh, dh).transpose(1, 2) for m in (L.attention.self.query, L.attention.self.key, L.attention.self.value))
+            p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh) + bias, dim=-1)
+            ctx = torch.matmul(p, v).transpose(1, 2).reshape(B, T, c.hidden_size)
+            x = L.attention.output.LayerNorm(L.attention.output.dense(ctx) + x)
+            h = L.mlp.gated_layers(x)
+            h = torch.nn.functional.gelu(h[..., : c.intermediate_size]) * h[..., c.intermediate_size:]
+            x = L.mlp.layernorm(L.mlp.wo(h) + x)
+        return (x,)

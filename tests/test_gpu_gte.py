@@ -133,3 +133,34 @@ def test_dense_plugin_runs_gte_on_the_hip_path():
     emb = d("doc", batch)["embedding"].float().cpu().numpy()
     want = model(**batch)[0][:, 0].numpy()
     _close(emb, want, "Dense gte CLS embedding")
+
+
+# ---- JinaBert (jina-embeddings-v2-base-en.yaml): ALiBi biases in the attention kernel + the GELU-gated feed-forward ----------
+
+@pytest.mark.parametrize("heads,hidden", [(2, 128), (12, 768)])
+def test_jina_alibi_model_matches_the_oracle_and_passes_its_self_check(heads, hidden):
+    """heads = 12: the slopes of a head count that is not a power of two (8 + every other one of 16), as in jina-embeddings-v2-base."""
+    from bergen_amd import BertEncoder
+    from gte_torch_model import TorchJinaBert, jina_config
+    cfg = jina_config(num_attention_heads=heads, hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=2, max_position_embeddings=256)
+    model = TorchJinaBert(cfg, seed=21).eval()
+    enc = BertEncoder.from_hf(model, device=0)
+    assert enc.needs_self_check and enc.self_check_result["min_cosine"] >= 0.995
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(5)
+    B, T = 6, 150  # longer than 128 tokens: the 8-wave attention instantiation; a short batch below: the 4-wave one
+    lens = np.array([T, 140, 97, 64, 33, 5])
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    ids = rng.integers(5, cfg.vocab_size, size=(B, T)).astype(np.int64) * mask
+    types = (np.arange(T)[None, :] >= (lens[:, None] // 2)).astype(np.int64) * mask
+    kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "token_type_ids": torch.from_numpy(types)}
+    hid = enc(**kw)[0].float().cpu().numpy()
+    want = new_oracle.jina_forward(sd, vars(cfg), ids, mask, types)
+    m = mask.astype(bool)
+    _close(hid[m], want[m], f"jina hidden states ({heads} heads)")
+    short = {k: v[2:, :97] for k, v in kw.items()}
+    got = enc.encode_pooled(short, "mean").float().cpu().numpy()
+    hs = new_oracle.jina_forward(sd, vars(cfg), ids[2:, :97], mask[2:, :97], types[2:, :97])
+    ms = mask[2:, :97].astype(np.float64)[..., None]
+    _close(got, (hs * ms).sum(1) / ms.sum(1), "jina mean-pooled (4-wave attention)")
+    enc.close()

@@ -86,3 +86,33 @@ def test_state_dict_maps_onto_the_bert_shaped_stack_and_reproduces_the_module():
         x = bert_oracle._ln(lin(h, "output.dense") + x, csd[p + "output.LayerNorm.weight"], csd[p + "output.LayerNorm.bias"], 1e-12)
     m = mask.astype(bool)
     np.testing.assert_allclose(x[m], want[m], rtol=0, atol=2e-4)
+
+
+# ---- JinaBert (jina-embeddings-v2): same standing — parity unpinned, two restatements compared, mapping checked arithmetically ----------
+
+def test_jina_oracle_agrees_with_the_torch_restatement_and_the_mapping():
+    from gte_torch_model import TorchJinaBert, jina_config
+    cfg = jina_config(num_attention_heads=2)
+    model = TorchJinaBert(cfg, seed=15).eval()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    ids, mask = _batch(cfg, seed=6)
+    want = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))[0].numpy()
+    got = new_oracle.jina_forward(sd, vars(cfg), ids, mask)
+    m = mask.astype(bool)
+    np.testing.assert_allclose(got[m], want[m], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(new_oracle.alibi_slopes(12), [2.0 ** -(i + 1) for i in range(8)] + [2.0 ** -(0.5 * (2 * i + 1)) for i in range(4)], rtol=1e-12)
+    canon = encoder.canonical_config(cfg)
+    assert canon["alibi"] == 1 and canon["ffn_gated"] == 1 and canon["self_check"] and canon["model_type"] == "bert"
+    csd = encoder.canonical_state_dict(canon, model.state_dict())
+    f, d = cfg.intermediate_size, cfg.hidden_size
+    w = csd["encoder.layer.1.intermediate.dense.weight"]
+    gl = model.state_dict()["encoder.layer.1.mlp.gated_layers.weight"]
+    assert torch.equal(w[0::2], gl[:f]) and torch.equal(w[1::2], gl[f:]), "rows must interleave (gated j, non-gated j)"
+    assert "encoder.layer.0.output.dense.weight" in csd and "encoder.layer.0.output.LayerNorm.bias" in csd
+    assert not any(".mlp." in k for k in csd) and not csd["embeddings.position_embeddings.weight"].any()
+    plain = encoder.canonical_config(jina_config(feed_forward_type="original"))
+    assert plain["alibi"] == 1 and plain["ffn_gated"] == 0
+    with pytest.raises(ValueError, match="feed_forward_type"):
+        encoder.canonical_config(jina_config(feed_forward_type="glu"))
+    with pytest.raises(ValueError, match="position_embedding_type"):
+        encoder.canonical_config(jina_config(model_type="roberta", pad_token_id=1))
