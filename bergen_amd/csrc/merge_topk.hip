@@ -65,9 +65,11 @@ __global__ void __launch_bounds__(256) bh_merge_lists_kernel(const float* __rest
         if (sorted) {
             const int l = i / k;
             rank = i - l * k;  // its own list's entries before it
-            for (int lo = 0; lo < n_lists; ++lo) {
+            for (int lo = 0; lo < n_lists && rank < k; ++lo) {  // (rank >= k: not in the result, whatever the other lists add)
                 if (lo == l) continue;
-                int a = 0, b = k;  // the prefix of list lo that precedes entry i: first position whose entry does not
+                // the prefix of list lo that precedes entry i: first position whose entry does not.  Only prefixes shorter than
+                // k - rank matter (a longer one pushes the entry out of the result all the same): the search is bounded by it
+                int a = 0, b = k - rank;
                 while (a < b) {
                     const int mid = (a + b) >> 1;
                     if (precedes(lo * k + mid, sc, id, i))

@@ -79,7 +79,10 @@ class CrossEncoder(Reranker):
         reaches a kernel), so the logits are the same bits and the host builds / copies [B, longest] instead of [B, max_len] ids."""
         question = [e['query'] for e in examples]
         doc = [e['doc'] for e in examples]
-        inp_dict = self.tokenizer(question, doc, padding=True, truncation='only_second', max_length=self.max_len, return_tensors='pt')
+        from .dense import fast_tokenize_pairs
+        inp_dict = fast_tokenize_pairs(self.tokenizer, question, doc, self.max_len)  # (the same values without HF's Python post-processing)
+        if inp_dict is None:
+            inp_dict = self.tokenizer(question, doc, padding=True, truncation='only_second', max_length=self.max_len, return_tensors='pt')
         inp_dict['q_id'] = [e['q_id'] for e in examples]
         inp_dict['d_id'] = [e['d_id'] for e in examples]
         return inp_dict

@@ -133,3 +133,38 @@ def test_native_pipeline_coalesces_yaml_batches_and_keeps_the_reference_order(ba
     assert out["doc_id"][1].index("d7") < out["doc_id"][1].index("d4")   # q1: d7 (8) above d4 (7)
     st = r.last_eval_stats
     assert st["pairs"] == 17 and st["launches"] == want_launches and st["algorithmic_flops"] == 10.0 * want_launches
+
+
+def test_fast_pair_tokenisation_equals_the_hf_call():
+    """CrossEncoder.collate_packed's fast path (dense.fast_tokenize_pairs) against the HF call it replaces — same ids, type ids and mask,
+    truncation of the SECOND sequence only, right padding to the longest pair — on a WordPiece tokenizer with BERT's pair template."""
+    import sys
+    sys.argv = [sys.argv[0]]
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_for_tok", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from bergen_amd.dense import fast_tokenize_pairs
+    tok, words = bench.toy_wordpiece(2000, seed=3)
+    rng = np.random.default_rng(4)
+    qs = [" ".join(words[j] for j in rng.integers(0, len(words), size=int(rng.integers(1, 14)))) for _ in range(37)]
+    ds = [" ".join(words[j] for j in rng.integers(0, len(words), size=int(rng.integers(1, 90)))) for _ in range(37)]
+    ds[5] = ""  # an empty passage
+    for max_len in (256, 48, 20):  # 48 / 20: the passages (and only they) are truncated
+        want = tok(qs, ds, padding=True, truncation="only_second", max_length=max_len, return_tensors="pt")
+        got = fast_tokenize_pairs(tok, qs, ds, max_len)
+        assert got is not None
+        for key in ("input_ids", "token_type_ids", "attention_mask"):
+            assert torch.equal(got[key], want[key]), (max_len, key)
+        assert int(want["input_ids"].shape[1]) <= max_len
+    # the singles' fast path configures another truncation strategy on the same backend: each call sets its own
+    from bergen_amd.dense import fast_tokenize
+    single = fast_tokenize(tok, ds[:7], 32)
+    assert torch.equal(single["input_ids"], tok(ds[:7], padding=True, truncation=True, max_length=32, return_tensors="pt")["input_ids"])
+    again = fast_tokenize_pairs(tok, qs, ds, 48)
+    assert torch.equal(again["input_ids"], tok(qs, ds, padding=True, truncation="only_second", max_length=48, return_tensors="pt")["input_ids"])
+
+    class Slow:
+        is_fast = False
+    assert fast_tokenize_pairs(Slow(), ["a"], ["b"], 8) is None
