@@ -314,13 +314,16 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
                     const half4 o = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v1[0], (_Float16)v1[1]};
                     acc[tb][fb] = floatx4{0.f, 0.f, 0.f, 0.f};
                     const int chunk = fb * 2 + (lg >> 1);  // the 16-byte chunk of the row's 128 bytes that holds features 16 fb + 4 lg ..
-                    *reinterpret_cast<half4*>(stg + tr * 128 + ((chunk ^ (tr & 7)) << 4) + (lg & 1) * 8) = o;
+                    // (chunk order XOR-permuted by (row >> 1) & 7: the 16 rows a half-wave's ds_write_b64 touches land in 16 distinct bank
+                    // groups — rows r and r + 1 in the two 128-byte halves of the 256-byte bank window, the eight row pairs on eight chunk
+                    // positions.  Round 6: with (row & 7) rows r and r + 8 collided — SQ_LDS_BANK_CONFLICT 5-9 % of SQ_LDS_IDX_ACTIVE)
+                    *reinterpret_cast<half4*>(stg + tr * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4) + (lg & 1) * 8) = o;
                 }
             }
             asm volatile("" ::: "memory");  // (a wave's LDS instructions execute in order, and no other wave touches stg)
 #pragma unroll
             for (int i = 0; i < (TBS > 1 ? 4 : 2); ++i) {
-                const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ rrow) << 4));
+                const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ (((8 * i + rrow) >> 1) & 7)) << 4));
                 half8* p = reinterpret_cast<half8*>(gptr + (size_t)(tp * 32 + 8 * i) * ldc_eff);
                 if constexpr ((ABL & 16) != 0) {
                     if (v[0] != (_Float16)12345.f) continue;  // (never true for the bench data: keeps the math alive)

@@ -65,8 +65,14 @@ fixed_collectives_ms = max(0.0, whole1_ms - local_ms)
 s1, i1 = sh.search(q, k, id_offset=lo)
 s1, i1 = torch.as_tensor(s1).to(dev), torch.as_tensor(i1).to(dev)
 gen = torch.Generator(device=dev).manual_seed(5)
-all_s = torch.stack([s1 + 1e-3 * torch.randn(s1.shape, generator=gen, device=dev) for _ in range(G)]).sort(dim=2, descending=True).values.contiguous()
-all_i = torch.stack([i1 + r * (hi - lo) for r in range(G)]).contiguous()
+# (canonical order inside every synthetic list, like a real shard's: score descending, ties by ascending id — a list that is not makes the
+# merge kernel count all pairs for that query, which a real search never triggers)
+all_s = torch.stack([s1 + 1e-3 * torch.randn(s1.shape, generator=gen, device=dev) for _ in range(G)])
+all_i = torch.stack([i1 + r * (hi - lo) for r in range(G)])
+order = torch.argsort(all_i, dim=2, stable=True)
+all_s, all_i = torch.gather(all_s, 2, order), torch.gather(all_i, 2, order)
+order = torch.argsort(all_s, dim=2, descending=True, stable=True)
+all_s, all_i = torch.gather(all_s, 2, order).contiguous(), torch.gather(all_i, 2, order).contiguous()
 per = nq * k * 12 + 8
 flat = torch.empty(G * per + 64, dtype=torch.uint8, device=dev)
 buf_s = torch.empty_like(all_s)
