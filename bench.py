@@ -284,6 +284,20 @@ def encoder_leg(args, device_index, arch="bert"):
     if arch == "nomic":
         cfg.update(model_type="nomic_bert", hidden_act="silu", vocab_size=30528, max_position_embeddings=2048, rope_theta=1000.0)
         sd = synth.random_nomic(cfg, seed=33, scale=0.02)
+    elif arch == "gte":
+        # Alibaba-NLP/gte-base-en-v1.5 (config/retriever/gte-base-en-v1.5.yaml): the remote "new" class — NTK-scaled rotary positions,
+        # packed biased q | k | v, GELU-gated feed-forward (one [2 d_ff] GEMM folded in its epilogue), CLS pooling
+        cfg = dict(model_type="new", vocab_size=30528, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                   hidden_act="gelu", max_position_embeddings=8192, type_vocab_size=0, layer_norm_type="layer_norm", layer_norm_eps=1e-12,
+                   position_embedding_type="rope", rope_theta=500000.0, rope_scaling={"type": "ntk", "factor": 2.0})
+        sd = synth.random_new(cfg, seed=37, scale=0.02)
+    elif arch == "jina":
+        # jinaai/jina-embeddings-v2-base-en (config/retriever/jina-embeddings-v2-base-en.yaml): remote JinaBert — symmetric ALiBi attention
+        # biases, GELU-gated feed-forward, mean pooling
+        cfg = dict(model_type="bert", vocab_size=30528, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                   hidden_act="gelu", max_position_embeddings=8192, type_vocab_size=2, layer_norm_eps=1e-12, position_embedding_type="alibi",
+                   feed_forward_type="geglu")
+        sd = synth.random_jina(cfg, seed=39, scale=0.02)
     elif arch == "e5_large":
         # BASELINE configs[4]'s encoder (config/retriever/e5-large-v2.yaml:1-10): bert-large shape, MeanPooler,
         # batch_size 512, max_len 256 — the same synthetic passages as the BERT-base leg
@@ -291,7 +305,7 @@ def encoder_leg(args, device_index, arch="bert"):
         sd = synth.random_bert(cfg, seed=35)
     else:
         sd = synth.random_bert(cfg, seed=31)
-    pooler = "cls" if arch == "bert" else "mean"
+    pooler = "cls" if arch in ("bert", "gte") else "mean"
     enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=device_index)
     rng = np.random.default_rng(6)
     lens = np.clip(np.rint(rng.normal(130, 30, size=args.enc_batch)), 16, 256).astype(np.int64)
@@ -319,6 +333,15 @@ def encoder_leg(args, device_index, arch="bert"):
                         f"random-init weights",
             "passages_per_s": args.enc_batch * args.enc_steps / wall, "steps": args.enc_steps, "ms_per_step_kernels": fwd_ms / args.enc_steps,
             "packed_rows": int(c["packed_rows"]), "finite_and_shaped": ok,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                         "algorithmic_flops_per_step": c["flops"]}}}
+    if arch in ("gte", "jina"):
+        what = ("the 'new' class of gte-base-en-v1.5 (12x768x12 heads, NTK rotary, GELU-gated d_ff 3072) forward + CLS pool" if arch == "gte" else
+                "JinaBert of jina-embeddings-v2-base-en (12x768x12 heads, ALiBi, GELU-gated d_ff 3072) forward + mean pool")
+        return {arch + "_encode": {
+            "workload": f"{what}, {args.enc_batch} synthetic passages/step, {int(c['real_tokens'])} real tokens, fp16 storage / fp32 accumulate, "
+                        f"random-init weights (remote architectures: parity unpinned offline, conversions self-checked — oracle/new_oracle.py)",
+            "passages_per_s": args.enc_batch * args.enc_steps / wall, "ms_per_step_kernels": fwd_ms / args.enc_steps, "finite_and_shaped": ok,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
                          "algorithmic_flops_per_step": c["flops"]}}}
     if arch == "nomic":
@@ -831,6 +854,30 @@ def encode_stage_leg(args, device_index):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def make_cross_encoder(deberta, device_index):
+    """A random-init cross-encoder of the reference's two reranker families on the HIP path: DeBERTa-v3-large shape (disentangled
+    attention, 256 position buckets: config/reranker/debertav3.yaml) or BERT-large shape (BAAI/bge-reranker-large ...).  Returns (encoder, cfg)."""
+    from bergen_amd import BertEncoder, synth
+    deb = deberta
+    cfg = dict(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+               max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
+    sd = synth.random_bert(cfg, seed=61)
+    synth.random_cls_head(cfg, seed=62, num_labels=1, sd=sd)
+    if deb:
+        g = np.random.default_rng(63)
+        cfg.update(model_type="deberta-v2", type_vocab_size=0, layer_norm_eps=1e-7, relative_attention=True, position_buckets=256,
+                   norm_rel_ebd="layer_norm", share_att_key=True, pos_att_type="p2c|c2p", position_biased_input=False,
+                   max_relative_positions=-1)
+        sd = {k.replace(".attention.self.query.", ".attention.self.query_proj.").replace(".attention.self.key.", ".attention.self.key_proj.")
+              .replace(".attention.self.value.", ".attention.self.value_proj."): v for k, v in sd.items()
+              if not k.startswith(("embeddings.position_embeddings", "embeddings.token_type_embeddings"))}
+        sd["encoder.rel_embeddings.weight"] = (g.standard_normal((512, 1024)) * 0.02).astype(np.float16).astype(np.float32)
+        sd["encoder.LayerNorm.weight"] = np.ones(1024, np.float32)
+        sd["encoder.LayerNorm.bias"] = np.zeros(1024, np.float32)
+    enc = BertEncoder(cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=device_index)
+    return enc, cfg
+
+
 def rerank_leg(args, device_index):
     """The rerank stage's model call (reference models/rerankers/crossencoder.py:34-38) at the shapes of the
     reference's two reranker families, random-init weights: a DeBERTa-v3-large-shaped cross-encoder (24 x 1024, 16 heads, 256
@@ -851,22 +898,7 @@ def rerank_leg(args, device_index):
     for name, deb in (("deberta_v3_large_shape", True), ("bert_large_shape", False), ("bert_large_shape_256_pairs", False)):
         lens, mask = (lens256, mask256) if name.endswith("256_pairs") else (lens32, mask32)
         n_pairs = len(lens)
-        cfg = dict(vocab_size=30522, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
-                   max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, hidden_act="gelu")
-        sd = synth.random_bert(cfg, seed=61)
-        synth.random_cls_head(cfg, seed=62, num_labels=1, sd=sd)
-        if deb:
-            g = np.random.default_rng(63)
-            cfg.update(model_type="deberta-v2", type_vocab_size=0, layer_norm_eps=1e-7, relative_attention=True, position_buckets=256,
-                       norm_rel_ebd="layer_norm", share_att_key=True, pos_att_type="p2c|c2p", position_biased_input=False,
-                       max_relative_positions=-1)
-            sd = {k.replace(".attention.self.query.", ".attention.self.query_proj.").replace(".attention.self.key.", ".attention.self.key_proj.")
-                  .replace(".attention.self.value.", ".attention.self.value_proj."): v for k, v in sd.items()
-                  if not k.startswith(("embeddings.position_embeddings", "embeddings.token_type_embeddings"))}
-            sd["encoder.rel_embeddings.weight"] = (g.standard_normal((512, 1024)) * 0.02).astype(np.float16).astype(np.float32)
-            sd["encoder.LayerNorm.weight"] = np.ones(1024, np.float32)
-            sd["encoder.LayerNorm.bias"] = np.zeros(1024, np.float32)
-        enc = BertEncoder(cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=device_index)
+        enc, cfg = make_cross_encoder(deb, device_index)
         ids = rng.integers(1, cfg["vocab_size"], size=(n_pairs, T)).astype(np.int64) * mask
         kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
         enc.classify(kw)
@@ -1649,6 +1681,8 @@ def run(args, env):
                 out.update(encoder_leg(args, local_rank))
                 out.update(encoder_leg(args, local_rank, arch="nomic"))
                 out.update(encoder_leg(args, local_rank, arch="e5_large"))
+                out.update(encoder_leg(args, local_rank, arch="gte"))
+                out.update(encoder_leg(args, local_rank, arch="jina"))
             except Exception as exc:
                 out["encoder_error"] = repr(exc)
         if not args.no_encoder and world == 1 and args.encode_stage_passages > 0:
@@ -1700,6 +1734,12 @@ def secondary_summary(out):
         "encode_stage_passages_per_s": get("encode_stage", "workers_threads_4", "passages_per_s"),
         "e5_large_passages_per_s": get("e5_large_encode", "passages_per_s"), "e5_large_frac": get("e5_large_encode", "roofline", "frac"),
         "nomic_passages_per_s": get("nomic_encode", "passages_per_s"), "nomic_frac": get("nomic_encode", "roofline", "frac"),
+        "gte_passages_per_s": get("gte_encode", "passages_per_s"), "gte_frac": get("gte_encode", "roofline", "frac"),
+        "jina_passages_per_s": get("jina_encode", "passages_per_s"), "jina_frac": get("jina_encode", "roofline", "frac"),
+        "rerank_stage_deberta_pairs_per_s": get("rerank", "deberta_v3_large_shape", "through_rerank_eval", "pairs_per_s"),
+        "rerank_stage_deberta_frac": get("rerank", "deberta_v3_large_shape", "through_rerank_eval", "frac"),
+        "rerank_stage_bert_large_pairs_per_s": get("rerank", "bert_large_shape", "through_rerank_eval", "pairs_per_s"),
+        "rerank_stage_bert_large_frac": get("rerank", "bert_large_shape", "through_rerank_eval", "frac"),
         "splade_queries_per_s": get("splade_search", "queries_per_s"), "splade_frac": get("splade_search", "roofline", "frac"),
         "splade_queries": get("splade_search", "queries"), "splade_full_list_gate": get("splade_search", "full_list_gate", "ids_and_fp32_scores_bit_exact"),
         "splade_encode_passages_per_s": get("splade_encode", "passages_per_s"),

@@ -220,3 +220,46 @@ def sparse_bench_blocks(n_docs, vocab, device, term_seeds=3, block=1_000_000):
             w = torch.log1p(torch.empty(nnz_b, device=device).exponential_(1.0, generator=gw)).half().clamp_(min=0.01).cpu().numpy()
         yield b, done, indptr[:m + 1], terms[:nnz_b], w
         done += m
+
+
+def random_new(cfg, seed=0, scale=0.05):
+    """Seeded random NewModel state dict (numpy fp32, fp16-representable), the remote file's tensor names."""
+    rng = np.random.default_rng(seed)
+    d, f, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    r = lambda *s, sc=scale: (rng.standard_normal(s) * sc).astype(np.float16).astype(np.float32)
+    g = lambda n: (1.0 + rng.standard_normal(n) * 0.05).astype(np.float16).astype(np.float32)
+    sd = {"embeddings.word_embeddings.weight": r(V, d, sc=0.5), "embeddings.LayerNorm.weight": g(d), "embeddings.LayerNorm.bias": r(d)}
+    if int(cfg.get("type_vocab_size", 0) or 0) > 0:
+        sd["embeddings.token_type_embeddings.weight"] = r(cfg["type_vocab_size"], d, sc=0.5)
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{l}."
+        sd[p + "attention.qkv_proj.weight"] = r(3 * d, d)
+        sd[p + "attention.qkv_proj.bias"] = r(3 * d)
+        sd[p + "attention.o_proj.weight"] = r(d, d)
+        sd[p + "attention.o_proj.bias"] = r(d)
+        sd[p + "attn_ln.weight"] = g(d)
+        sd[p + "attn_ln.bias"] = r(d)
+        sd[p + "mlp.up_gate_proj.weight"] = r(2 * f, d)
+        sd[p + "mlp.down_proj.weight"] = r(d, f)
+        sd[p + "mlp.down_proj.bias"] = r(d)
+        sd[p + "mlp_ln.weight"] = g(d)
+        sd[p + "mlp_ln.bias"] = r(d)
+    return sd
+
+
+def random_jina(cfg, seed=0, scale=0.05):
+    rng = np.random.default_rng(seed)
+    d, f, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    r = lambda *s, sc=scale: (rng.standard_normal(s) * sc).astype(np.float16).astype(np.float32)
+    g = lambda n: (1.0 + rng.standard_normal(n) * 0.05).astype(np.float16).astype(np.float32)
+    sd = {"embeddings.word_embeddings.weight": r(V, d, sc=0.5), "embeddings.token_type_embeddings.weight": r(cfg.get("type_vocab_size", 2), d, sc=0.5),
+          "embeddings.LayerNorm.weight": g(d), "embeddings.LayerNorm.bias": r(d)}
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"encoder.layer.{l}."
+        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = r(d, d), r(d)
+        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"] = g(d), r(d)
+        sd[p + "mlp.gated_layers.weight"] = r(2 * f, d)
+        sd[p + "mlp.wo.weight"], sd[p + "mlp.wo.bias"] = r(d, f), r(d)
+        sd[p + "mlp.layernorm.weight"], sd[p + "mlp.layernorm.bias"] = g(d), r(d)
+    return sd

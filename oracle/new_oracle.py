@@ -106,31 +106,6 @@ def geglu_ref(gu):
     return _gelu(gu[:, 0::2]) * gu[:, 1::2]
 
 
-def random_new(cfg, seed=0, scale=0.05):
-    """Seeded random NewModel state dict (numpy fp32, fp16-representable), the remote file's tensor names."""
-    rng = np.random.default_rng(seed)
-    d, f, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
-    r = lambda *s, sc=scale: (rng.standard_normal(s) * sc).astype(np.float16).astype(np.float32)
-    g = lambda n: (1.0 + rng.standard_normal(n) * 0.05).astype(np.float16).astype(np.float32)
-    sd = {"embeddings.word_embeddings.weight": r(V, d, sc=0.5), "embeddings.LayerNorm.weight": g(d), "embeddings.LayerNorm.bias": r(d)}
-    if int(cfg.get("type_vocab_size", 0) or 0) > 0:
-        sd["embeddings.token_type_embeddings.weight"] = r(cfg["type_vocab_size"], d, sc=0.5)
-    for l in range(cfg["num_hidden_layers"]):
-        p = f"encoder.layer.{l}."
-        sd[p + "attention.qkv_proj.weight"] = r(3 * d, d)
-        sd[p + "attention.qkv_proj.bias"] = r(3 * d)
-        sd[p + "attention.o_proj.weight"] = r(d, d)
-        sd[p + "attention.o_proj.bias"] = r(d)
-        sd[p + "attn_ln.weight"] = g(d)
-        sd[p + "attn_ln.bias"] = r(d)
-        sd[p + "mlp.up_gate_proj.weight"] = r(2 * f, d)
-        sd[p + "mlp.down_proj.weight"] = r(d, f)
-        sd[p + "mlp.down_proj.bias"] = r(d)
-        sd[p + "mlp_ln.weight"] = g(d)
-        sd[p + "mlp_ln.bias"] = r(d)
-    return sd
-
-
 # ---- JinaBert (jinaai/jina-embeddings-v2-*: config/retriever/jina-embeddings-v2-base-en.yaml, Dense + MeanPooler + CosineSim) ----------
 # The same situation as "new": the architecture is the checkpoint's REMOTE modelling file (hub repository
 # jinaai/jina-bert-implementation, modeling_bert.py: JinaBertModel, model_type "bert"), absent offline -> PARITY UNPINNED; restated from its
@@ -186,19 +161,5 @@ def jina_forward(sd, cfg, input_ids, attention_mask=None, token_type_ids=None, d
     return x
 
 
-def random_jina(cfg, seed=0, scale=0.05):
-    rng = np.random.default_rng(seed)
-    d, f, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
-    r = lambda *s, sc=scale: (rng.standard_normal(s) * sc).astype(np.float16).astype(np.float32)
-    g = lambda n: (1.0 + rng.standard_normal(n) * 0.05).astype(np.float16).astype(np.float32)
-    sd = {"embeddings.word_embeddings.weight": r(V, d, sc=0.5), "embeddings.token_type_embeddings.weight": r(cfg.get("type_vocab_size", 2), d, sc=0.5),
-          "embeddings.LayerNorm.weight": g(d), "embeddings.LayerNorm.bias": r(d)}
-    for l in range(cfg["num_hidden_layers"]):
-        p = f"encoder.layer.{l}."
-        for n in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
-            sd[p + n + ".weight"], sd[p + n + ".bias"] = r(d, d), r(d)
-        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"] = g(d), r(d)
-        sd[p + "mlp.gated_layers.weight"] = r(2 * f, d)
-        sd[p + "mlp.wo.weight"], sd[p + "mlp.wo.bias"] = r(d, f), r(d)
-        sd[p + "mlp.layernorm.weight"], sd[p + "mlp.layernorm.bias"] = g(d), r(d)
-    return sd
+# seeded synthetic weights live in the product package's bench helpers (no arithmetic of the path)
+from bergen_amd.synth import random_jina, random_new  # noqa: E402,F401
