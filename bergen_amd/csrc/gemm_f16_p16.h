@@ -316,7 +316,8 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
                     const int chunk = fb * 2 + (lg >> 1);  // the 16-byte chunk of the row's 128 bytes that holds features 16 fb + 4 lg ..
                     // (chunk order XOR-permuted by (row >> 1) & 7: the 16 rows a half-wave's ds_write_b64 touches land in 16 distinct bank
                     // groups — rows r and r + 1 in the two 128-byte halves of the 256-byte bank window, the eight row pairs on eight chunk
-                    // positions.  Round 6: with (row & 7) rows r and r + 8 collided — SQ_LDS_BANK_CONFLICT 5-9 % of SQ_LDS_IDX_ACTIVE)
+                    // positions; with (row & 7), until round 6, rows r and r + 8 shared one.  Measured: the kernel's SQ_LDS_BANK_CONFLICT
+                    // share (5-9 % of SQ_LDS_IDX_ACTIVE) and the forward pass did not move with it: those conflicts are not these writes)
                     *reinterpret_cast<half4*>(stg + tr * 128 + ((chunk ^ ((tr >> 1) & 7)) << 4) + (lg & 1) * 8) = o;
                 }
             }

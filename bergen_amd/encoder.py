@@ -584,9 +584,23 @@ class BertEncoder:
         except StopIteration:
             dev, was_training = torch.device("cpu"), False
         model.eval()
-        want = model(input_ids=ids.to(dev), attention_mask=mask.to(dev))[0].float().cpu()
-        if was_training:
-            model.train()
+        try:
+            try:
+                want = model(input_ids=ids.to(dev), attention_mask=mask.to(dev))[0].float().cpu()
+            except Exception:  # noqa: BLE001 — e.g. an fp16 module still on the CPU (Dense loads with torch_dtype=float16): probe it on the GPU
+                if dev.type == "cuda" or not torch.cuda.is_available():
+                    raise
+                gpu = torch.device("cuda", self.device_index)
+                model.to(gpu)
+                try:
+                    want = model(input_ids=ids.to(gpu), attention_mask=mask.to(gpu))[0].float().cpu()
+                finally:
+                    model.to(dev)
+        except Exception as exc:  # noqa: BLE001 — a module that cannot be probed cannot vouch for the mapping: stay on it
+            raise ValueError(f"self-check could not run the HF module on the probe batch: {type(exc).__name__}: {exc}") from exc
+        finally:
+            if was_training:
+                model.train()
         got = self(input_ids=ids, attention_mask=mask)[0].float().cpu()
         worst_cos, worst_abs = 1.0, 0.0
         for b in range(batch):

@@ -67,7 +67,7 @@ def test_hipcc_pairs_the_vt_reads(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     body, on = [], False
     for line in open(out):
-        if re.match(r"^_Z19bh_attention_kernelILi4ELb1EEv10BhAttnArgs:", line):
+        if re.match(r"^_Z19bh_attention_kernelILi4ELb1ELb0EEv10BhAttnArgs:", line):  # <NWV = 4, WIDE, ALIBI = false>
             on = True
         if on:
             body.append(line)

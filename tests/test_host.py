@@ -455,12 +455,12 @@ def test_unsupported_encoders_are_reported_not_silent(caplog):
     from types import SimpleNamespace
     from bergen_amd.dense import _native_encoder, _warned
     from bergen_amd.encoder import BertEncoder
-    # jina-embeddings-v2 (config/retriever/jina-embeddings-v2-base-en.yaml): a remote "bert" class with ALiBi attention biases
-    cfg = SimpleNamespace(model_type="bert", position_embedding_type="alibi", _name_or_path="jinaai/jina-embeddings-v2-base-en", hidden_size=768,
-                          num_attention_heads=12, num_hidden_layers=12, intermediate_size=3072, vocab_size=30528, max_position_embeddings=8192,
+    # a BERT with relative_key position embeddings: outside the HIP forward pass (absolute / rotary / ALiBi positions only)
+    cfg = SimpleNamespace(model_type="bert", position_embedding_type="relative_key", _name_or_path="org/bert-relative-key", hidden_size=768,
+                          num_attention_heads=12, num_hidden_layers=12, intermediate_size=3072, vocab_size=30528, max_position_embeddings=512,
                           type_vocab_size=2, hidden_act="gelu")
     model = SimpleNamespace(config=cfg)
-    assert "position_embedding_type 'alibi'" in BertEncoder.unsupported_reason(model)
+    assert "position_embedding_type 'relative_key'" in BertEncoder.unsupported_reason(model)
     assert BertEncoder.unsupported_reason(SimpleNamespace(config=SimpleNamespace(model_type="llama"))).startswith("model_type 'llama'")
     # a DeBERTa-v2 checkpoint outside deberta-v3's configuration (no relative attention) is refused with the reason
     assert "relative_attention is off" in BertEncoder.unsupported_reason(SimpleNamespace(config=SimpleNamespace(model_type="deberta-v2")))
@@ -473,7 +473,7 @@ def test_unsupported_encoders_are_reported_not_silent(caplog):
         assert _native_encoder(model) is model
         assert _native_encoder(model) is model
     msgs = [r.getMessage() for r in caplog.records if "stays on the HF torch implementation" in r.getMessage()]
-    assert len(msgs) == 1 and "jina-embeddings-v2" in msgs[0]
+    assert len(msgs) == 1 and "bert-relative-key" in msgs[0]
 
 
 def test_reference_model_families_resolve_to_the_hip_forward_pass():
