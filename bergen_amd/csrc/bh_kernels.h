@@ -254,8 +254,11 @@ struct BhLnArgs {
     int d;
     float eps;
     const _Float16 *gamma, *beta;
+    int small_regs = -1;  // 1: the 32-register kernel (row widths 512 / 768 / 1024: fits beside a persistent GEMM workgroup); 0: the general
+                          // kernel; -1: the process default (option ln_small, default 1)
 };
 hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t stream);
+void bh_ln_set_small(int on);  // process default of BhLnArgs::small_regs = -1 (bh_set_option "ln_small")
 
 // Fused LayerNorm (encoder.hip, option ln_fused): the two small kernels beside the GEMM epilogues of gemm_f16_persist.h.
 //   bh_launch_ln_fold      once per weight, at commit: W'[n][k] = fp16(W[n][k] gamma[k]), c[n] = fp16(sum_k W'[n][k]) (the sum of the

@@ -119,6 +119,84 @@ __global__ void __launch_bounds__(256) bh_layernorm_kernel(BhLnArgs a) {
     store_row(a.out + (size_t)row * a.d, x, nchunk, lane);
 }
 
+// The same LayerNorm(dense output + residual) in at most 32 vector registers, for row widths of 256 NJ (768: BERT-base, 1024: the large
+// shapes).  Why (round 6): a persistent GEMM workgroup (gemm_f16_p16.h: 235-237 VGPRs, allocated as 240, two waves per SIMD = 480 of the
+// 512-entry file) leaves 32 registers per SIMD lane and no LDS on its CU.  The 62-register kernel above therefore cannot start on a CU a
+// GEMM workgroup of the OTHER micro-batch's stream occupies: the LayerNorm passes (12 % of the forward pass's kernel time, HBM-bound) wait
+// for whole GEMMs to drain and the forward pass is the SUM of the isolated kernel times.  One wave of this kernel fits beside the two GEMM
+// waves of a SIMD, so a LayerNorm of one micro-batch streams through HBM while the other micro-batch's GEMM owns the matrix pipes.
+// A lane owns NJ groups of 4 consecutive elements (8-byte accesses, 512 contiguous bytes per wave instruction); the wave reductions are
+// DPP adds inside a row of 16 lanes + four v_readlane (no ds_bpermute: the LDS crossbar is the GEMM's).  Same arithmetic order as
+// row_layernorm is NOT kept (another summation tree): the two kernels agree to fp32 round-off, tests/test_gpu_encoder.py.
+namespace {
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += ln_dpp<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v += ln_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += ln_dpp<0x141>(v);  // row_half_mirror: lane i <-> 7 - i of its 8
+    v += ln_dpp<0x140>(v);  // row_mirror: lane i <-> 15 - i of its 16 -> every lane of a row holds the row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+}  // namespace
+
+template <int NJ>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) bh_layernorm_small_kernel(BhLnArgs a) {
+    const int lane = threadIdx.x & 63;
+    // (the row is wave-uniform, and the compiler is told so: every row address is then a scalar base + ONE lane-offset register)
+    const long long row = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (row >= a.n_rows) return;
+    constexpr int D = 256 * NJ;
+    const _Float16* src = a.in + (size_t)row * D + lane * 4;
+    float x[NJ][4];
+    {
+        half4 v[NJ], r[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const half4*>(src + j * 256);
+        if (a.residual) {
+            const _Float16* res = a.residual + (size_t)row * D + lane * 4;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) r[j] = *reinterpret_cast<const half4*>(res + j * 256);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[j][e] = (float)v[j][e] + (float)r[j][e];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[j][e] = (float)v[j][e];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += x[j][e];
+    const float mean = wave_sum_dpp(s) * (1.0f / (float)D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[j][e] -= mean;
+            q = fmaf(x[j][e], x[j][e], q);
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) * (1.0f / (float)D) + a.eps);
+    _Float16* dst = a.out + (size_t)row * D + lane * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {  // one group at a time: its gamma / beta registers are dead before the next group's arrive
+        const half4 g = *reinterpret_cast<const half4*>(a.gamma + j * 256 + lane * 4);
+        const half4 b = *reinterpret_cast<const half4*>(a.beta + j * 256 + lane * 4);
+        half4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (_Float16)(x[j][e] * rstd * (float)g[e] + (float)b[e]);
+        *reinterpret_cast<half4*>(dst + j * 256) = o;
+    }
+}
+
 // one wave per sequence
 __global__ void __launch_bounds__(256) bh_pool_kernel(BhPoolArgs a) {
     const int lane = threadIdx.x & 63;
@@ -333,9 +411,22 @@ hipError_t bh_launch_ln_finalize(const BhLnFinalizeArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t st) {
-    if (a.n_rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bh_layernorm_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+static int g_ln_small = 1;
+void bh_ln_set_small(int on) { g_ln_small = on ? 1 : 0; }
+
+hipError_t bh_launch_layernorm(const BhLnArgs& a_in, hipStream_t st) {
+    if (a_in.n_rows <= 0) return hipSuccess;
+    BhLnArgs a = a_in;
+    if (a.small_regs < 0) a.small_regs = g_ln_small;
+    // the 32-register kernel (fits beside a persistent GEMM workgroup's waves) where the row width allows it and the caller asks for it
+    if (a.small_regs && a.d == 768)
+        hipLaunchKernelGGL(bh_layernorm_small_kernel<3>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+    else if (a.small_regs && a.d == 1024)
+        hipLaunchKernelGGL(bh_layernorm_small_kernel<4>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+    else if (a.small_regs && a.d == 512)
+        hipLaunchKernelGGL(bh_layernorm_small_kernel<2>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(bh_layernorm_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 // One thread = 8 consecutive dims j .. j + 7 (j < 32) of one head slice and their partners j + 32 ..: two 16-byte loads, the 8

@@ -20,7 +20,7 @@ sd = synth.random_nomic(cfg, seed=33, scale=0.02) if arch == "nomic" else synth.
 enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=0)
 for kv in sys.argv[3:]:
     name, val = kv.split("=")
-    (_lib.set_option if name.startswith("gemm_") else enc.set_option)(name, int(val))
+    (_lib.set_option if name.startswith(("gemm_", "ln_small")) else enc.set_option)(name, int(val))
 rng = np.random.default_rng(6)
 batch = 512
 lens = np.clip(np.rint(rng.normal(130, 30, size=batch)), 16, 256).astype(np.int64)

@@ -261,14 +261,22 @@ def test_attention_against_oracle(lens):
 
 
 def test_layernorm_against_oracle():
-    from bergen_amd import encoder
+    """Both LayerNorm kernels: the general one-wave-per-row kernel and (option ln_small, the default; row widths 512 / 768 / 1024) the
+    32-register kernel that fits beside a persistent GEMM workgroup — another summation tree, the same fp32 mathematics."""
+    from bergen_amd import _lib, encoder
     rng = np.random.default_rng(9)
-    for d in (128, 768, 1024):
-        x = rnd16(rng, 37, d, scale=3.0)
-        g, b = rnd16(rng, d) + np.float16(1), rnd16(rng, d)
-        got = encoder.layernorm(h16(x), h16(g), h16(b), 1e-12).float().cpu().numpy()
-        ref = bert_oracle.layernorm_ref(x, g, b, 1e-12)
-        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-3
+    try:
+        for small in (1, 0):
+            _lib.set_option("ln_small", small)
+            for d in (128, 512, 768, 1024):
+                for rows in (37, 4, 1):
+                    x = rnd16(rng, rows, d, scale=3.0)
+                    g, b = rnd16(rng, d) + np.float16(1), rnd16(rng, d)
+                    got = encoder.layernorm(h16(x), h16(g), h16(b), 1e-12).float().cpu().numpy()
+                    ref = bert_oracle.layernorm_ref(x, g, b, 1e-12)
+                    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-3, (small, d, rows)
+    finally:
+        _lib.set_option("ln_small", 1)
 
 
 def _native(cfg, sd):
