@@ -254,7 +254,7 @@ struct BhLnArgs {
     int d;
     float eps;
     const _Float16 *gamma, *beta;
-    int small_regs = -1;  // 1: the 32-register kernel (row widths 512 / 768 / 1024: fits beside a persistent GEMM workgroup); 0: the general
+    int small_regs = -1;  // 1: the 32-register kernel (768-wide rows: fits beside a persistent GEMM workgroup); 0: the general
                           // kernel; -1: the process default (option ln_small, default 1)
 };
 hipError_t bh_launch_layernorm(const BhLnArgs& a, hipStream_t stream);

@@ -119,8 +119,7 @@ __global__ void __launch_bounds__(256) bh_layernorm_kernel(BhLnArgs a) {
     store_row(a.out + (size_t)row * a.d, x, nchunk, lane);
 }
 
-// The same LayerNorm(dense output + residual) in at most 32 vector registers, for row widths of 256 NJ (768: BERT-base, 1024: the large
-// shapes).  Why (round 6): a persistent GEMM workgroup (gemm_f16_p16.h: 235-237 VGPRs, allocated as 240, two waves per SIMD = 480 of the
+// The same LayerNorm(dense output + residual) in 32 vector registers for 768-wide rows (row widths of 256 NJ; launched for NJ = 3 only).  Why (round 6): a persistent GEMM workgroup (gemm_f16_p16.h: 235-237 VGPRs, allocated as 240, two waves per SIMD = 480 of the
 // 512-entry file) leaves 32 registers per SIMD lane and no LDS on its CU.  The 62-register kernel above therefore cannot start on a CU a
 // GEMM workgroup of the OTHER micro-batch's stream occupies: the LayerNorm passes (12 % of the forward pass's kernel time, HBM-bound) wait
 // for whole GEMMs to drain and the forward pass is the SUM of the isolated kernel times.  One wave of this kernel fits beside the two GEMM
@@ -419,12 +418,10 @@ hipError_t bh_launch_layernorm(const BhLnArgs& a_in, hipStream_t st) {
     BhLnArgs a = a_in;
     if (a.small_regs < 0) a.small_regs = g_ln_small;
     // the 32-register kernel (fits beside a persistent GEMM workgroup's waves) where the row width allows it and the caller asks for it
+    // (768-wide rows only: the 1024-wide instantiation needs 40 registers, does not fit beside the GEMM and measured no gain — the large shapes
+    // keep the general kernel and their round-5 bits)
     if (a.small_regs && a.d == 768)
         hipLaunchKernelGGL(bh_layernorm_small_kernel<3>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
-    else if (a.small_regs && a.d == 1024)
-        hipLaunchKernelGGL(bh_layernorm_small_kernel<4>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
-    else if (a.small_regs && a.d == 512)
-        hipLaunchKernelGGL(bh_layernorm_small_kernel<2>, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL(bh_layernorm_kernel, dim3((unsigned)((a.n_rows + 3) / 4)), dim3(256), 0, st, a);
     return hipGetLastError();
