@@ -1230,6 +1230,11 @@ def scan_roofline(acc, c, steps, n_rows, dim, k, traffic_json, dim_padded=None):
     out["mfma_busy_frac"] = busy["mfma_busy_frac"] if busy else None
     out["mfma"] = {"achieved": out["mfma_tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": out["mfma_frac"],
                    "busy_frac": out["mfma_busy_frac"], "busy": busy}
+    # the two rooflines side by side, each self-consistent (achieved / peak / unit / frac): `hbm` by SURVEY §8d's algorithmic bytes (the
+    # top-level achieved / peak / unit / frac repeat it: the contract's accounting and north_star's ">= 50 % of HBM peak" figure), `mfma`
+    # above; `bound` says which of the two physically binds the launch
+    out["hbm"] = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "accounting": "SURVEY 8d bytes per pass x passes per launch",
+                  "traffic": traffic, "frac_of_bytes_it_must_move": out["hbm_frac_of_needed_bytes"]}
     if n_pair and n_single > 0:
         a1 = single_ms / (n_single * steps)
         out["unpaired_launch"] = {"kernel": name, "passes_per_launch": 1, "launches": n_single * steps, "avg_launch_ms": a1,
