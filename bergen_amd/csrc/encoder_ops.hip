@@ -137,7 +137,11 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += ln_dpp<0x4E>(v);   // quad_perm [2, 3, 0, 1]
     v += ln_dpp<0x141>(v);  // row_half_mirror: lane i <-> 7 - i of its 8
     v += ln_dpp<0x140>(v);  // row_mirror: lane i <-> 15 - i of its 16 -> every lane of a row holds the row's sum
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    // (the builtin takes and returns an int: bit casts, not value conversions — a float argument is silently TRUNCATED to an integer, which
+    // cost this kernel a factor 2.4 in mean error until tests/test_gpu_encoder.py's accuracy comparison with the general kernel caught it)
+    const unsigned u = __float_as_uint(v);
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 0)) + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 16)) +
+           __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 32)) + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)u, 48));
 }
 }  // namespace
 
