@@ -283,7 +283,7 @@ def test_layernorm_against_oracle():
         for small in (1, 0):
             _lib.set_option("ln_small", small)
             errs[small] = float(np.abs(encoder.layernorm(h16(x), h16(g), h16(b), 1e-12).float().cpu().numpy() - ref).mean())
-        assert errs[1] <= 1.02 * errs[0] + 1e-7, errs
+        assert errs[1] <= 1.05 * errs[0] + 1e-7, errs  # (equal to ~1e-3 relative: both are the fp16 rounding of the same fp32 values; the truncation bug was 2.4x)
     finally:
         _lib.set_option("ln_small", 1)
 
