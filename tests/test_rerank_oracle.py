@@ -168,3 +168,47 @@ def test_fast_pair_tokenisation_equals_the_hf_call():
     class Slow:
         is_fast = False
     assert fast_tokenize_pairs(Slow(), ["a"], ["b"], 8) is None
+
+
+def test_native_pipeline_on_an_hf_dataset_and_on_an_empty_one():
+    """The rerank stage is handed an HF Dataset by BERGEN (modules/rag.py builds it from the retrieval run): columnar slices instead of
+    row look-ups, same result; an empty dataset gives empty lists (the reference's torch.cat of nothing would raise: a query set whose
+    retrieval came back empty should not take the stage down)."""
+    import datasets
+    import bergen_amd
+
+    class FakeEncoder:
+        num_labels = 1
+
+        def classify(self, batch):
+            return batch["x"].float()
+
+        def counters(self):
+            return {"flops": 1.0, "forward_ms": 0.1}
+
+    class FakeCE(bergen_amd.Reranker):
+        native = True
+
+        def __init__(self):
+            super().__init__("org/fake-native")
+            self.model = FakeEncoder()
+
+        def collate_fn(self, examples, query_or_doc=None):
+            raise AssertionError
+
+        def collate_packed(self, examples):
+            assert all(set(e) >= {"query", "doc", "q_id", "d_id"} for e in examples)
+            return {"x": torch.tensor([[float(len(e["doc"]))] for e in examples]),
+                    "q_id": [e["q_id"] for e in examples], "d_id": [e["d_id"] for e in examples]}
+
+        def __call__(self, kwargs):
+            raise AssertionError
+
+    rows = [{"query": "q", "doc": "x" * n, "q_id": f"q{i % 2}", "d_id": f"d{i}"} for i, n in enumerate([3, 9, 5, 1, 7, 2, 8])]
+    stage = bergen_amd.Rerank(init_args=FakeCE(), batch_size=2, launch_pairs=4, num_workers=2)
+    out_list = stage.eval(rows)
+    out_ds = stage.eval(datasets.Dataset.from_list(rows))
+    assert out_ds["q_id"] == out_list["q_id"] == ["q0", "q1"] and out_ds["doc_id"] == out_list["doc_id"] == [["d6", "d4", "d2", "d0"], ["d1", "d5", "d3"]]
+    assert [s.tolist() for s in out_ds["score"]] == [s.tolist() for s in out_list["score"]]
+    empty = stage.eval([])
+    assert empty == {"score": [], "doc_id": [], "q_id": []} and stage.last_eval_stats["launches"] == 0
