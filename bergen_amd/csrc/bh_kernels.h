@@ -182,6 +182,14 @@ struct BhGemmArgs {
     const _Float16 *res_gamma, *res_beta;
     float* stats_out;
     int tail_split;  // gemm_f16_p16.h: a last round of at most half the workgroups' worth of tiles is cut into 2 or 4 sub-tiles along M
+    // Rotary positions applied to the OUTPUT (the Q | K projection of NomicBert / gte: every 64-column slice is one head of Q or K): set
+    // rot_pos (position of every output row) and rot_cs ([rot_max_pos][64] fp32: 32 cosines | 32 sines) and bh_launch_gemm_f16 returns the
+    // ROTATED projection — in the 16x16x32 kernel's epilogue for the rows of whole tiles (a lane's partner column, 32 further, is its own
+    // accumulator two feature blocks on: no exchange), by bh_launch_rotary for whatever rows another kernel computed — the same bits either way.
+    // Needs bias_mode 1, N % 64 == 0, ldc == N, no other epilogue.
+    const int* rot_pos = nullptr;
+    const float* rot_cs = nullptr;
+    int rot_max_pos = 0;
 };
 // whether bh_launch_gemm_f16 would run an M x N problem on the persistent kernel's full-line-store path (the fused-LayerNorm epilogues exist there only)
 bool bh_gemm_ln_fusable(int M, int N, bool blocked_out);
@@ -197,6 +205,7 @@ void bh_gemm_set_stagger(int phases, int pct);  // bench knob: start stagger of 
 void bh_gemm_set_gelu_nontemporal(int on);      // A/B knob: non-temporal stores of the bias + GELU output (default on)
 void bh_gemm_set_mfma16(int on);                // bias (+ GELU) projections on the 16x16x32 persistent kernel (gemm_f16_p16.h)
 void bh_gemm_set_tail_split(int on);            // gemm_f16_p16.h: sub-tiles for a short last round (default on)
+void bh_gemm_set_rotary_fused(int on);          // BhGemmArgs::rot_pos: rotary positions in the 16x16x32 kernel's epilogue (default on; 0 = standalone kernel for all rows)
 void bh_gemm_set_full_line_stores(int on);      // persistent kernel: outputs through LDS as whole 128-byte lines (gemm_f16_persist.h PST bit 32)
 
 struct BhAttnArgs {

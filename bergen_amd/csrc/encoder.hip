@@ -974,17 +974,26 @@ int bh_encoder_forward(bh_encoder* e, const int64_t* input_ids, const int64_t* a
             g.ln_stats = S2p;
             g.ln_c = L.cqk;
             if ((rc = gemm_args(e, g, ls))) return rc;
+        } else if (c.rotary_theta > 0.f) {
+            // rotary positions (NomicBert, gte): the Q | K projection comes back ROTATED by the rows' token indices — in the GEMM's epilogue for
+            // the rows of whole tiles on the 16x16x32 kernel, by bh_launch_rotary for the rest (BhGemmArgs::rot_pos; option gemm_rotary_fused)
+            BhGemmArgs g{};
+            g.A = Xp;
+            g.lda = d;
+            g.B = L.wqk;
+            g.ldb = d;
+            g.C = QKp;
+            g.ldc = 2 * da;
+            g.bias = L.bqk;
+            g.bias_mode = 1;
+            g.M = (int)rows;
+            g.N = (int)(2 * da);
+            g.K = (int)d;
+            g.rot_pos = d_pos + r0;
+            g.rot_cs = e->rot.p;
+            g.rot_max_pos = c.max_position;
+            if ((rc = gemm_args(e, g, ls))) return rc;
         } else if ((rc = gemm(e, Xp, d, L.wqk, d, QKp, 2 * da, rows, 2 * da, d, L.bqk, 1, nullptr, 0, 0, 0, ls))) return rc;
-        if (c.rotary_theta > 0.f) {  // rotary positions: queries and keys of this micro-batch's rows, in place, by their token index
-            BhRotaryArgs ra{};
-            ra.qk = QKp;
-            ra.pos = d_pos + r0;
-            ra.cos_sin = e->rot.p;
-            ra.n_rows = rows;
-            ra.n_heads = c.n_heads;
-            ra.max_pos = c.max_position;
-            BH_HIP_TRY(bh_launch_rotary(ra, ls));
-        }
         if (fork) BH_HIP_TRY(hipStreamWaitEvent(ls, evj, 0));
         BhAttnArgs aa{};
         aa.qk = e->QK.p;  // (the attention kernels address tokens by their absolute packed row: seq_off)

@@ -454,8 +454,14 @@ __global__ void __launch_bounds__(256) bh_rotary_kernel(BhRotaryArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float a1 = (float)x1[e], a2 = (float)x2[e];
-        o1[e] = (_Float16)(a1 * co[e] - a2 * si[e]);
-        o2[e] = (_Float16)(a2 * co[e] + a1 * si[e]);
+        // (explicit fma: the GEMM epilogue that rotates the rows of whole tiles — gemm_f16_p16.h, BH_EPI_ROTARY — writes the same expression)
+        // (and the fp32 results are rounded to fp16 by a conversion of their own — an opaque register keeps hipcc from fusing fma and
+        // conversion into v_fma_mix*_f16, whose single rounding differs from fma-then-convert in rare cases: both kernels do the same)
+        float r1 = __builtin_fmaf(-a2, si[e], a1 * co[e]);
+        float r2 = __builtin_fmaf(a1, si[e], a2 * co[e]);
+        asm volatile("" : "+v"(r1), "+v"(r2));
+        o1[e] = (_Float16)r1;
+        o2[e] = (_Float16)r2;
     }
     *reinterpret_cast<half8*>(x) = o1;
     *reinterpret_cast<half8*>(x + 32) = o2;

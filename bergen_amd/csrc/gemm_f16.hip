@@ -148,7 +148,36 @@ static int gemm_cu_count() {
 // ablations (results invalid); 33 = 7 with deferred stores and alternating loader teams; 10 = 7 with the last partial round of tiles re-cut into 128x128 tiles (experiment, measured neutral).
 bool bh_gemm_geglu_fusable() { return g_mfma16 != 0 && g_mfma16 < 16 && g_full_line_stores >= 2; }
 
+static hipError_t launch_gemm_impl(const BhGemmArgs& a_in, int variant, hipStream_t stream, long long* rot_rows);
+
+// BhGemmArgs::rot_pos set: the projection comes back with rotary positions applied — fused into the 16x16x32 kernel's epilogue for the rows
+// that kernel computes (launch_gemm_impl reports how many), by the standalone kernel for the rest (edge strips, small problems, other routes)
 hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t stream) {
+    if (!a_in.rot_pos) return launch_gemm_impl(a_in, variant, stream, nullptr);
+    if (!a_in.rot_cs || a_in.rot_max_pos <= 0 || !a_in.bias || a_in.bias_mode != 1 || a_in.N % 128 != 0 || a_in.ldc != a_in.N || a_in.gelu || a_in.swiglu ||
+        a_in.residual || a_in.c_block_rows || a_in.seg_out || a_in.ln_stats || a_in.stats_out)
+        return hipErrorInvalidValue;
+    if (a_in.M <= 0) return hipSuccess;
+    long long done = 0;
+    hipError_t e = launch_gemm_impl(a_in, variant, stream, &done);
+    if (e != hipSuccess) return e;
+    if (done < a_in.M) {
+        BhRotaryArgs ra{};
+        ra.qk = a_in.C + (size_t)done * a_in.ldc;
+        ra.pos = a_in.rot_pos + done;
+        ra.cos_sin = a_in.rot_cs;
+        ra.n_rows = a_in.M - done;
+        ra.n_heads = a_in.N / 128;
+        ra.max_pos = a_in.rot_max_pos;
+        e = bh_launch_rotary(ra, stream);
+    }
+    return e;
+}
+
+static int g_rotary_fused = 1;
+void bh_gemm_set_rotary_fused(int on) { g_rotary_fused = on ? 1 : 0; }
+
+static hipError_t launch_gemm_impl(const BhGemmArgs& a_in, int variant, hipStream_t stream, long long* rot_rows) {
     BhGemmArgs a = a_in;
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (a.K <= 0 || (a.K & 63) || (a.lda & 7) || (a.ldb & 7) || (a.ldc & 7) || (a.residual && (a.ldr & 7)))
@@ -291,9 +320,13 @@ hipError_t bh_launch_gemm_f16(const BhGemmArgs& a_in, int variant, hipStream_t s
             if (persist && g_mfma16 && (pst_eff == 33 || pst_eff == 35) &&
                 (epi == 0 || epi == BH_EPI_BIAS_COL || epi == (BH_EPI_BIAS_COL | BH_EPI_GELU) || (epi == BH_EPI_BIAS_ROW && t.c_block_rows))) {
                 t.tail_split = g_tail_split;
+                // rotary positions in the epilogue (BhGemmArgs::rot_pos; option rotary_fused): all columns must be this kernel's
+                int epi_l = epi;
+                if (rot_rows && a.rot_pos && g_rotary_fused && epi == BH_EPI_BIAS_COL && !t.c_block_rows && ni == a.N) epi_l |= BH_EPI_ROTARY;
                 // (gemm_mfma16 >= 16 are the bench-only ablation modes of the bias + GELU instantiation, profiles/gemm_p16_ablate.py:
                 // every other epilogue runs the production kernel — mode 1 — so that a forward pass never fails on them)
-                e = bh_gemm_p16(t, epi, pst_eff == 35, (g_mfma16 >= 16 && epi != (BH_EPI_BIAS_COL | BH_EPI_GELU)) ? 1 : g_mfma16, stream);
+                e = bh_gemm_p16(t, epi_l, pst_eff == 35, (g_mfma16 >= 16 && epi != (BH_EPI_BIAS_COL | BH_EPI_GELU)) ? 1 : g_mfma16, stream);
+                if (e == hipSuccess && (epi_l & BH_EPI_ROTARY)) *rot_rows = t.M;
             } else
                 e = persist ? bh_gemm_persist(t, epi, pst_eff, stream) : run_cfg(variant, t, epi, stream);
             if (e != hipSuccess) return e;

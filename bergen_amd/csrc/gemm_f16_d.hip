@@ -22,6 +22,7 @@ hipError_t p16_v(const BhGemmArgs& a, int epi, bool nontemporal, hipStream_t s) 
         case BH_EPI_BIAS_COL | BH_EPI_SWIGLU:
             return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, true>(a, n_cu(), s)
                                : bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_SWIGLU, false>(a, n_cu(), s);
+        case BH_EPI_BIAS_COL | BH_EPI_ROTARY: return bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_ROTARY, false>(a, n_cu(), s);
         case BH_EPI_BIAS_COL | BH_EPI_SWIGLU | BH_EPI_GELU:
             return nontemporal ? bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_SWIGLU | BH_EPI_GELU, true>(a, n_cu(), s)
                                : bh_gemm_launch_p16<BH_EPI_BIAS_COL | BH_EPI_SWIGLU | BH_EPI_GELU, false>(a, n_cu(), s);

@@ -20,6 +20,8 @@
 #define BH_EPI_RESLN 256   // persistent kernel, full-line stores: + residual rows (normalised on the fly when res_stats is set), and the
                            // per-row (sum, sum of squares) of the stored outputs into BhGemmArgs::stats_out
 
+#define BH_EPI_ROTARY 512  // 16x16x32 kernel only: rotate-half RoPE on the (bias-added) output by BhGemmArgs::rot_pos / rot_cs
+
 namespace bh_gemm {
 
 // erf-GELU, 0.5 x (1 + erf(x / sqrt 2)) = x Phi(x), without a transcendental instruction (round 5):

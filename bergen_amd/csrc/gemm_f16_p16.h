@@ -34,7 +34,8 @@ template <int EPI, bool NT, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(EPI == 0 || EPI == BH_EPI_BIAS_COL || EPI == (BH_EPI_BIAS_COL | BH_EPI_GELU) || EPI == BH_EPI_BIAS_ROW ||
-                      EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU) || EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU | BH_EPI_GELU),
+                      EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU) || EPI == (BH_EPI_BIAS_COL | BH_EPI_SWIGLU | BH_EPI_GELU) ||
+                      EPI == (BH_EPI_BIAS_COL | BH_EPI_ROTARY),
                   "epilogues of this kernel");
     constexpr int BK = 64, WN = 4, R = 2;
     constexpr int NW = 8;
@@ -272,6 +273,69 @@ __global__ void __launch_bounds__(512, 2) bh_gemm_f16_p16kernel(BhGemmArgs a) {
                         __builtin_nontemporal_store(v, p);
                     else
                         *p = v;
+                }
+                asm volatile("" ::: "memory");
+            }
+            return;
+        }
+        if constexpr ((EPI & BH_EPI_ROTARY) != 0) {
+            // Q | K projection with rotary positions (NomicBert, gte): the wave's 64 columns are ONE head slice; a lane holds, per 16-token block,
+            // columns 16 fb + 4 lg + e of it (fb < 4, e < 4): the rotate-half partner of column j < 32 is j + 32 = the SAME lane's value of
+            // feature block fb + 2.  x1' = x1 cos - x2 sin, x2' = x2 cos + x1 sin; cos / sin of the token's position from the fp32 table (L1 / L2 hits: a batch spans a few hundred positions),
+            // all of a part's loads issued before its arithmetic.  Stores as in the plain epilogue below.
+            const int rrow = lane >> 3, rch = lane & 7;
+            _Float16* gptr = a.C + (size_t)(m0 + wm * 16 * TBS + rrow) * a.ldc + rch * 8 + (size_t)(n0 + wn * 64);
+            half4 bias4[FB];
+#pragma unroll
+            for (int fb = 0; fb < FB; ++fb) bias4[fb] = *reinterpret_cast<const half4*>(a.bias + n0 + wn * 64 + fb * 16 + 4 * lg);
+#pragma unroll
+            for (int tp = 0; tp < (TBS + 1) / 2; ++tp) {
+                floatx4 co[2][2], si[2][2];  // [half_][fb]
+#pragma unroll
+                for (int half_ = 0; half_ < (TBS > 1 ? 2 : 1); ++half_) {
+                    int pos = a.rot_pos[m0 + wm * 16 * TBS + (2 * tp + half_) * 16 + q16];
+                    pos = pos < 0 ? 0 : pos < a.rot_max_pos ? pos : a.rot_max_pos - 1;
+                    const float* cs = a.rot_cs + (size_t)pos * 64 + 4 * lg;
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {
+                        co[half_][fb] = *reinterpret_cast<const floatx4*>(cs + fb * 16);
+                        si[half_][fb] = *reinterpret_cast<const floatx4*>(cs + 32 + fb * 16);
+                    }
+                }
+#pragma unroll
+                for (int half_ = 0; half_ < (TBS > 1 ? 2 : 1); ++half_) {
+                    const int tb = 2 * tp + half_;
+                    const int tr = half_ * 16 + q16;
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {
+                        half4 o1, o2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // (the projection is ROUNDED to fp16 before it is rotated, and the rotation is bh_rotary_kernel's expression, fma for
+                            // fma: rows of whole tiles and rows the standalone kernel rotates — edge strips, small batches — carry the same
+                            // bits, so a sequence's embedding does not depend on the batch it is encoded in)
+                            const float x1 = (float)(_Float16)(acc[tb][fb][e] + (float)bias4[fb][e]), x2 = (float)(_Float16)(acc[tb][fb + 2][e] + (float)bias4[fb + 2][e]);
+                            // (the fp32 results pass through an opaque register: hipcc otherwise selects v_fma_mix*_f16, which rounds the exact
+                            // fma ONCE to fp16 — the standalone kernel rounds to fp32 first: one double-rounding case in a few thousand, enough
+                            // to move 10 % of a layer's outputs by an ulp)
+                            float r1 = __builtin_fmaf(-x2, si[half_][fb][e], x1 * co[half_][fb][e]);
+                            float r2 = __builtin_fmaf(x1, si[half_][fb][e], x2 * co[half_][fb][e]);
+                            asm volatile("" : "+v"(r1), "+v"(r2));
+                            o1[e] = (_Float16)r1;
+                            o2[e] = (_Float16)r2;
+                        }
+                        acc[tb][fb] = floatx4{0.f, 0.f, 0.f, 0.f};
+                        acc[tb][fb + 2] = floatx4{0.f, 0.f, 0.f, 0.f};
+                        const int c1 = fb * 2 + (lg >> 1), c2 = (fb + 2) * 2 + (lg >> 1);
+                        *reinterpret_cast<half4*>(stg + tr * 128 + ((c1 ^ ((tr >> 1) & 7)) << 4) + (lg & 1) * 8) = o1;
+                        *reinterpret_cast<half4*>(stg + tr * 128 + ((c2 ^ ((tr >> 1) & 7)) << 4) + (lg & 1) * 8) = o2;
+                    }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < (TBS > 1 ? 4 : 2); ++i) {
+                    const half8 v = *reinterpret_cast<const half8*>(stg + (8 * i + rrow) * 128 + ((rch ^ (((8 * i + rrow) >> 1) & 7)) << 4));
+                    *reinterpret_cast<half8*>(gptr + (size_t)(tp * 32 + 8 * i) * a.ldc) = v;
                 }
                 asm volatile("" ::: "memory");
             }

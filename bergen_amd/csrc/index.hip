@@ -373,6 +373,9 @@ int bh_set_option(const char* name, int64_t value) {
     } else if (s == "gemm_mfma16") {
         if (value < 0 || value > 511 || (value > 1 && (value & 15) != 1)) return fail(BH_EINVAL, "gemm_mfma16 must be 0, 1 or 16 x ablation bits + 1");
         bh_gemm_set_mfma16((int)value);
+    } else if (s == "gemm_rotary_fused") {
+        if (value != 0 && value != 1) return fail(BH_EINVAL, "gemm_rotary_fused must be 0 or 1");
+        bh_gemm_set_rotary_fused((int)value);
     } else if (s == "ln_small") {
         if (value != 0 && value != 1) return fail(BH_EINVAL, "ln_small must be 0 or 1");
         bh_ln_set_small((int)value);

@@ -16,7 +16,11 @@ if arch == "e5_large":
     cfg.update(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
 if arch == "nomic":
     cfg.update(model_type="nomic_bert", hidden_act="silu", vocab_size=30528, max_position_embeddings=2048, rope_theta=1000.0)
-sd = synth.random_nomic(cfg, seed=33, scale=0.02) if arch == "nomic" else synth.random_bert(cfg, seed=31)
+if arch == "gte":
+    cfg = dict(model_type="new", vocab_size=30528, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+               hidden_act="gelu", max_position_embeddings=8192, type_vocab_size=0, layer_norm_type="layer_norm", layer_norm_eps=1e-12,
+               position_embedding_type="rope", rope_theta=500000.0, rope_scaling={"type": "ntk", "factor": 2.0})
+sd = synth.random_nomic(cfg, seed=33, scale=0.02) if arch == "nomic" else synth.random_new(cfg, seed=37, scale=0.02) if arch == "gte" else synth.random_bert(cfg, seed=31)
 enc = BertEncoder(cfg, {k: torch.from_numpy(v) for k, v in sd.items()}, device=0)
 for kv in sys.argv[3:]:
     name, val = kv.split("=")
@@ -28,7 +32,7 @@ T = int(lens.max())
 mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
 ids = rng.integers(1, cfg["vocab_size"], size=(batch, T)).astype(np.int64) * mask
 kw = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
-pool = "cls" if arch == "bert" else "mean"
+pool = "cls" if arch in ("bert", "gte") else "mean"
 enc.encode_pooled(kw, pool)
 ms = []
 for _ in range(steps):

@@ -94,6 +94,14 @@ def test_base_width_layers_take_the_fused_path_and_match_the_oracle():
     # a sequence alone runs the unfused fold (fewer than half a chip of tiles): fp16 round-off apart from the fused batch, same bound
     alone = enc.encode_pooled({k: v[3:4] for k, v in kw.items()}, "cls")
     _close(alone.float().cpu().numpy(), want[3:4], "one sequence alone (unfused fold)")
+    # NTK-scaled rotary positions in the Q | K GEMM's epilogue vs the standalone kernel on all rows: the same bits
+    from bergen_amd import _lib
+    try:
+        _lib.set_option("gemm_rotary_fused", 0)
+        standalone = enc.encode_pooled(kw, "cls")
+    finally:
+        _lib.set_option("gemm_rotary_fused", 1)
+    assert torch.equal(standalone.view(torch.int16), got.view(torch.int16)), "fused and standalone rotary must agree bit for bit"
     # with the fused fold switched off the batch and the lone sequence agree bit for bit (batch-composition invariance of one path)
     enc.set_option("ffn_fused", 0)
     b0 = enc.encode_pooled(kw, "cls")

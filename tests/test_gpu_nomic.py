@@ -114,6 +114,15 @@ def test_encoder_nomic_embed_shape_against_oracle():
     enc.set_option("micro_batches", 1)
     one = enc.encode_pooled(kw, "mean")
     assert torch.equal(one, got), "one micro-batch and two must agree bit for bit"
+    enc.set_option("micro_batches", 2)
+    # rotary positions in the Q | K GEMM's epilogue (rows of whole tiles; round 6) and by the standalone kernel (all rows): the same bits
+    from bergen_amd import _lib
+    try:
+        _lib.set_option("gemm_rotary_fused", 0)
+        standalone = enc.encode_pooled(kw, "mean")
+    finally:
+        _lib.set_option("gemm_rotary_fused", 1)
+    assert torch.equal(standalone, got), "fused and standalone rotary must agree bit for bit"
     # the unfused feed-forward (plain GEMM into [rows][2 dff] + the fold kernel: what small batches run) meets the same bound
     enc.set_option("ffn_fused", 0)
     unfused = enc.encode_pooled(kw, "mean")
