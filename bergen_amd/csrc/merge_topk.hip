@@ -10,7 +10,7 @@
 //     by binary search: (n_lists - 1) * log2(k) steps per entry.  (Round 6: the one-GPU proxy of the whole 8-GPU search showed the
 //     all-pairs count below taking 2.45 ms for 8 lists of 200 on rank 0's critical path — 28 % of the step it follows.)
 //   * The entry point accepts ANY lists (the reference's host merge, torch.cat + torch.topk, does): every workgroup first checks
-//     that its query's lists are sorted, and counts all pairs — O(M^2), M a few hundred to ~1600 — when one is not.
+//     that its query's lists are sorted, and sorts them in LDS (rank inside the own list: k compares per entry) when one is not.
 #include "bh_device.h"
 #include "bh_kernels.h"
 
@@ -56,46 +56,60 @@ __global__ void __launch_bounds__(256) bh_merge_lists_kernel(const float* __rest
     }
     if (bad) s_unsorted = 1;
     __syncthreads();
-    const bool sorted = s_unsorted == 0;
+    if (s_unsorted != 0) {
+        // Arbitrary input (an external caller's lists): sort every list in place first — an entry's position inside its own list by counting
+        // that list's entries that precede it (k compares per entry instead of the M an all-pairs rank over all lists takes: 8 x 200 entries
+        // 0.68 -> ~0.1 ms for the one workgroup that needs it), padding behind the valid entries in index order.  Every thread holds its
+        // entries in registers across the barrier, so the permutation needs no second buffer.
+        constexpr int PER = (BH_MERGE_MAX + 255) / 256;
+        float rs[PER];
+        long long ri[PER];
+        int rp[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = threadIdx.x + u * 256;
+            rp[u] = -1;
+            if (i < M) {
+                const int l = i / k, base = l * k;
+                rs[u] = s_sc[i];
+                ri[u] = s_id[i];
+                int pos = 0;
+                if (ri[u] >= 0) {
+                    for (int j = base; j < base + k; ++j) pos += precedes(j, rs[u], ri[u], i) ? 1 : 0;
+                } else {
+                    for (int j = base; j < base + k; ++j) pos += (s_id[j] >= 0 || j < i) ? 1 : 0;  // every valid entry, and the padding before it
+                }
+                rp[u] = base + pos;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (rp[u] >= 0) {
+                s_sc[rp[u]] = rs[u];
+                s_id[rp[u]] = ri[u];
+            }
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
         const long long id = s_id[i];
         if (id < 0) continue;
         const float sc = s_sc[i];
-        int rank = 0;
-        if (sorted) {
-            const int l = i / k;
-            rank = i - l * k;  // its own list's entries before it
-            for (int lo = 0; lo < n_lists && rank < k; ++lo) {  // (rank >= k: not in the result, whatever the other lists add)
-                if (lo == l) continue;
-                // the prefix of list lo that precedes entry i: first position whose entry does not.  Only prefixes shorter than
-                // k - rank matter (a longer one pushes the entry out of the result all the same): the search is bounded by it
-                int a = 0, b = k - rank;
-                while (a < b) {
-                    const int mid = (a + b) >> 1;
-                    if (precedes(lo * k + mid, sc, id, i))
-                        a = mid + 1;
-                    else
-                        b = mid;
-                }
-                rank += a;
+        const int l = i / k;
+        int rank = i - l * k;  // its own list's entries before it
+        for (int lo = 0; lo < n_lists && rank < k; ++lo) {  // (rank >= k: not in the result, whatever the other lists add)
+            if (lo == l) continue;
+            // the prefix of list lo that precedes entry i: first position whose entry does not.  Only prefixes shorter than
+            // k - rank matter (a longer one pushes the entry out of the result all the same): the search is bounded by it
+            int a = 0, b = k - rank;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (precedes(lo * k + mid, sc, id, i))
+                    a = mid + 1;
+                else
+                    b = mid;
             }
-        } else {
-            // all pairs, eight entries per step: the reads of a step are independent (a block is four waves on a CU of its own when
-            // few queries are unsorted — one LDS round trip per entry made this path 1.2 ms per query of 8 x 200 entries)
-            int j = 0;
-            for (; j + 8 <= M; j += 8) {
-                float scj[8];
-                long long idj[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    scj[u] = s_sc[j + u];
-                    idj[u] = s_id[j + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    rank += ((idj[u] >= 0) && ((scj[u] > sc) || (scj[u] == sc && (idj[u] < id || (idj[u] == id && j + u < i))))) ? 1 : 0;
-            }
-            for (; j < M; ++j) rank += precedes(j, sc, id, i) ? 1 : 0;
+            rank += a;
         }
         if (rank < k) {
             out_scores[(size_t)q * k + rank] = sc;

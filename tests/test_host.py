@@ -498,7 +498,17 @@ def test_reference_model_families_resolve_to_the_hip_forward_pass():
                               relative_attention=True, position_buckets=256, norm_rel_ebd="layer_norm", share_att_key=True,
                               pos_att_type=["p2c", "c2p"], position_biased_input=False, max_relative_positions=-1))
     assert (deb["rel_span"], deb["max_relative_positions"], deb["head_dim"], deb["type_vocab_size"]) == (256, 512, 64, 1)
-    assert not BertEncoder.supports(NS(config=NS(model_type="new")))
+    assert not BertEncoder.supports(NS(config=NS(model_type="new")))  # (a "new" config without its fields: refused, not guessed)
+    # round 6: the remote architectures of gte-base / gte-large-en-v1.5 and jina-embeddings-v2-base-en (their published config.json fields)
+    gte = canonical_config(NS(model_type="new", hidden_size=1024, num_attention_heads=16, num_hidden_layers=24, intermediate_size=4096, hidden_act="gelu",
+                              vocab_size=30528, max_position_embeddings=8192, type_vocab_size=0, layer_norm_type="layer_norm", layer_norm_eps=1e-12,
+                              position_embedding_type="rope", rope_theta=160000, rope_scaling={"type": "ntk", "factor": 2.0}, pack_qkv=True,
+                              unpad_inputs=False, use_memory_efficient_attention=False, logn_attention_scale=False, logn_attention_clip1=False))
+    assert (gte["ffn_gated"], gte["hidden_act"], gte["rotary_theta"], gte["head_dim"], gte["self_check"]) == (1, "gelu", 320000.0, 64, True)
+    jina = canonical_config(NS(model_type="bert", hidden_size=768, num_attention_heads=12, num_hidden_layers=12, intermediate_size=3072, hidden_act="gelu",
+                               vocab_size=30528, max_position_embeddings=8192, type_vocab_size=2, layer_norm_eps=1e-12, position_embedding_type="alibi",
+                               feed_forward_type="geglu", emb_pooler="mean"))
+    assert (jina["alibi"], jina["ffn_gated"], jina["self_check"], jina["head_dim"]) == (1, 1, True, 64)
 
 
 def test_head_padding_keeps_the_attention_arithmetic():
