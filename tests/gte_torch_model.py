@@ -21,18 +21,20 @@ def new_config(**kw):
 
 
 class _Rotary(nn.Module):
+    """cos / sin of RotaryEmbedding (factor None) or NTKScalingRotaryEmbedding with mixed_b None, whose cache is built for max_pos * factor
+    positions, i.e. always in the scaled regime.  No buffers: the frequencies are recomputed in forward (nothing for a loader to mishandle)."""
+
     def __init__(self, dim, max_pos, base, factor):
         super().__init__()
-        if factor is not None:  # NTKScalingRotaryEmbedding, mixed_b None: the cache is built for max_pos * factor positions
-            base = base * factor
-        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
-        if factor is not None:
-            inv_freq = inv_freq / factor ** (2 / dim)
-        self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self.dim, self.base, self.factor = int(dim), float(base), (None if factor is None else float(factor))
 
     def forward(self, seq_len):
+        base = self.base * self.factor if self.factor is not None else self.base
+        inv_freq = 1.0 / (base ** (torch.arange(0, self.dim, 2).float() / self.dim))
+        if self.factor is not None:
+            inv_freq = inv_freq / self.factor ** (2 / self.dim)
         t = torch.arange(seq_len, dtype=torch.float32)
-        freqs = torch.outer(t, self.inv_freq.float().cpu())
+        freqs = torch.outer(t, inv_freq)
         emb = torch.cat((freqs, freqs), dim=-1)
         return emb.cos(), emb.sin()
 
@@ -216,3 +218,71 @@ class TorchJinaBert(nn.Module):
             h = torch.nn.functional.gelu(h[..., : c.intermediate_size]) * h[..., c.intermediate_size:]
             x = L.mlp.layernorm(L.mlp.wo(h) + x)
         return (x,)
+
+
+# ---- a REMOTE-CODE checkpoint directory of the "new" class: what `AutoModel.from_pretrained(path, trust_remote_code=True)` (reference
+# models/retrievers/dense.py:16) loads for gte-*-en-v1.5, offline — configuration_new.py / modeling_new.py beside the weights, auto_map in config.json
+
+_CONFIGURATION_PY = """
+from transformers import PretrainedConfig
+
+
+class NewConfig(PretrainedConfig):
+    model_type = "new"
+
+    def __init__(self, vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, hidden_act="gelu",
+                 max_position_embeddings=128, type_vocab_size=0, layer_norm_type="layer_norm", layer_norm_eps=1e-12, position_embedding_type="rope",
+                 rope_theta=500000.0, rope_scaling=None, pack_qkv=True, unpad_inputs=False, use_memory_efficient_attention=False,
+                 logn_attention_scale=False, logn_attention_clip1=False, **kwargs):
+        super().__init__(**kwargs)
+        self.vocab_size, self.hidden_size, self.num_hidden_layers, self.num_attention_heads = vocab_size, hidden_size, num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.hidden_act, self.max_position_embeddings, self.type_vocab_size = intermediate_size, hidden_act, max_position_embeddings, type_vocab_size
+        self.layer_norm_type, self.layer_norm_eps, self.position_embedding_type = layer_norm_type, layer_norm_eps, position_embedding_type
+        self.rope_theta, self.rope_scaling, self.pack_qkv, self.unpad_inputs = rope_theta, rope_scaling, pack_qkv, unpad_inputs
+        self.use_memory_efficient_attention, self.logn_attention_scale, self.logn_attention_clip1 = use_memory_efficient_attention, logn_attention_scale, logn_attention_clip1
+"""
+
+_MODELING_TAIL = """
+
+from transformers import PreTrainedModel
+
+from .configuration_new import NewConfig
+
+
+class NewModel(PreTrainedModel):
+    config_class = NewConfig
+    base_model_prefix = "new"
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__(config)
+        self.embeddings = _Embeddings(config)
+        self.encoder = _Encoder(config)
+        self.break_it = None
+        self.post_init()
+
+    def _init_weights(self, module):
+        pass
+
+    forward = TorchNewModel.forward
+"""
+
+
+def write_remote_code_checkpoint(path, config_kwargs=None, seed=0):
+    """Save a seeded TorchNewModel as a checkpoint directory with its modelling code beside the weights (fp16 safetensors, config.json with
+    auto_map).  Returns the reference module (fp32, eval) whose weights were written."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    cfg = new_config(**(config_kwargs or {}))
+    model = TorchNewModel(cfg, seed=seed).eval()
+    os.makedirs(path, exist_ok=True)
+    here = open(os.path.abspath(__file__)).read()
+    body = here[: here.index("# ---- JinaBert")]  # the "new" classes only
+    open(os.path.join(path, "configuration_new.py"), "w").write(_CONFIGURATION_PY)
+    open(os.path.join(path, "modeling_new.py"), "w").write(body + _MODELING_TAIL)
+    conf = {k: v for k, v in vars(cfg).items() if not k.startswith("_")}
+    conf.update(architectures=["NewModel"], auto_map={"AutoConfig": "configuration_new.NewConfig", "AutoModel": "modeling_new.NewModel"},
+                torch_dtype="float16")
+    json.dump(conf, open(os.path.join(path, "config.json"), "w"), indent=1)
+    save_file({k: v.half().contiguous() for k, v in model.state_dict().items()}, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    return model

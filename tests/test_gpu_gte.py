@@ -182,3 +182,31 @@ def test_jina_alibi_model_matches_the_oracle_and_passes_its_self_check(heads, hi
     ms = mask[2:, :97].astype(np.float64)[..., None]
     _close(got, (hs * ms).sum(1) / ms.sum(1), "jina mean-pooled (4-wave attention)")
     enc.close()
+
+
+def test_dense_loads_a_remote_code_checkpoint_onto_the_hip_path(tmp_path):
+    """The reference's own route for gte-*-en-v1.5: `AutoModel.from_pretrained(model_name, trust_remote_code=True)` (models/retrievers/dense.py:16)
+    on a checkpoint directory that carries its modelling code (configuration_new.py / modeling_new.py, auto_map in config.json) — here the torch
+    restatement of tests/gte_torch_model.py written out as such a directory, loaded offline.  bergen_amd.Dense must put it on the HIP forward pass
+    (self-check against the loaded remote module passed) and return that module's CLS embeddings."""
+    import transformers as T
+    import bergen_amd
+    from gte_torch_model import write_remote_code_checkpoint
+    from test_gpu_hf_path import TEXTS, WORDS
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    vocab = ["[CLS]", "[PAD]", "[SEP]", "[UNK]", "[MASK]"] + WORDS + ["?", ".", ","]
+    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer(lowercase=True)
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1", special_tokens=[("[CLS]", 0), ("[SEP]", 2)])
+    tok = T.PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]", mask_token="[MASK]",
+                                    model_input_names=["input_ids", "attention_mask"])
+    path = str(tmp_path / "gte-remote")
+    ref = write_remote_code_checkpoint(path, dict(vocab_size=len(vocab), max_position_embeddings=64), seed=11)
+    tok.save_pretrained(path)
+    dense = bergen_amd.Dense(model_name=path, max_len=32, pooler=bergen_amd.ClsPooler(), similarity=bergen_amd.CosineSim(), require_native=True)
+    assert dense.backend == "hip" and dense.model.needs_self_check and dense.model.self_check_result["min_cosine"] >= 0.995
+    batch = dense.collate_fn([{"content": x} for x in TEXTS], "doc")
+    got = dense("doc", batch)["embedding"].float().cpu().numpy()
+    want = ref(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"])[0][:, 0].numpy()
+    _close(got, want, "Dense(model_name=<remote-code checkpoint>) CLS embeddings")

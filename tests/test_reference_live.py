@@ -75,3 +75,40 @@ def test_reference_golden_runs_pin_format_only():
     q, d, s = utils.load_trec(f)
     assert len(q) > 0 and all(len(x) == 50 for x in d)
     assert all(all(a >= b for a, b in zip(x, x[1:])) for x in s)
+
+
+def test_reference_dense_on_a_remote_code_checkpoint_vs_the_new_oracle(tmp_path):
+    """The reference's route for gte-*-en-v1.5 end to end on CPU: its UNMODIFIED `Dense(model_name=<directory>)` calls
+    `AutoModel.from_pretrained(..., trust_remote_code=True)` (models/retrievers/dense.py:16), which imports the modelling code that lies
+    beside the weights — here tests/gte_torch_model.py's restatement of the "new" class written out as such a checkpoint (the real remote
+    file is not available offline: parity with IT stays unpinned, oracle/new_oracle.py).  The reference's ClsPooler output must equal the
+    numpy oracle's on the same token ids."""
+    import transformers as T
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from oracle import new_oracle
+    from gte_torch_model import write_remote_code_checkpoint
+    ref = ref_import.load()
+    words = ["the", "a", "of", "river", "city", "music", "science", "history", "water", "energy", "planet", "what", "is", "capital"]
+    vocab = ["[CLS]", "[PAD]", "[SEP]", "[UNK]", "[MASK]"] + words
+    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer(lowercase=True)
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1", special_tokens=[("[CLS]", 0), ("[SEP]", 2)])
+    tok = T.PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]", mask_token="[MASK]",
+                                    model_input_names=["input_ids", "attention_mask"])
+    path = str(tmp_path / "gte-remote")
+    cfg_kw = dict(vocab_size=len(vocab), max_position_embeddings=64)
+    torch_ref = write_remote_code_checkpoint(path, cfg_kw, seed=17)
+    tok.save_pretrained(path)
+    dense = ref.dense.Dense(model_name=path, max_len=32, pooler=ref.dense.ClsPooler(), similarity=ref.dense.CosineSim())
+    assert type(dense.model).__name__ == "NewModel" and dense.model.config.model_type == "new"
+    dense.model = dense.model.float()  # (the reference loads fp16; fp32 on the CPU for a tight comparison)
+    dense.query_encoder = dense.model
+    texts = ["the capital of the city", "what is music", "water energy planet river", "history"]
+    batch = dense.collate_fn([{"content": x} for x in texts], "doc")
+    with torch.no_grad():
+        emb = dense("doc", {k: v for k, v in batch.items()})["embedding"].float().numpy()
+    sd = {k: v.numpy() for k, v in torch_ref.state_dict().items()}
+    cfg = dict(vars(torch_ref.config))
+    want = new_oracle.encode(sd, cfg, batch["input_ids"].numpy(), batch["attention_mask"].numpy(), pooler="cls")
+    np.testing.assert_allclose(emb, want, rtol=0, atol=2e-4)
