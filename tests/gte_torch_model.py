@@ -286,3 +286,65 @@ def write_remote_code_checkpoint(path, config_kwargs=None, seed=0):
     json.dump(conf, open(os.path.join(path, "config.json"), "w"), indent=1)
     save_file({k: v.half().contiguous() for k, v in model.state_dict().items()}, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
     return model
+
+
+_JINA_CONFIGURATION_PY = """
+from transformers import PretrainedConfig
+
+
+class JinaBertConfig(PretrainedConfig):
+    model_type = "bert"
+
+    def __init__(self, vocab_size=600, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, hidden_act="gelu",
+                 max_position_embeddings=128, type_vocab_size=2, layer_norm_eps=1e-12, position_embedding_type="alibi", feed_forward_type="geglu",
+                 emb_pooler="mean", **kwargs):
+        super().__init__(**kwargs)
+        self.vocab_size, self.hidden_size, self.num_hidden_layers, self.num_attention_heads = vocab_size, hidden_size, num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.hidden_act, self.max_position_embeddings, self.type_vocab_size = intermediate_size, hidden_act, max_position_embeddings, type_vocab_size
+        self.layer_norm_eps, self.position_embedding_type, self.feed_forward_type, self.emb_pooler = layer_norm_eps, position_embedding_type, feed_forward_type, emb_pooler
+"""
+
+_JINA_MODELING_TAIL = """
+
+from transformers import PreTrainedModel
+
+from .configuration_bert import JinaBertConfig
+
+
+class JinaBertModel(PreTrainedModel):
+    config_class = JinaBertConfig
+    base_model_prefix = "bert"
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__(config)
+        inner = TorchJinaBert(config, seed=0)
+        self.embeddings = inner.embeddings
+        self.encoder = inner.encoder
+        self.post_init()
+
+    def _init_weights(self, module):
+        pass
+
+    forward = TorchJinaBert.forward
+"""
+
+
+def write_jina_remote_code_checkpoint(path, config_kwargs=None, seed=0):
+    """The same for JinaBert (jina-embeddings-v2): model_type "bert" whose auto_map names the remote JinaBertModel."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    cfg = jina_config(**(config_kwargs or {}))
+    model = TorchJinaBert(cfg, seed=seed).eval()
+    os.makedirs(path, exist_ok=True)
+    here = open(os.path.abspath(__file__)).read()
+    head = here[: here.index("def new_config(")]                                    # imports
+    body = here[here.index("# ---- JinaBert"): here.index("# ---- a REMOTE-CODE checkpoint directory")]  # the JinaBert classes only
+    open(os.path.join(path, "configuration_bert.py"), "w").write(_JINA_CONFIGURATION_PY)
+    open(os.path.join(path, "modeling_bert.py"), "w").write(head + body + _JINA_MODELING_TAIL)
+    conf = {k: v for k, v in vars(cfg).items() if not k.startswith("_")}
+    conf.update(architectures=["JinaBertModel"], auto_map={"AutoConfig": "configuration_bert.JinaBertConfig", "AutoModel": "modeling_bert.JinaBertModel"},
+                torch_dtype="float16")
+    json.dump(conf, open(os.path.join(path, "config.json"), "w"), indent=1)
+    save_file({k: v.half().contiguous() for k, v in model.state_dict().items()}, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    return model

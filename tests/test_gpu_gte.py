@@ -210,3 +210,30 @@ def test_dense_loads_a_remote_code_checkpoint_onto_the_hip_path(tmp_path):
     got = dense("doc", batch)["embedding"].float().cpu().numpy()
     want = ref(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"])[0][:, 0].numpy()
     _close(got, want, "Dense(model_name=<remote-code checkpoint>) CLS embeddings")
+
+
+def test_dense_loads_a_jina_remote_code_checkpoint_onto_the_hip_path(tmp_path):
+    """The same route for jina-embeddings-v2 (config/retriever/jina-embeddings-v2-base-en.yaml: MeanPooler + CosineSim): model_type "bert" whose
+    auto_map names a remote JinaBertModel (ALiBi, GELU-gated feed-forward)."""
+    import transformers as T
+    import bergen_amd
+    from gte_torch_model import write_jina_remote_code_checkpoint
+    from test_gpu_hf_path import TEXTS, WORDS
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    vocab = ["[CLS]", "[PAD]", "[SEP]", "[UNK]", "[MASK]"] + WORDS + ["?", ".", ","]
+    t = Tokenizer(models.WordPiece({w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer(lowercase=True)
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", pair="[CLS] $A [SEP] $B:1 [SEP]:1", special_tokens=[("[CLS]", 0), ("[SEP]", 2)])
+    tok = T.PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]", mask_token="[MASK]",
+                                    model_input_names=["input_ids", "token_type_ids", "attention_mask"])
+    path = str(tmp_path / "jina-remote")
+    ref = write_jina_remote_code_checkpoint(path, dict(vocab_size=len(vocab), max_position_embeddings=64), seed=13)
+    tok.save_pretrained(path)
+    dense = bergen_amd.Dense(model_name=path, max_len=32, pooler=bergen_amd.MeanPooler(), similarity=bergen_amd.CosineSim(), require_native=True)
+    assert dense.backend == "hip" and dense.model.needs_self_check and dense.model.self_check_result["min_cosine"] >= 0.995
+    batch = dense.collate_fn([{"content": x} for x in TEXTS], "doc")
+    got = dense("doc", batch)["embedding"].float().cpu().numpy()
+    hidden = ref(**{k: v for k, v in batch.items()})[0]
+    want = bergen_amd.MeanPooler.pool(hidden, batch["attention_mask"]).numpy()
+    _close(got, want, "Dense(model_name=<jina remote-code checkpoint>) mean embeddings")
