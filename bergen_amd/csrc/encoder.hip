@@ -431,6 +431,9 @@ int bh_encoder_create(bh_encoder** out, const bh_encoder_config* cfg) {
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_mb_fork, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming);
+        // (round 6: a stream priority for the micro-batch streams — hipStreamCreateWithPriority, high or low — changes nothing: 13.59 / 13.61 /
+        // 13.58 ms, profiles/r06l_ab_mb_priority.txt.  Persistent GEMMs of the two streams do not share CUs workgroup by workgroup anyway: the
+        // second one's workgroups start as the first one's exit)
         for (int m = 0; m < bh_encoder::kMaxMicroBatches - 1 && he == hipSuccess; ++m) {
             he = hipStreamCreateWithFlags(&e->mb_stream[m], hipStreamNonBlocking);
             if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_mb_join[m], hipEventDisableTiming);
