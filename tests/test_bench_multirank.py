@@ -123,6 +123,11 @@ def test_scan_roofline_accounts_for_paired_unpaired_and_tail_launches():
     assert r["hbm_bytes_needed_per_launch"] == n * d * 2.0 + 2 * (256 * d * 2.0 + 256 * k * 12.0) and r["traffic"] is None
     assert r["unpaired_launch"]["launches"] == steps and abs(r["unpaired_launch"]["avg_launch_ms"] - 7.3) < 1e-9
     assert abs(r["tail_pass"]["avg_launch_ms"] - 5.0) < 1e-9
+    # the two rooflines side by side, each self-consistent; `bound` names the one that binds (round-5 review: "hbm" stood beside binding "mfma")
+    assert r["hbm"]["unit"] == "GB/s" and r["hbm"]["frac"] == r["frac"] and r["hbm"]["peak"] == 8000.0
+    assert r["mfma"]["unit"] == "TFLOP/s" and r["mfma"]["frac"] == r["mfma_frac"] and abs(r["mfma"]["achieved"] - 2 * 2.0 * 256 * n * d / 13.4e-3 / 1e12) < 1e-6
+    assert r["bound"] == r["binding_resource"] == ("mfma" if r["mfma_frac"] >= r["hbm_frac_of_needed_bytes"] else "hbm")
+    assert r["mfma_busy_frac"] is None or 0.0 < r["mfma_busy_frac"] < 1.0  # (from profiles/sq_counters.json when the kernel source is unchanged)
     # the figure that cannot be misread: the larger of (bytes the launch must move) / time / peak and flops / time / peak
     assert r["algorithmic_frac"] == r["frac"] and r["binding_resource"] == "mfma"
     assert abs(r["frac_binding"] - 2.0 * 2 * 256 * n * d / 13.4e-3 / 1e12 / 2500.0) < 1e-9 and r["frac_binding"] < r["frac"]
